@@ -1,0 +1,435 @@
+// TEST INFRASTRUCTURE ONLY -- flat C entry points (ctypes) over the CPU oracle in oracle/*.hpp.
+// Used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product.
+// PARITY UNPINNED (see field.hpp / DESIGN.md).
+//
+// Encodings are those of include/pcdhip.h: field element = N little-endian u64 limbs in Montgomery
+// form (R = 2^(64N)); extension element = consecutive base elements c0,c1(,c2); affine point = x||y
+// with a separate infinity byte; Jacobian = X||Y||Z (Z = 0 => infinity); scalars canonical.
+#include <algorithm>
+#include <vector>
+
+#include "groth16.hpp"
+
+using namespace orc;
+
+namespace {
+
+struct SplitMix {
+  u64 s;
+  explicit SplitMix(u64 seed) : s(seed) {}
+  u64 next() {
+    u64 z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+};
+
+template <class F>  // uniform canonical value < p (rejection sampling on the top bits)
+void rand_canonical(SplitMix& g, u64* out) {
+  typedef typename F::Params P;
+  constexpr int N = F::N;
+  const int top_bits = P::BITS - 64 * (N - 1);
+  for (;;) {
+    for (int i = 0; i < N; i++) out[i] = g.next();
+    out[N - 1] &= (top_bits == 64) ? ~0ull : (((u64)1 << top_bits) - 1);
+    if (!F::geq_mod(out)) return;
+  }
+}
+
+template <class F>
+void load_affine(const u64* xy, const uint8_t* inf, size_t n, std::vector<Affine<F>>& out) {
+  constexpr size_t EL = sizeof(F) / sizeof(u64);
+  out.resize(n);
+  for (size_t i = 0; i < n; i++) {
+    memcpy((void*)&out[i].x, xy + i * 2 * EL, sizeof(F));
+    memcpy((void*)&out[i].y, xy + i * 2 * EL + EL, sizeof(F));
+    out[i].inf = inf ? inf[i] != 0 : false;
+  }
+}
+template <class F>
+Affine<F> load_affine1(const u64* xy, bool inf = false) {
+  Affine<F> r;
+  constexpr size_t EL = sizeof(F) / sizeof(u64);
+  memcpy((void*)&r.x, xy, sizeof(F));
+  memcpy((void*)&r.y, xy + EL, sizeof(F));
+  r.inf = inf;
+  return r;
+}
+template <class F>
+void store_affine(const Affine<F>& p, u64* xy, uint8_t* inf) {
+  constexpr size_t EL = sizeof(F) / sizeof(u64);
+  if (p.inf) { memset(xy, 0, 2 * sizeof(F)); } else { memcpy(xy, &p.x, sizeof(F)); memcpy(xy + EL, &p.y, sizeof(F)); }
+  if (inf) *inf = p.inf ? 1 : 0;
+}
+template <class F>
+void store_jac(const Jac<F>& p, u64* xyz) { memcpy(xyz, &p, 3 * sizeof(F)); }
+template <class F>
+Jac<F> load_jac(const u64* xyz) { Jac<F> p; memcpy((void*)&p, xyz, 3 * sizeof(F)); return p; }
+
+// batch normalisation (Montgomery's trick)
+template <class F>
+void batch_to_affine(const Group<F>& G, const std::vector<Jac<F>>& in, std::vector<Affine<F>>& out) {
+  size_t n = in.size();
+  out.resize(n);
+  std::vector<F> pre(n);
+  F acc = F::one();
+  for (size_t i = 0; i < n; i++) { pre[i] = acc; if (!in[i].is_inf()) acc = acc * in[i].Z; }
+  F inv = acc.inv();
+  for (size_t i = n; i-- > 0;) {
+    if (in[i].is_inf()) { out[i] = Affine<F>::infinity(); continue; }
+    F zi = inv * pre[i];
+    inv = inv * in[i].Z;
+    F zi2 = zi.sqr();
+    out[i] = {in[i].X * zi2, in[i].Y * zi2 * zi, false};
+  }
+  (void)G;
+}
+
+template <class C, class F>
+int gen_points_impl(const Group<F>& G, const Affine<F>& gen, size_t n, u64 seed, u64* xy) {
+  typedef typename C::Fr Fr;
+  SplitMix g(seed);
+  u64 k0[Fr::N], k1[Fr::N];
+  rand_canonical<Fr>(g, k0);
+  rand_canonical<Fr>(g, k1);
+  Jac<F> P = G.mul(Jac<F>::from_affine(gen), k0, Fr::N);
+  Affine<F> D = G.to_affine(G.mul(Jac<F>::from_affine(gen), k1, Fr::N));
+  const size_t CH = 4096;
+  std::vector<Jac<F>> buf;
+  std::vector<Affine<F>> aff;
+  for (size_t base = 0; base < n; base += CH) {
+    size_t cnt = std::min(CH, n - base);
+    buf.resize(cnt);
+    for (size_t i = 0; i < cnt; i++) { buf[i] = P; P = G.madd(P, D); }
+    batch_to_affine(G, buf, aff);
+    for (size_t i = 0; i < cnt; i++) store_affine(aff[i], xy + (base + i) * 2 * (sizeof(F) / sizeof(u64)), nullptr);
+  }
+  return 0;
+}
+
+template <class C, class F>
+F curve_b() {
+  if constexpr (F::DEG == 1) return C::b(); else return C::twist_b();
+}
+
+template <class F>
+Csr<F> mk_csr(size_t rows, const u64* row_ptr, const uint32_t* col, const u64* coeff) {
+  return {rows, row_ptr, col, reinterpret_cast<const F*>(coeff)};
+}
+
+}  // namespace
+
+#define DISPATCH_FIELD(id, ...)                                   \
+  switch (id) {                                                   \
+    case 0: { typedef Fp<F298A> F; __VA_ARGS__; } break;                 \
+    case 1: { typedef Fp<F298B> F; __VA_ARGS__; } break;                 \
+    case 2: { typedef Fp<F753A> F; __VA_ARGS__; } break;                 \
+    case 3: { typedef Fp<F753B> F; __VA_ARGS__; } break;                 \
+    default: return -1;                                           \
+  }
+#define DISPATCH_CURVE(id, ...)                                   \
+  switch (id) {                                                   \
+    case 0: { typedef MNT4_298 C; __VA_ARGS__; } break;                  \
+    case 1: { typedef MNT6_298 C; __VA_ARGS__; } break;                  \
+    case 2: { typedef MNT4_753 C; __VA_ARGS__; } break;                  \
+    case 3: { typedef MNT6_753 C; __VA_ARGS__; } break;                  \
+    default: return -1;                                           \
+  }
+// BODY sees: C, F (coordinate field), G (Group<F>), GEN (Affine<F>)
+#define DISPATCH_GROUP(cid, grp, ...)                                                           \
+  DISPATCH_CURVE(cid, {                                                                         \
+    if ((grp) == 1) { typedef C::Fq F; Group<F> G = C::G1(); Affine<F> GEN = C::g1(); (void)GEN; __VA_ARGS__; }     \
+    else if ((grp) == 2) { typedef C::G2F F; Group<F> G = C::G2(); Affine<F> GEN = C::g2(); (void)GEN; __VA_ARGS__; } \
+    else return -1;                                                                             \
+  })
+
+extern "C" {
+
+int orc_field_n64(int field) { DISPATCH_FIELD(field, return F::N); return -1; }
+int orc_field_bits(int field) { DISPATCH_FIELD(field, return F::Params::BITS); return -1; }
+int orc_curve_fq(int curve) { DISPATCH_CURVE(curve, return C::Fq::Params::ID); return -1; }
+int orc_curve_fr(int curve) { DISPATCH_CURVE(curve, return C::Fr::Params::ID); return -1; }
+int orc_curve_g2_degree(int curve) { DISPATCH_CURVE(curve, return C::G2F::DEG); return -1; }
+
+// op: 0 add, 1 sub, 2 mul, 3 inv(a), 4 from_canonical(a), 5 to_canonical(a), 6 neg(a), 7 sqr(a)
+int orc_fp_op(int field, int op, const u64* a, const u64* b, u64* out, size_t n) {
+  DISPATCH_FIELD(field, {
+    for (size_t i = 0; i < n; i++) {
+      F x = F::from_raw(a + i * F::N), y = b ? F::from_raw(b + i * F::N) : F::zero(), r;
+      switch (op) {
+        case 0: r = x + y; break;
+        case 1: r = x - y; break;
+        case 2: r = x * y; break;
+        case 3: r = x.inv(); break;
+        case 4: r = F::from_canonical(a + i * F::N); break;
+        case 5: x.to_canonical(r.v); break;
+        case 6: r = x.neg(); break;
+        case 7: r = x.sqr(); break;
+        default: return -2;
+      }
+      memcpy(out + i * F::N, r.v, sizeof r.v);
+    }
+  });
+  return 0;
+}
+
+int orc_msm_window(size_t n) { return upstream_window(n); }
+
+int orc_msm(int curve, int group, const u64* bases, const uint8_t* inf, const u64* scalars, size_t n,
+            int nthreads, int c_override, u64* out_xyz) {
+  DISPATCH_GROUP(curve, group, {
+    std::vector<Affine<F>> pts;
+    load_affine<F>(bases, inf, n, pts);
+    Jac<F> r = msm_pippenger(G, pts.data(), scalars, C::Fr::N, n, C::Fr::Params::BITS, nthreads, c_override);
+    store_jac(r, out_xyz);
+  });
+  return 0;
+}
+
+int orc_to_affine(int curve, int group, const u64* xyz, size_t n, u64* xy, uint8_t* inf) {
+  DISPATCH_GROUP(curve, group, {
+    constexpr size_t EL = sizeof(F) / sizeof(u64);
+    for (size_t i = 0; i < n; i++) store_affine(G.to_affine(load_jac<F>(xyz + i * 3 * EL)), xy + i * 2 * EL, inf ? inf + i : nullptr);
+  });
+  return 0;
+}
+
+int orc_jac_add(int curve, int group, const u64* a, const u64* b, u64* out) {
+  DISPATCH_GROUP(curve, group, { store_jac(G.add(load_jac<F>(a), load_jac<F>(b)), out); });
+  return 0;
+}
+
+int orc_scalar_mul(int curve, int group, const u64* xy, const u64* scalar_canonical, u64* out_xyz) {
+  DISPATCH_GROUP(curve, group, {
+    store_jac(G.mul(Jac<F>::from_affine(load_affine1<F>(xy)), scalar_canonical, C::Fr::N), out_xyz);
+  });
+  return 0;
+}
+
+int orc_on_curve(int curve, int group, const u64* xy) {
+  DISPATCH_GROUP(curve, group, {
+    Affine<F> p = load_affine1<F>(xy);
+    return (p.y.sqr() == p.x.sqr() * p.x + G.a * p.x + curve_b<C, F>()) ? 1 : 0;
+  });
+  return -1;
+}
+
+int orc_generator(int curve, int group, u64* xy) {
+  DISPATCH_GROUP(curve, group, { store_affine(GEN, xy, nullptr); });
+  return 0;
+}
+
+int orc_gen_points(int curve, int group, size_t n, u64 seed, u64* xy) {
+  DISPATCH_GROUP(curve, group, { return gen_points_impl<C, F>(G, GEN, n, seed, xy); });
+  return 0;
+}
+
+// dist 0: uniform in [0, r);  dist 1: "witness-like": 45 % zero, 35 % one, 20 % uniform
+int orc_gen_scalars(int field, size_t n, u64 seed, int dist, u64* out) {
+  DISPATCH_FIELD(field, {
+    SplitMix g(seed);
+    for (size_t i = 0; i < n; i++) {
+      u64* o = out + i * F::N;
+      if (dist == 1) {
+        u64 t = g.next() % 100;
+        if (t < 45) { memset(o, 0, sizeof(u64) * F::N); continue; }
+        if (t < 80) { memset(o, 0, sizeof(u64) * F::N); o[0] = 1; continue; }
+      }
+      rand_canonical<F>(g, o);
+    }
+  });
+  return 0;
+}
+
+int orc_gen_field(int field, size_t n, u64 seed, u64* out_mont) {
+  DISPATCH_FIELD(field, {
+    SplitMix g(seed);
+    for (size_t i = 0; i < n; i++) rand_canonical<F>(g, out_mont + i * F::N);  // a uniform residue is a uniform Montgomery residue
+  });
+  return 0;
+}
+
+int orc_fft(int field, u64* data, int log_n, int inverse, int coset, int nthreads) {
+  DISPATCH_FIELD(field, {
+    if (log_n > F::Params::TWO_ADICITY) return -3;
+    Radix2Domain<F> dom(log_n);
+    F* a = reinterpret_cast<F*>(data);
+    if (!inverse && !coset) dom.fft(a, nthreads);
+    else if (inverse && !coset) dom.ifft(a, nthreads);
+    else if (!inverse && coset) dom.coset_fft(a, nthreads);
+    else dom.coset_ifft(a, nthreads);
+  });
+  return 0;
+}
+
+// Synthetic banded R1CS (same construction as pyoracle.synthetic_r1cs, different RNG):
+//   z = [1, inputs (num_inputs-1), 4 free witnesses, one product variable per constraint]
+//   row j: <A_j,z> * <B_j,z> = z[new_j];  A_j, B_j: 3 random coefficients on the 8 latest variables.
+// Outputs: row_ptr (nc+1) for A/B (3 per row) and C (1 per row), cols, coeffs (Montgomery), z (Montgomery).
+int orc_synthetic_r1cs(int field, size_t nc, size_t num_inputs, u64 seed, u64* rowptr_ab, uint32_t* col_a,
+                       u64* coeff_a, uint32_t* col_b, u64* coeff_b, u64* rowptr_c, uint32_t* col_c, u64* coeff_c,
+                       u64* z_out) {
+  DISPATCH_FIELD(field, {
+    SplitMix g(seed);
+    F* z = reinterpret_cast<F*>(z_out);
+    F* ca = reinterpret_cast<F*>(coeff_a);
+    F* cb = reinterpret_cast<F*>(coeff_b);
+    F* cc = reinterpret_cast<F*>(coeff_c);
+    size_t m = 0;
+    z[m++] = F::one();
+    u64 tmp[F::N];
+    for (size_t i = 1; i < num_inputs + 4; i++) { rand_canonical<F>(g, tmp); z[m++] = F::from_raw(tmp); }
+    for (size_t j = 0; j < nc; j++) {
+      size_t lo = m > 8 ? m - 8 : 0;
+      F va = F::zero(), vb = F::zero();
+      for (int t = 0; t < 3; t++) {
+        rand_canonical<F>(g, tmp); F c = F::from_raw(tmp); uint32_t col = (uint32_t)(lo + g.next() % (m - lo));
+        ca[3 * j + t] = c; col_a[3 * j + t] = col; va = va + c * z[col];
+        rand_canonical<F>(g, tmp); c = F::from_raw(tmp); col = (uint32_t)(lo + g.next() % (m - lo));
+        cb[3 * j + t] = c; col_b[3 * j + t] = col; vb = vb + c * z[col];
+      }
+      rowptr_ab[j] = 3 * j; rowptr_c[j] = j;
+      z[m] = va * vb;
+      cc[j] = F::one(); col_c[j] = (uint32_t)m;
+      m++;
+    }
+    rowptr_ab[nc] = 3 * nc; rowptr_c[nc] = nc;
+  });
+  return 0;
+}
+size_t orc_synthetic_r1cs_num_vars(size_t nc, size_t num_inputs) { return num_inputs + 4 + nc; }
+
+int orc_witness_map(int field, size_t nc, size_t num_inputs, const u64* rp_a, const uint32_t* col_a, const u64* coeff_a,
+                    const u64* rp_b, const uint32_t* col_b, const u64* coeff_b, const u64* rp_c,
+                    const uint32_t* col_c, const u64* coeff_c, const u64* z, int nthreads, u64* h_out) {
+  DISPATCH_FIELD(field, {
+    auto h = witness_map<F>(mk_csr<F>(nc, rp_a, col_a, coeff_a), mk_csr<F>(nc, rp_b, col_b, coeff_b),
+                            mk_csr<F>(nc, rp_c, col_c, coeff_c), reinterpret_cast<const F*>(z), num_inputs, nthreads);
+    memcpy(h_out, h.data(), h.size() * sizeof(F));
+  });
+  return 0;
+}
+
+// Host-side key bundle; layout mirrors include/pcdhip.h `pcdhip_g16_pk_host`.
+struct orc_g16_pk {
+  uint32_t curve_id, _pad;
+  u64 num_vars, num_inputs, domain_size;
+  const u64 *alpha_g1, *beta_g1, *delta_g1, *beta_g2, *delta_g2;
+  const u64* a_query; const uint8_t* a_inf;
+  const u64* b_g1_query; const uint8_t* b_g1_inf;
+  const u64* b_g2_query; const uint8_t* b_g2_inf;
+  const u64* h_query; const uint8_t* h_inf; u64 h_len;
+  const u64* l_query; const uint8_t* l_inf; u64 l_len;
+};
+
+// proof_out: A (G1 x||y) || B (G2 x||y) || C (G1 x||y); inf_out[3]
+int orc_groth16_prove(const orc_g16_pk* k, size_t nc, const u64* rp_a, const uint32_t* col_a, const u64* coeff_a,
+                      const u64* rp_b, const uint32_t* col_b, const u64* coeff_b, const u64* rp_c,
+                      const uint32_t* col_c, const u64* coeff_c, const u64* z, const u64* r_mont, const u64* s_mont,
+                      int nthreads, u64* proof_out, uint8_t* inf_out) {
+  DISPATCH_CURVE((int)k->curve_id, {
+    typedef G16<C> G;
+    typedef C::Fq Fq; typedef C::Fr Fr; typedef C::G2F E;
+    std::vector<Affine<Fq>> aq, b1q, hq, lq;
+    std::vector<Affine<E>> b2q;
+    load_affine<Fq>(k->a_query, k->a_inf, k->num_vars, aq);
+    load_affine<Fq>(k->b_g1_query, k->b_g1_inf, k->num_vars, b1q);
+    load_affine<E>(k->b_g2_query, k->b_g2_inf, k->num_vars, b2q);
+    load_affine<Fq>(k->h_query, k->h_inf, k->h_len, hq);
+    load_affine<Fq>(k->l_query, k->l_inf, k->l_len, lq);
+    G::PK pk;
+    pk.alpha_g1 = load_affine1<Fq>(k->alpha_g1); pk.beta_g1 = load_affine1<Fq>(k->beta_g1);
+    pk.delta_g1 = load_affine1<Fq>(k->delta_g1);
+    pk.beta_g2 = load_affine1<E>(k->beta_g2); pk.delta_g2 = load_affine1<E>(k->delta_g2);
+    pk.a_query = aq.data(); pk.b_g1_query = b1q.data(); pk.b_g2_query = b2q.data();
+    pk.h_query = hq.data(); pk.l_query = lq.data();
+    pk.m = k->num_vars; pk.num_inputs = k->num_inputs; pk.h_len = k->h_len; pk.l_len = k->l_len;
+    G::Proof pr = G::prove(pk, mk_csr<Fr>(nc, rp_a, col_a, coeff_a), mk_csr<Fr>(nc, rp_b, col_b, coeff_b),
+                           mk_csr<Fr>(nc, rp_c, col_c, coeff_c), reinterpret_cast<const Fr*>(z),
+                           Fr::from_raw(r_mont), Fr::from_raw(s_mont), nthreads);
+    constexpr size_t E1 = 2 * Fq::N, E2 = 2 * E::DEG * Fq::N;
+    store_affine(pr.a, proof_out, inf_out);
+    store_affine(pr.b, proof_out + E1, inf_out + 1);
+    store_affine(pr.c, proof_out + E1 + E2, inf_out + 2);
+  });
+  return 0;
+}
+
+// Setup with fixed toxic waste (5 Fr elements, Montgomery): writes every query into caller buffers.
+int orc_groth16_setup(int curve, size_t nc, size_t num_vars, size_t num_inputs, const u64* rp_a, const uint32_t* col_a,
+                      const u64* coeff_a, const u64* rp_b, const uint32_t* col_b, const u64* coeff_b, const u64* rp_c,
+                      const uint32_t* col_c, const u64* coeff_c, const u64* toxic_mont, int nthreads,
+                      u64* alpha_g1, u64* beta_g1, u64* delta_g1, u64* beta_g2, u64* delta_g2, u64* gamma_g2,
+                      u64* a_query, uint8_t* a_inf, u64* b_g1_query, uint8_t* b_g1_inf, u64* b_g2_query,
+                      uint8_t* b_g2_inf, u64* h_query, uint8_t* h_inf, u64* l_query, uint8_t* l_inf,
+                      u64* gamma_abc_g1, uint8_t* gamma_abc_inf) {
+  DISPATCH_CURVE(curve, {
+    typedef G16<C> G;
+    typedef C::Fq Fq; typedef C::Fr Fr; typedef C::G2F E;
+    Fr toxic[5];
+    for (int i = 0; i < 5; i++) toxic[i] = Fr::from_raw(toxic_mont + i * Fr::N);
+    auto K = G::setup(mk_csr<Fr>(nc, rp_a, col_a, coeff_a), mk_csr<Fr>(nc, rp_b, col_b, coeff_b),
+                      mk_csr<Fr>(nc, rp_c, col_c, coeff_c), num_vars, num_inputs, toxic, nthreads);
+    constexpr size_t E1 = 2 * Fq::N, E2 = 2 * E::DEG * Fq::N;
+    store_affine(K.alpha_g1, alpha_g1, nullptr); store_affine(K.beta_g1, beta_g1, nullptr);
+    store_affine(K.delta_g1, delta_g1, nullptr); store_affine(K.beta_g2, beta_g2, nullptr);
+    store_affine(K.delta_g2, delta_g2, nullptr); store_affine(K.gamma_g2, gamma_g2, nullptr);
+    for (size_t i = 0; i < K.a_query.size(); i++) store_affine(K.a_query[i], a_query + i * E1, a_inf + i);
+    for (size_t i = 0; i < K.b_g1_query.size(); i++) store_affine(K.b_g1_query[i], b_g1_query + i * E1, b_g1_inf + i);
+    for (size_t i = 0; i < K.b_g2_query.size(); i++) store_affine(K.b_g2_query[i], b_g2_query + i * E2, b_g2_inf + i);
+    for (size_t i = 0; i < K.h_query.size(); i++) store_affine(K.h_query[i], h_query + i * E1, h_inf + i);
+    for (size_t i = 0; i < K.l_query.size(); i++) store_affine(K.l_query[i], l_query + i * E1, l_inf + i);
+    for (size_t i = 0; i < K.gamma_abc_g1.size(); i++) store_affine(K.gamma_abc_g1[i], gamma_abc_g1 + i * E1, gamma_abc_inf + i);
+  });
+  return 0;
+}
+
+// returns 1 accept, 0 reject
+int orc_groth16_verify(int curve, const u64* alpha_g1, const u64* beta_g2, const u64* gamma_g2, const u64* delta_g2,
+                       const u64* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs,
+                       const u64* public_inputs_mont, const u64* proof, const uint8_t* proof_inf) {
+  DISPATCH_CURVE(curve, {
+    typedef G16<C> G;
+    typedef C::Fq Fq; typedef C::Fr Fr; typedef C::G2F E;
+    constexpr size_t E1 = 2 * Fq::N, E2 = 2 * E::DEG * Fq::N;
+    std::vector<Affine<Fq>> abc;
+    load_affine<Fq>(gamma_abc_g1, gamma_abc_inf, num_inputs, abc);
+    G::Proof pr = {load_affine1<Fq>(proof, proof_inf && proof_inf[0]), load_affine1<E>(proof + E1, proof_inf && proof_inf[1]),
+                   load_affine1<Fq>(proof + E1 + E2, proof_inf && proof_inf[2])};
+    bool ok = G::verify(load_affine1<Fq>(alpha_g1), load_affine1<E>(beta_g2), load_affine1<E>(gamma_g2),
+                        load_affine1<E>(delta_g2), abc.data(), num_inputs,
+                        reinterpret_cast<const Fr*>(public_inputs_mont), pr);
+    return ok ? 1 : 0;
+  });
+  return -1;
+}
+
+// reduced ate pairing; gt_out = Fqk in tower order (c0, c1), each over G2F, Montgomery limbs
+int orc_pairing(int curve, const u64* g1_xy, const u64* g2_xy, u64* gt_out) {
+  DISPATCH_CURVE(curve, {
+    typedef Pairing<C> PE;
+    auto v = PE::pairing(load_affine1<C::Fq>(g1_xy), load_affine1<C::G2F>(g2_xy));
+    memcpy(gt_out, &v, sizeof v);
+  });
+  return 0;
+}
+int orc_miller_loop(int curve, const u64* g1_xy, const u64* g2_xy, u64* out) {
+  DISPATCH_CURVE(curve, {
+    typedef Pairing<C> PE;
+    auto v = PE::miller_loop(PE::prepare_g1(load_affine1<C::Fq>(g1_xy)), PE::prepare_g2(load_affine1<C::G2F>(g2_xy)));
+    memcpy(out, &v, sizeof v);
+  });
+  return 0;
+}
+int orc_final_exponentiation(int curve, const u64* in, u64* out) {
+  DISPATCH_CURVE(curve, {
+    typedef Pairing<C> PE;
+    typename PE::Fqk v; memcpy((void*)&v, in, sizeof v);
+    v = PE::final_exponentiation(v);
+    memcpy(out, &v, sizeof v);
+  });
+  return 0;
+}
+
+}  // extern "C"
