@@ -1,0 +1,153 @@
+/* pcdhip.h -- C ABI of libpcdhip.so: MI355X (gfx950) prover arithmetic for arkworks-style PCD.
+ *
+ * Drop-in boundary for the hot path behind `ECCyclePCD::prove`
+ * (/root/reference src/ec_cycle_pcd/mod.rs:92-181): the two calls `IC::MainSNARK::prove`
+ * (mod.rs:171) and `IC::HelpSNARK::prove` (mod.rs:179) spend their time in upstream
+ * ark-ec `VariableBaseMSM::multi_scalar_mul`, ark-poly `Radix2EvaluationDomain::{fft,ifft,
+ * coset_fft,coset_ifft}_in_place` and ark-groth16 `R1CSToQAP::witness_map` / `create_proof`
+ * (Cargo.toml:17-19,39: git dependencies, not vendored).  Each entry point below names the
+ * upstream function it replaces; INTEGRATION.md shows the Rust `extern "C"` binding and the
+ * `SNARK` impl (the plug-in seam `ECCyclePCDConfig`, mod.rs:24-33) that calls them.
+ *
+ * Encodings (exactly the in-memory image of the upstream types, so the Rust side is a memcpy):
+ *   field element   L little-endian uint64_t limbs (L = 5 for the 298-bit fields, 12 for the
+ *                   753-bit fields), Montgomery form with R = 2^(64 L)       [ark-ff Fp320/Fp768]
+ *   scalar (MSM)    L limbs, canonical (non-Montgomery)                      [`into_repr()`]
+ *   Fq2 / Fq3       consecutive base-field elements c0, c1 (, c2)
+ *   affine point    x || y, infinity in a separate byte array (nullable = no point at infinity)
+ *   Jacobian point  X || Y || Z, Z = 0 means infinity                        [GroupProjective]
+ * Ownership: the caller owns every host buffer for the duration of the call only; device
+ * objects are opaque handles with explicit free functions.  No RNG inside the library: the
+ * Groth16 blinding factors r, s are inputs.  Thread-safety: one pcdhip_ctx per host thread;
+ * handles may be shared by contexts on the same device once created.
+ * Every function returns 0 on success or a negative PCDHIP_E_* code; nothing aborts or throws.
+ * There is NO CPU fallback: without a usable GPU every call fails with PCDHIP_E_NO_DEVICE.
+ */
+#ifndef PCDHIP_H
+#define PCDHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PCDHIP_MNT4_298 = 0, PCDHIP_MNT6_298 = 1, PCDHIP_MNT4_753 = 2, PCDHIP_MNT6_753 = 3 };  /* curve_id */
+/* field_id: 0 = MNT4-298 Fq (= MNT6-298 Fr), 1 = MNT4-298 Fr (= MNT6-298 Fq),
+ *           2 = MNT4-753 Fq (= MNT6-753 Fr), 3 = MNT4-753 Fr (= MNT6-753 Fq) */
+enum { PCDHIP_F298A = 0, PCDHIP_F298B = 1, PCDHIP_F753A = 2, PCDHIP_F753B = 3 };
+enum { PCDHIP_G1 = 1, PCDHIP_G2 = 2 };  /* group_id */
+
+enum {
+  PCDHIP_OK = 0,
+  PCDHIP_E_ARG = -1,              /* null pointer / bad id / inconsistent sizes */
+  PCDHIP_E_SIZE_UNSUPPORTED = -2, /* e.g. log_n above the field's 2-adicity (mixed-radix domain needed) */
+  PCDHIP_E_NO_DEVICE = -3,
+  PCDHIP_E_OOM = -4,
+  PCDHIP_E_HIP = -5               /* any other HIP runtime failure; see pcdhip_last_hip_error */
+};
+
+typedef struct pcdhip_ctx pcdhip_ctx;
+typedef struct pcdhip_bases pcdhip_bases;     /* device-resident affine base points (one query vector) */
+typedef struct pcdhip_buf pcdhip_buf;         /* device-resident vector of field elements / scalars */
+typedef struct pcdhip_g16_pk pcdhip_g16_pk;   /* device-resident Groth16 proving key */
+
+const char* pcdhip_strerror(int code);
+int pcdhip_device_count(void);
+/* One context = one device + one HIP stream + reusable workspaces. */
+int pcdhip_init(int device_id, pcdhip_ctx** out);
+void pcdhip_destroy(pcdhip_ctx* ctx);
+int pcdhip_sync(pcdhip_ctx* ctx);
+const char* pcdhip_last_hip_error(pcdhip_ctx* ctx);
+/* Static facts (no GPU needed). */
+int pcdhip_field_limbs(int field_id);                 /* L */
+int pcdhip_curve_base_field(int curve_id);            /* field_id of Fq */
+int pcdhip_curve_scalar_field(int curve_id);          /* field_id of Fr */
+int pcdhip_point_limbs(int curve_id, int group_id);   /* uint64 limbs per affine point (x||y) */
+
+/* ---- device vectors ------------------------------------------------------------------------- */
+int pcdhip_buf_upload(pcdhip_ctx* ctx, int field_id, const uint64_t* host, size_t n, pcdhip_buf** out);
+int pcdhip_buf_alloc(pcdhip_ctx* ctx, int field_id, size_t n, pcdhip_buf** out);
+int pcdhip_buf_download(pcdhip_ctx* ctx, const pcdhip_buf* buf, uint64_t* host, size_t n);
+void pcdhip_buf_free(pcdhip_ctx* ctx, pcdhip_buf* buf);
+
+/* ---- K3/K4: variable-base MSM ----------------------------------------------------------------
+ * Replaces ark-ec `VariableBaseMSM::multi_scalar_mul(&bases[offset..offset+n], &scalars)`.
+ * Bases are uploaded once (proving-key residency) and addressed by handle. */
+int pcdhip_bases_upload(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xy_mont,
+                        const uint8_t* inf_flags, size_t n, pcdhip_bases** out);
+void pcdhip_bases_free(pcdhip_ctx* ctx, pcdhip_bases* bases);
+int pcdhip_msm(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const uint64_t* scalars_canonical,
+               size_t n, uint64_t* out_xyz_mont);
+/* Same with scalars already resident on the device (element `scalar_offset` onwards). */
+int pcdhip_msm_dev(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars,
+                   size_t scalar_offset, size_t n, uint64_t* out_xyz_mont);
+/* Tuning / introspection: window bits (0 = automatic), sorted entries per lane (0 = default). */
+int pcdhip_msm_config(pcdhip_ctx* ctx, int window_bits, int chunk);
+/* Per-stage device time of the last MSM (HIP events on the context's stream), milliseconds:
+ * [digits, scan, scatter, accumulate, fixup, tail, horner, total]; enable with on != 0. */
+int pcdhip_msm_profile(pcdhip_ctx* ctx, int on);
+int pcdhip_msm_last_timings(pcdhip_ctx* ctx, float out_ms[8]);
+/* Sum of n Jacobian points (the multi-GPU combine step after the all-gather of partial results). */
+int pcdhip_points_sum(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xyz_mont, size_t n,
+                      uint64_t* out_xyz_mont);
+/* Jacobian -> affine (x||y, flag) for n points, as `into_affine()`. */
+int pcdhip_to_affine(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xyz_mont, size_t n,
+                     uint64_t* out_xy_mont, uint8_t* out_inf);
+
+/* ---- K2: radix-2 FFT --------------------------------------------------------------------------
+ * Replaces ark-poly Radix2EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place on a
+ * domain of size 2^log_n: (inverse, coset) = (0,0) fft, (1,0) ifft, (0,1) coset_fft, (1,1) coset_ifft.
+ * In place, natural order in and out, Montgomery form. */
+int pcdhip_fft(pcdhip_ctx* ctx, int field_id, uint64_t* data_mont, uint32_t log_n, int inverse, int coset);
+int pcdhip_fft_dev(pcdhip_ctx* ctx, pcdhip_buf* data, uint32_t log_n, int inverse, int coset);
+/* Per-pass device time of the last transform; returns the number of passes written (<= 8). */
+int pcdhip_fft_last_timings(pcdhip_ctx* ctx, float out_ms[8]);
+
+/* ---- K1: Groth16 witness map -------------------------------------------------------------------
+ * Replaces ark-groth16 `R1CSToQAP::witness_map` (libsnark reduction): h = (A z o B z - C z) / Z on
+ * the domain of size n = 2^ceil(log2(num_constraints + num_inputs)); writes n elements of h. */
+typedef struct {
+  uint64_t num_rows;        /* = num_constraints */
+  const uint64_t* row_ptr;  /* num_rows + 1 */
+  const uint32_t* col;      /* nnz column (variable) indices */
+  const uint64_t* coeff;    /* nnz coefficients, Montgomery limbs */
+} pcdhip_csr;
+int pcdhip_groth16_witness_map(pcdhip_ctx* ctx, int field_id, const pcdhip_csr* A, const pcdhip_csr* B,
+                               const pcdhip_csr* C, const uint64_t* z_mont, size_t num_vars, size_t num_inputs,
+                               uint64_t* h_out_mont);
+
+/* ---- K1+K3+K4+K5: Groth16 prover arithmetic ----------------------------------------------------
+ * Replaces the body of ark-groth16 `create_proof` after constraint synthesis (which stays in the
+ * Rust host): witness map + 4 G1 MSMs + 1 G2 MSM + assembly with the caller's r, s. */
+typedef struct {
+  uint32_t curve_id, _pad;
+  uint64_t num_vars;     /* m, including the leading 1 */
+  uint64_t num_inputs;   /* including the leading 1 */
+  uint64_t domain_size;  /* n */
+  const uint64_t *alpha_g1, *beta_g1, *delta_g1;  /* vk.alpha_g1, pk.beta_g1, pk.delta_g1 */
+  const uint64_t *beta_g2, *delta_g2;             /* vk.beta_g2, vk.delta_g2 */
+  const uint64_t* a_query;    const uint8_t* a_inf;      /* m points */
+  const uint64_t* b_g1_query; const uint8_t* b_g1_inf;   /* m */
+  const uint64_t* b_g2_query; const uint8_t* b_g2_inf;   /* m */
+  const uint64_t* h_query;    const uint8_t* h_inf;  uint64_t h_len;   /* n - 1 */
+  const uint64_t* l_query;    const uint8_t* l_inf;  uint64_t l_len;   /* m - num_inputs */
+} pcdhip_g16_pk_host;
+int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* host, pcdhip_g16_pk** out);
+void pcdhip_g16_pk_free(pcdhip_ctx* ctx, pcdhip_g16_pk* pk);
+/* proof_out = A (G1 x||y) || B (G2 x||y) || C (G1 x||y), affine Montgomery; inf_out[3]. */
+int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B,
+                         const pcdhip_csr* C, const uint64_t* z_mont, const uint64_t* r_mont, const uint64_t* s_mont,
+                         uint64_t* proof_out, uint8_t* inf_out);
+/* Device time of the stages of the last prove, milliseconds:
+ * [witness_map, msm_h, msm_l, msm_a, msm_b_g1, msm_b_g2, assembly, total]. */
+int pcdhip_groth16_last_timings(pcdhip_ctx* ctx, float out_ms[8]);
+
+/* ---- timing helpers (HIP events on the context's stream, for bench.py) ------------------------- */
+int pcdhip_timer_start(pcdhip_ctx* ctx);
+int pcdhip_timer_stop(pcdhip_ctx* ctx, float* out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCDHIP_H */

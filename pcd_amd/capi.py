@@ -1,0 +1,270 @@
+"""ctypes binding of libpcdhip.so (include/pcdhip.h).  numpy uint64 arrays in, numpy arrays out.
+
+Mirrors the C-ABI one to one; the class/method names follow the upstream functions they stand in
+for (`multi_scalar_mul`, `fft`/`ifft`/`coset_fft`/`coset_ifft`, `witness_map`, `create_proof`).
+No fallback: a missing library or a missing GPU raises PcdHipError."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import library_path
+
+MNT4_298, MNT6_298, MNT4_753, MNT6_753 = 0, 1, 2, 3
+G1, G2 = 1, 2
+FIELD_LIMBS = [5, 5, 12, 12]
+CURVE_FQ = [0, 1, 2, 3]
+CURVE_FR = [1, 0, 3, 2]
+CURVE_G2_DEG = [2, 3, 2, 3]
+
+
+class PcdHipError(RuntimeError):
+    pass
+
+
+class Csr(C.Structure):
+    _fields_ = [("num_rows", C.c_uint64), ("row_ptr", C.c_void_p), ("col", C.c_void_p), ("coeff", C.c_void_p)]
+
+
+class G16PkHost(C.Structure):
+    _fields_ = [("curve_id", C.c_uint32), ("_pad", C.c_uint32), ("num_vars", C.c_uint64), ("num_inputs", C.c_uint64),
+                ("domain_size", C.c_uint64),
+                ("alpha_g1", C.c_void_p), ("beta_g1", C.c_void_p), ("delta_g1", C.c_void_p),
+                ("beta_g2", C.c_void_p), ("delta_g2", C.c_void_p),
+                ("a_query", C.c_void_p), ("a_inf", C.c_void_p),
+                ("b_g1_query", C.c_void_p), ("b_g1_inf", C.c_void_p),
+                ("b_g2_query", C.c_void_p), ("b_g2_inf", C.c_void_p),
+                ("h_query", C.c_void_p), ("h_inf", C.c_void_p), ("h_len", C.c_uint64),
+                ("l_query", C.c_void_p), ("l_inf", C.c_void_p), ("l_len", C.c_uint64)]
+
+
+_LIB = None
+
+EXPORTS = [
+    "pcdhip_strerror", "pcdhip_device_count", "pcdhip_init", "pcdhip_destroy", "pcdhip_sync", "pcdhip_last_hip_error",
+    "pcdhip_field_limbs", "pcdhip_curve_base_field", "pcdhip_curve_scalar_field", "pcdhip_point_limbs",
+    "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
+    "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config",
+    "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_to_affine",
+    "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
+    "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings",
+    "pcdhip_timer_start", "pcdhip_timer_stop",
+]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise PcdHipError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)")
+        _LIB = C.CDLL(path)
+        _LIB.pcdhip_strerror.restype = C.c_char_p
+        _LIB.pcdhip_last_hip_error.restype = C.c_char_p
+        _LIB.pcdhip_destroy.restype = None
+        for name in ("pcdhip_buf_free", "pcdhip_bases_free", "pcdhip_g16_pk_free"):
+            getattr(_LIB, name).restype = None
+    return _LIB
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def point_limbs(curve, group):
+    return 2 * (1 if group == G1 else CURVE_G2_DEG[curve]) * FIELD_LIMBS[CURVE_FQ[curve]]
+
+
+class Context:
+    """One device + one HIP stream (pcdhip_ctx)."""
+
+    def __init__(self, device=0):
+        self._ctx = C.c_void_p()
+        rc = lib().pcdhip_init(int(device), C.byref(self._ctx))
+        if rc != 0:
+            raise PcdHipError(f"pcdhip_init(device={device}) failed: {lib().pcdhip_strerror(rc).decode()}")
+        self.device = device
+
+    def close(self):
+        if self._ctx:
+            lib().pcdhip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            detail = lib().pcdhip_last_hip_error(self._ctx).decode()
+            raise PcdHipError(f"{lib().pcdhip_strerror(rc).decode()} (rc={rc}) {detail}")
+
+    def sync(self):
+        self._check(lib().pcdhip_sync(self._ctx))
+
+    # ---- device vectors
+    def buf_upload(self, field, arr):
+        arr = _u64(arr)
+        n = arr.shape[0]
+        h = C.c_void_p()
+        self._check(lib().pcdhip_buf_upload(self._ctx, field, _p(arr), C.c_size_t(n), C.byref(h)))
+        return DeviceBuf(self, h, field, n)
+
+    # ---- MSM
+    def bases_upload(self, curve, group, xy, inf=None):
+        xy = _u64(xy)
+        n = xy.shape[0]
+        infp = np.ascontiguousarray(inf, dtype=np.uint8) if inf is not None else None
+        h = C.c_void_p()
+        self._check(lib().pcdhip_bases_upload(self._ctx, curve, group, _p(xy), _p(infp), C.c_size_t(n), C.byref(h)))
+        return Bases(self, h, curve, group, n)
+
+    def msm(self, bases, scalars, offset=0, n=None):
+        """multi_scalar_mul(bases[offset:offset+n], scalars) -> Jacobian X||Y||Z (uint64 limbs)."""
+        out = np.zeros(3 * point_limbs(bases.curve, bases.group) // 2, dtype=np.uint64)
+        if isinstance(scalars, DeviceBuf):
+            n = scalars.n if n is None else n
+            self._check(lib().pcdhip_msm_dev(self._ctx, bases._h, C.c_size_t(offset), scalars._h, C.c_size_t(0), C.c_size_t(n), _p(out)))
+        else:
+            scalars = _u64(scalars)
+            n = scalars.shape[0] if n is None else n
+            self._check(lib().pcdhip_msm(self._ctx, bases._h, C.c_size_t(offset), _p(scalars), C.c_size_t(n), _p(out)))
+        return out
+
+    def msm_config(self, window_bits=0, chunk=0):
+        self._check(lib().pcdhip_msm_config(self._ctx, window_bits, chunk))
+
+    def msm_profile(self, on=True):
+        self._check(lib().pcdhip_msm_profile(self._ctx, int(on)))
+
+    def msm_last_timings(self):
+        out = (C.c_float * 8)()
+        self._check(lib().pcdhip_msm_last_timings(self._ctx, out))
+        return dict(zip(["digits", "scan", "scatter", "accumulate", "fixup", "tail", "horner", "total"], list(out)))
+
+    def points_sum(self, curve, group, xyz):
+        xyz = _u64(xyz).reshape(-1, 3 * point_limbs(curve, group) // 2)
+        out = np.zeros(xyz.shape[1], dtype=np.uint64)
+        self._check(lib().pcdhip_points_sum(self._ctx, curve, group, _p(xyz), C.c_size_t(xyz.shape[0]), _p(out)))
+        return out
+
+    def to_affine(self, curve, group, xyz):
+        xyz = _u64(xyz).reshape(-1, 3 * point_limbs(curve, group) // 2)
+        n = xyz.shape[0]
+        xy = np.zeros((n, point_limbs(curve, group)), dtype=np.uint64)
+        inf = np.zeros(n, dtype=np.uint8)
+        self._check(lib().pcdhip_to_affine(self._ctx, curve, group, _p(xyz), C.c_size_t(n), _p(xy), _p(inf)))
+        return xy, inf
+
+    # ---- FFT
+    def fft(self, field, data, inverse=False, coset=False):
+        if isinstance(data, DeviceBuf):
+            log_n = data.n.bit_length() - 1
+            self._check(lib().pcdhip_fft_dev(self._ctx, data._h, log_n, int(inverse), int(coset)))
+            return data
+        data = _u64(data).copy()
+        n = data.shape[0]
+        log_n = n.bit_length() - 1
+        assert 1 << log_n == n
+        self._check(lib().pcdhip_fft(self._ctx, field, _p(data), log_n, int(inverse), int(coset)))
+        return data
+
+    def fft_last_timings(self):
+        out = (C.c_float * 8)()
+        k = lib().pcdhip_fft_last_timings(self._ctx, out)
+        return list(out)[:max(k, 0)]
+
+    # ---- Groth16
+    @staticmethod
+    def _csr(rp, col, coeff):
+        s = Csr()
+        s.num_rows = len(rp) - 1
+        s.row_ptr, s.col, s.coeff = rp.ctypes.data, col.ctypes.data, coeff.ctypes.data
+        return s
+
+    def witness_map(self, field, r1cs):
+        """R1CSToQAP::witness_map: r1cs has rp_/col_/coeff_{a,b,c}, z, num_inputs (oracle.coracle.R1CS layout)."""
+        A = self._csr(r1cs.rp_a, r1cs.col_a, r1cs.coeff_a)
+        B = self._csr(r1cs.rp_b, r1cs.col_b, r1cs.coeff_b)
+        Cm = self._csr(r1cs.rp_c, r1cs.col_c, r1cs.coeff_c)
+        n = 1 << r1cs.domain_log
+        h = np.zeros((n, FIELD_LIMBS[field]), dtype=np.uint64)
+        self._check(lib().pcdhip_groth16_witness_map(self._ctx, field, C.byref(A), C.byref(B), C.byref(Cm), _p(r1cs.z),
+                                                     C.c_size_t(r1cs.num_vars), C.c_size_t(r1cs.num_inputs), _p(h)))
+        return h
+
+    def g16_pk_upload(self, host_struct, curve):
+        h = C.c_void_p()
+        self._check(lib().pcdhip_g16_pk_upload(self._ctx, C.byref(host_struct), C.byref(h)))
+        return G16Pk(self, h, curve)
+
+    def groth16_prove(self, pk, r1cs, r_mont, s_mont):
+        """create_proof after synthesis -> (proof A||B||C affine limbs, inf flags[3])."""
+        A = self._csr(r1cs.rp_a, r1cs.col_a, r1cs.coeff_a)
+        B = self._csr(r1cs.rp_b, r1cs.col_b, r1cs.coeff_b)
+        Cm = self._csr(r1cs.rp_c, r1cs.col_c, r1cs.coeff_c)
+        w1, w2 = point_limbs(pk.curve, G1), point_limbs(pk.curve, G2)
+        proof = np.zeros(2 * w1 + w2, dtype=np.uint64)
+        inf = np.zeros(3, dtype=np.uint8)
+        self._check(lib().pcdhip_groth16_prove(self._ctx, pk._h, C.byref(A), C.byref(B), C.byref(Cm), _p(r1cs.z),
+                                               _p(_u64(r_mont)), _p(_u64(s_mont)), _p(proof), _p(inf)))
+        return proof, inf
+
+    def groth16_last_timings(self):
+        out = (C.c_float * 8)()
+        self._check(lib().pcdhip_groth16_last_timings(self._ctx, out))
+        return dict(zip(["witness_map", "msm_h", "msm_l", "msm_a", "msm_b_g1", "msm_b_g2", "assembly", "total"], list(out)))
+
+    # ---- timing
+    def timer_start(self):
+        self._check(lib().pcdhip_timer_start(self._ctx))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._check(lib().pcdhip_timer_stop(self._ctx, C.byref(ms)))
+        return ms.value
+
+
+class DeviceBuf:
+    def __init__(self, ctx, h, field, n):
+        self.ctx, self._h, self.field, self.n = ctx, h, field, n
+
+    def download(self):
+        out = np.zeros((self.n, FIELD_LIMBS[self.field]), dtype=np.uint64)
+        self.ctx._check(lib().pcdhip_buf_download(self.ctx._ctx, self._h, _p(out), C.c_size_t(self.n)))
+        return out
+
+    def free(self):
+        if self._h:
+            lib().pcdhip_buf_free(self.ctx._ctx, self._h)
+            self._h = None
+
+
+class Bases:
+    def __init__(self, ctx, h, curve, group, n):
+        self.ctx, self._h, self.curve, self.group, self.n = ctx, h, curve, group, n
+
+    def free(self):
+        if self._h:
+            lib().pcdhip_bases_free(self.ctx._ctx, self._h)
+            self._h = None
+
+
+class G16Pk:
+    def __init__(self, ctx, h, curve):
+        self.ctx, self._h, self.curve = ctx, h, curve
+
+    def free(self):
+        if self._h:
+            lib().pcdhip_g16_pk_free(self.ctx._ctx, self._h)
+            self._h = None

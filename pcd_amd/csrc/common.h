@@ -1,0 +1,100 @@
+// Host-side plumbing shared by the translation units of libpcdhip.so: context, handles and the
+// per-field / per-group / per-curve entry tables (each instantiation lives in its own object file so
+// the eight group instantiations compile in parallel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pcdhip.h"
+#include "msm.cuh"
+
+namespace pcd {
+
+struct FftTables {  // per (field, log_n): powers of w, w^-1, g, g^-1 (*1/n folded in), resident for reuse
+  uint32_t *tw_fwd = nullptr, *tw_inv = nullptr, *coset = nullptr, *coset_inv_scaled = nullptr;
+};
+
+}  // namespace pcd
+
+struct pcdhip_buf {
+  int field_id;
+  size_t n;        // elements
+  uint32_t* dptr;  // n * words u32
+};
+struct pcdhip_bases {
+  int curve_id, group_id;
+  size_t n;
+  uint32_t* dptr;  // n affine points, (0,0) = infinity
+};
+struct pcdhip_g16_pk {
+  int curve_id;
+  uint64_t num_vars, num_inputs, domain_size;
+  pcdhip_bases *a_query, *b_g1_query, *b_g2_query, *h_query, *l_query;
+  uint32_t* singles;  // device: alpha_g1, beta_g1, delta_g1, a0, b1_0 (G1 affine) then beta_g2, delta_g2, b2_0 (G2 affine)
+};
+struct pcdhip_ctx {
+  int device;
+  hipStream_t stream;
+  pcd::MsmWorkspace msm_ws;
+  pcd::MsmWorkspace aux_ws;  // fft ping-pong, witness-map vectors, groth16 scratch
+  std::map<uint64_t, pcd::FftTables> fft_tables;
+  int msm_c = 0;
+  uint32_t msm_chunk = 0;
+  bool msm_profile = false;
+  pcd::MsmTimings msm_tm;
+  float fft_ms[8] = {0};
+  int fft_passes = 0;
+  float g16_ms[8] = {0};
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  std::string last_hip_error;
+};
+
+namespace pcd {
+
+// ---- per-group entries (inst_group.hip, one object per group) ------------------------------------
+typedef hipError_t (*MsmFn)(MsmWorkspace&, hipStream_t, const uint32_t* bases, const uint32_t* scalars, uint32_t n,
+                            uint32_t* out_dev, int c, uint32_t chunk, MsmTimings* tm);
+typedef hipError_t (*PointsSumFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* out_dev);
+typedef hipError_t (*ToAffineFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* aff_dev);
+struct GroupEntry {
+  int point_words;  // u32 words per affine point
+  int scalar_words; // u32 words per scalar
+  MsmFn msm;
+  PointsSumFn points_sum;
+  ToAffineFn to_affine;
+};
+const GroupEntry& group_entry(int curve_id, int group_id);  // group_id 1 / 2
+
+// ---- per-field entries (inst_field.hip) ------------------------------------------------------------
+struct FieldEntry {
+  int words;  // u32 words per element
+  int two_adicity;
+  // fills tables for a domain of 2^log_n (allocates into `t`)
+  hipError_t (*fft_make_tables)(hipStream_t, int log_n, FftTables* t);
+  // x -> result in `x` (uses `tmp` as the ping-pong partner; both n elements)
+  hipError_t (*fft_run)(hipStream_t, const FftTables& t, uint32_t* x, uint32_t* tmp, int log_n, int inverse, int coset,
+                        float* pass_ms, int* npasses);
+  hipError_t (*convert)(hipStream_t, const uint32_t* in, uint32_t* out, uint32_t n, int to_mont);
+  // a[i] = <A_i, z> for the rows, a[nc + j] = z[j] for inputs when `append_inputs`, zero padding to n
+  hipError_t (*spmv)(hipStream_t, const uint64_t* row_ptr, const uint32_t* col, const uint32_t* coeff, uint32_t rows,
+                     const uint32_t* z, uint32_t num_inputs, int append_inputs, uint32_t n, uint32_t* out);
+  // a = (a * b - c) / Z(g) on the coset of size 2^log_n
+  hipError_t (*mul_sub_divz)(hipStream_t, uint32_t* a, const uint32_t* b, const uint32_t* c, int log_n);
+};
+const FieldEntry& field_entry(int field_id);
+
+// ---- per-curve entries (inst_g16.hip) --------------------------------------------------------------
+struct CurveEntry {
+  // msm_results: 5 Jacobian points on device in the order h, l, a, b_g1 (G1) then b_g2 (G2, at g2_off words)
+  // singles: see pcdhip_g16_pk;  r, s: Fr Montgomery (device);  proof_out: device affine A || B || C
+  hipError_t (*assemble)(hipStream_t, const uint32_t* msm_g1, const uint32_t* msm_g2, const uint32_t* singles,
+                         const uint32_t* rs_dev, uint32_t* scratch, uint32_t* proof_out);
+  size_t assemble_scratch_bytes;
+};
+const CurveEntry& curve_entry(int curve_id);
+
+}  // namespace pcd

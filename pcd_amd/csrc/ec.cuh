@@ -1,0 +1,148 @@
+// Device short-Weierstrass Jacobian arithmetic (a != 0) for MNT4/MNT6 G1 and G2.
+//
+// Device counterpart of ark-ec `short_weierstrass_jacobian` as used by
+// `VariableBaseMSM::multi_scalar_mul` under SNARK::prove (/root/reference
+// src/ec_cycle_pcd/mod.rs:171,179).  Formulas are the EFD ones upstream uses (madd-2007-bl,
+// add-2007-bl, dbl-2007-bl); results are compared with the oracle on affine coordinates only,
+// since projective representatives are not unique.
+//
+// Affine infinity is encoded as (0, 0) on device: (0,0) is not on any of the eight curves
+// (b != 0), and pcdhip_bases_upload rewrites flagged points to it.
+#pragma once
+#include "fp.cuh"
+
+namespace pcd {
+
+template <class F>
+struct Jac {
+  F X, Y, Z;
+  PCD_HD static Jac infinity() { return {F::zero(), F::one(), F::zero()}; }
+  PCD_HD bool is_inf() const { return Z.is_zero(); }
+  static constexpr int WORDS = 3 * F::WORDS;
+  PCD_HD static Jac load(const uint32_t* p) { return {F::load(p), F::load(p + F::WORDS), F::load(p + 2 * F::WORDS)}; }
+  PCD_HD void store(uint32_t* p) const { X.store(p); Y.store(p + F::WORDS); Z.store(p + 2 * F::WORDS); }
+};
+
+template <class F>
+struct Aff {
+  F x, y;
+  static constexpr int WORDS = 2 * F::WORDS;
+  PCD_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+  PCD_HD static Aff load(const uint32_t* p) { return {F::load(p), F::load(p + F::WORDS)}; }
+  PCD_HD void store(uint32_t* p) const { x.store(p); y.store(p + F::WORDS); }
+};
+
+// ------------------------------------------------------------------------------------------------ group configs
+// G: coordinate field F, scalar-field parameters FR, and multiplication by the curve coefficient a.
+template <class FQ, class FRP, unsigned A, int CURVE>
+struct G1Cfg {
+  typedef Fp<FQ> F;
+  typedef FRP FR;
+  static constexpr int CURVE_ID = CURVE;
+  static constexpr int GROUP = 1;
+  PCD_HD static F mul_by_a(const F& x) { return x.mul_small(A); }
+};
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+struct G2Cfg2 {  // twist over Fq2: a' = (a*nr, 0)
+  typedef Fp2<Fp<FQ>, NR> F;
+  typedef FRP FR;
+  static constexpr int CURVE_ID = CURVE;
+  static constexpr int GROUP = 2;
+  PCD_HD static F mul_by_a(const F& x) { return x.mul_small(A * NR); }
+};
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+struct G2Cfg3 {  // twist over Fq3: a' = (0, 0, a) = a u^2;  x u^2 = (nr c1, nr c2, c0)
+  typedef Fp3<Fp<FQ>, NR> F;
+  typedef FRP FR;
+  static constexpr int CURVE_ID = CURVE;
+  static constexpr int GROUP = 2;
+  PCD_HD static F mul_by_a(const F& x) { return {x.c1.mul_small(A * NR), x.c2.mul_small(A * NR), x.c0.mul_small(A)}; }
+};
+
+typedef G1Cfg<F298A, F298B, PCD_MNT4_298_A_SMALL, 0> G1_MNT4_298;
+typedef G1Cfg<F298B, F298A, PCD_MNT6_298_A_SMALL, 1> G1_MNT6_298;
+typedef G1Cfg<F753A, F753B, PCD_MNT4_753_A_SMALL, 2> G1_MNT4_753;
+typedef G1Cfg<F753B, F753A, PCD_MNT6_753_A_SMALL, 3> G1_MNT6_753;
+typedef G2Cfg2<F298A, F298B, PCD_MNT4_298_A_SMALL, PCD_MNT4_298_NR_SMALL, 0> G2_MNT4_298;
+typedef G2Cfg3<F298B, F298A, PCD_MNT6_298_A_SMALL, PCD_MNT6_298_NR_SMALL, 1> G2_MNT6_298;
+typedef G2Cfg2<F753A, F753B, PCD_MNT4_753_A_SMALL, PCD_MNT4_753_NR_SMALL, 2> G2_MNT4_753;
+typedef G2Cfg3<F753B, F753A, PCD_MNT6_753_A_SMALL, PCD_MNT6_753_NR_SMALL, 3> G2_MNT6_753;
+
+// ------------------------------------------------------------------------------------------------ group law
+template <class G>
+struct EC {
+  typedef typename G::F F;
+  typedef Jac<F> J;
+  typedef Aff<F> A;
+
+  // dbl-2007-bl
+  PCD_HD static J dbl(const J& p) {
+    if (p.is_inf()) return p;
+    F XX = p.X.sqr(), YY = p.Y.sqr(), YYYY = YY.sqr(), ZZ = p.Z.sqr();
+    F S = ((p.X + YY).sqr() - XX - YYYY).dbl();
+    F M = XX.dbl() + XX + G::mul_by_a(ZZ.sqr());
+    F T = M.sqr() - S.dbl();
+    J r;
+    r.X = T;
+    r.Y = M * (S - T) - YYYY.dbl().dbl().dbl();
+    r.Z = (p.Y + p.Z).sqr() - YY - ZZ;
+    return r;
+  }
+  // madd-2007-bl; q = (0,0) is the identity
+  PCD_HD static J madd(const J& p, const A& q) {
+    if (q.is_inf()) return p;
+    if (p.is_inf()) return {q.x, q.y, F::one()};
+    F Z1Z1 = p.Z.sqr();
+    F U2 = q.x * Z1Z1;
+    F S2 = q.y * p.Z * Z1Z1;
+    if (p.X == U2 && p.Y == S2) return dbl(p);
+    F H = U2 - p.X;
+    F HH = H.sqr();
+    F I = HH.dbl().dbl();
+    F Jv = H * I;
+    F r = (S2 - p.Y).dbl();
+    F V = p.X * I;
+    J o;
+    o.X = r.sqr() - Jv - V.dbl();
+    o.Y = r * (V - o.X) - (p.Y * Jv).dbl();
+    o.Z = (p.Z + H).sqr() - Z1Z1 - HH;
+    return o;
+  }
+  // add-2007-bl
+  PCD_HD static J add(const J& p, const J& q) {
+    if (p.is_inf()) return q;
+    if (q.is_inf()) return p;
+    F Z1Z1 = p.Z.sqr(), Z2Z2 = q.Z.sqr();
+    F U1 = p.X * Z2Z2, U2 = q.X * Z1Z1;
+    F S1 = p.Y * q.Z * Z2Z2, S2 = q.Y * p.Z * Z1Z1;
+    if (U1 == U2 && S1 == S2) return dbl(p);
+    F H = U2 - U1;
+    F I = H.dbl().sqr();
+    F Jv = H * I;
+    F r = (S2 - S1).dbl();
+    F V = U1 * I;
+    J o;
+    o.X = r.sqr() - Jv - V.dbl();
+    o.Y = r * (V - o.X) - (S1 * Jv).dbl();
+    o.Z = ((p.Z + q.Z).sqr() - Z1Z1 - Z2Z2) * H;
+    return o;
+  }
+  PCD_HD static J neg(const J& p) { return {p.X, p.Y.neg(), p.Z}; }
+  // affine (x, y) or (0, 0) for the identity
+  PCD_HD static A to_affine(const J& p) {
+    if (p.is_inf()) return {F::zero(), F::zero()};
+    F zi = p.Z.inv(), zi2 = zi.sqr();
+    return {p.X * zi2, p.Y * zi2 * zi};
+  }
+  // k given as `nwords` canonical little-endian u32 words
+  PCD_HD static J mul(const J& p, const uint32_t* k, int nwords) {
+    J r = J::infinity();
+    for (int i = nwords * 32 - 1; i >= 0; i--) {
+      r = dbl(r);
+      if ((k[i >> 5] >> (i & 31)) & 1) r = add(r, p);
+    }
+    return r;
+  }
+};
+
+}  // namespace pcd

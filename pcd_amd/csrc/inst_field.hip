@@ -1,0 +1,160 @@
+// One object per scalar field (compile with -DPCD_FIELD_IDX=0..3): FFT driver, witness-map helpers.
+#include "common.h"
+#include "fft.cuh"
+
+namespace pcd {
+
+#if PCD_FIELD_IDX == 0
+typedef Fp<F298A> FT;
+#elif PCD_FIELD_IDX == 1
+typedef Fp<F298B> FT;
+#elif PCD_FIELD_IDX == 2
+typedef Fp<F753A> FT;
+#elif PCD_FIELD_IDX == 3
+typedef Fp<F753B> FT;
+#else
+#error "PCD_FIELD_IDX must be 0..3"
+#endif
+
+namespace {
+
+constexpr int EW = FT::WORDS;
+
+// Host-side copies of a few field constants are produced on the DEVICE (no host bigint code in the
+// product): this kernel writes w, w^-1, g, g^-1, 1/n, 1/Z(g) for a domain of 2^log_n.
+__global__ void domain_consts_kernel(int log_n, uint32_t* out /* 6 elements */) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  FT w = FT::two_adic_root();
+  for (int i = log_n; i < FT::Params::TWO_ADICITY; i++) w = w.sqr();
+  FT g = FT::generator();
+  FT ninv = FT::from_u64(1ull << log_n).inv();
+  FT gn = g;
+  for (int i = 0; i < log_n; i++) gn = gn.sqr();
+  FT zinv = (gn - FT::one()).inv();
+  w.store(out);
+  w.inv().store(out + EW);
+  g.store(out + 2 * EW);
+  g.inv().store(out + 3 * EW);
+  ninv.store(out + 4 * EW);
+  zinv.store(out + 5 * EW);
+}
+
+struct DomainConsts { FT w, winv, g, ginv, ninv, zinv; };
+
+hipError_t get_consts(hipStream_t st, int log_n, DomainConsts* c) {
+  uint32_t* d = nullptr;
+  PCD_HIP_TRY(hipMalloc(&d, 6 * EW * 4));
+  hipLaunchKernelGGL(domain_consts_kernel, dim3(1), dim3(64), 0, st, log_n, d);
+  hipError_t e = hipMemcpyAsync(c, d, 6 * EW * 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d);
+  return e;
+}
+
+hipError_t make_tables(hipStream_t st, int log_n, FftTables* t) {
+  DomainConsts c;
+  PCD_HIP_TRY(get_consts(st, log_n, &c));
+  const uint32_t n = 1u << log_n;
+  const size_t bytes = (size_t)n * EW * 4;
+  PCD_HIP_TRY(hipMalloc(&t->tw_fwd, bytes));
+  PCD_HIP_TRY(hipMalloc(&t->tw_inv, bytes));
+  PCD_HIP_TRY(hipMalloc(&t->coset, bytes));
+  PCD_HIP_TRY(hipMalloc(&t->coset_inv_scaled, bytes));
+  dim3 gd(((n + 255) / 256 + 63) / 64), bd(64);
+  hipLaunchKernelGGL(fft_fill_powers<FT>, gd, bd, 0, st, t->tw_fwd, n, c.w, FT::one());
+  hipLaunchKernelGGL(fft_fill_powers<FT>, gd, bd, 0, st, t->tw_inv, n, c.winv, FT::one());
+  hipLaunchKernelGGL(fft_fill_powers<FT>, gd, bd, 0, st, t->coset, n, c.g, FT::one());
+  hipLaunchKernelGGL(fft_fill_powers<FT>, gd, bd, 0, st, t->coset_inv_scaled, n, c.ginv, c.ninv);  // g^-j / n
+  PCD_HIP_TRY(hipGetLastError());
+  return hipStreamSynchronize(st);
+}
+
+// transform x in place (tmp = ping-pong partner).  inverse: w^-1 and 1/n;  coset: see fft.cuh header.
+hipError_t run(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t* tmp, int log_n, int inverse, int coset,
+               float* pass_ms, int* npasses) {
+  std::vector<FftPass> plan = fft_plan(log_n);
+  const int P = (int)plan.size();
+  const uint32_t* tw = inverse ? t.tw_inv : t.tw_fwd;
+  DomainConsts c;
+  FT scale = FT::one();
+  int use_scale = 0;
+  if (inverse && !coset) {  // plain 1/n: constant multiply in the last pass
+    PCD_HIP_TRY(get_consts(st, log_n, &c));
+    scale = c.ninv;
+    use_scale = 1;
+  }
+  std::vector<hipEvent_t> ev;
+  if (pass_ms) { ev.resize(P + 1); for (auto& e : ev) PCD_HIP_TRY(hipEventCreate(&e)); PCD_HIP_TRY(hipEventRecord(ev[0], st)); }
+  uint32_t* src = x;
+  uint32_t* dst = tmp;
+  int logs = 0;
+  for (int i = 0; i < P; i++) {
+    const int d = plan[i].d, logT = plan[i].logT;
+    const bool first = (i == 0), last = (i == P - 1);
+    const uint32_t* pre = (first && coset && !inverse) ? t.coset : nullptr;
+    const uint32_t* post = (last && coset && inverse) ? t.coset_inv_scaled : nullptr;
+    const uint32_t blocks = 1u << (log_n - d - logT);
+    const size_t lds = ((size_t)1 << (d + logT)) * EW * 4;
+    hipLaunchKernelGGL(fft_pass_kernel<FT>, dim3(blocks), dim3(256), lds, st, src, dst, tw, log_n, d, logT, logs, pre, post,
+                       (last ? use_scale : 0), scale);
+    if (pass_ms) PCD_HIP_TRY(hipEventRecord(ev[i + 1], st));
+    logs += d;
+    std::swap(src, dst);
+  }
+  PCD_HIP_TRY(hipGetLastError());
+  if (src != x) PCD_HIP_TRY(hipMemcpyAsync(x, src, ((size_t)1 << log_n) * EW * 4, hipMemcpyDeviceToDevice, st));
+  if (pass_ms) {
+    PCD_HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < P && i < 8; i++) (void)hipEventElapsedTime(&pass_ms[i], ev[i], ev[i + 1]);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+  }
+  if (npasses) *npasses = P;
+  return hipSuccess;
+}
+
+hipError_t convert(hipStream_t st, const uint32_t* in, uint32_t* out, uint32_t n, int to_mont) {
+  if (n == 0) return hipSuccess;
+  if (to_mont) hipLaunchKernelGGL((fp_convert_kernel<FT, true>), dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
+  else hipLaunchKernelGGL((fp_convert_kernel<FT, false>), dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
+  return hipGetLastError();
+}
+
+// out[i] = <M_i, z> (i < rows);  out[rows + j] = z[j] (j < num_inputs) if append_inputs;  0 up to n
+__global__ void __launch_bounds__(256) spmv_kernel(const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                   const uint32_t* __restrict__ coeff, uint32_t rows, const uint32_t* __restrict__ z,
+                                                   uint32_t num_inputs, int append_inputs, uint32_t n, uint32_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  FT acc = FT::zero();
+  if (i < rows) {
+    for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; k++)
+      acc = acc + FT::load(coeff + k * EW) * FT::load(z + (size_t)col[k] * EW);
+  } else if (append_inputs && i < rows + num_inputs) {
+    acc = FT::load(z + (size_t)(i - rows) * EW);
+  }
+  acc.store(out + (size_t)i * EW);
+}
+hipError_t spmv(hipStream_t st, const uint64_t* row_ptr, const uint32_t* col, const uint32_t* coeff, uint32_t rows,
+                const uint32_t* z, uint32_t num_inputs, int append_inputs, uint32_t n, uint32_t* out) {
+  hipLaunchKernelGGL(spmv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, row_ptr, col, coeff, rows, z, num_inputs, append_inputs, n, out);
+  return hipGetLastError();
+}
+
+hipError_t mul_sub_divz(hipStream_t st, uint32_t* a, const uint32_t* b, const uint32_t* c, int log_n) {
+  DomainConsts dc;
+  PCD_HIP_TRY(get_consts(st, log_n, &dc));
+  const uint32_t n = 1u << log_n;
+  hipLaunchKernelGGL(fft_mul_sub_scale<FT>, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, n, dc.zinv);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+#define PCD_CAT_(a, b) a##b
+#define PCD_CAT(a, b) PCD_CAT_(a, b)
+const FieldEntry* PCD_CAT(pcd_field_entry_, PCD_FIELD_IDX)() {
+  static const FieldEntry e = {EW, FT::Params::TWO_ADICITY, make_tables, run, convert, spmv, mul_sub_divz};
+  return &e;
+}
+
+}  // namespace pcd

@@ -1,0 +1,67 @@
+// One object per group (compile with -DPCD_GROUP_IDX=0..7, idx = 2 * curve_id + (group_id - 1)):
+// MSM driver + small point utilities instantiated for that group.
+#include "common.h"
+
+namespace pcd {
+
+#if PCD_GROUP_IDX == 0
+typedef G1_MNT4_298 GT;
+#elif PCD_GROUP_IDX == 1
+typedef G2_MNT4_298 GT;
+#elif PCD_GROUP_IDX == 2
+typedef G1_MNT6_298 GT;
+#elif PCD_GROUP_IDX == 3
+typedef G2_MNT6_298 GT;
+#elif PCD_GROUP_IDX == 4
+typedef G1_MNT4_753 GT;
+#elif PCD_GROUP_IDX == 5
+typedef G2_MNT4_753 GT;
+#elif PCD_GROUP_IDX == 6
+typedef G1_MNT6_753 GT;
+#elif PCD_GROUP_IDX == 7
+typedef G2_MNT6_753 GT;
+#else
+#error "PCD_GROUP_IDX must be 0..7"
+#endif
+
+namespace {
+
+typedef typename GT::F F;
+
+__global__ void points_sum_kernel(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Jac<F> acc = Jac<F>::infinity();
+  for (uint32_t i = 0; i < n; i++) acc = EC<GT>::add(acc, Jac<F>::load(in + (size_t)i * Jac<F>::WORDS));
+  acc.store(out);
+}
+__global__ void __launch_bounds__(64) to_affine_kernel(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F> a = EC<GT>::to_affine(Jac<F>::load(in + (size_t)i * Jac<F>::WORDS));
+  a.store(out + (size_t)i * Aff<F>::WORDS);
+}
+
+hipError_t msm_entry(MsmWorkspace& ws, hipStream_t st, const uint32_t* bases, const uint32_t* scalars, uint32_t n,
+                     uint32_t* out_dev, int c, uint32_t chunk, MsmTimings* tm) {
+  return msm_run<GT>(ws, st, bases, scalars, n, out_dev, c, chunk, tm);
+}
+hipError_t points_sum_entry(hipStream_t st, const uint32_t* jac, uint32_t n, uint32_t* out) {
+  hipLaunchKernelGGL(points_sum_kernel, dim3(1), dim3(64), 0, st, jac, n, out);
+  return hipGetLastError();
+}
+hipError_t to_affine_entry(hipStream_t st, const uint32_t* jac, uint32_t n, uint32_t* aff) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(to_affine_kernel, dim3((n + 63) / 64), dim3(64), 0, st, jac, n, aff);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+#define PCD_CAT_(a, b) a##b
+#define PCD_CAT(a, b) PCD_CAT_(a, b)
+const GroupEntry* PCD_CAT(pcd_group_entry_, PCD_GROUP_IDX)() {
+  static const GroupEntry e = {Aff<F>::WORDS, GT::FR::N, msm_entry, points_sum_entry, to_affine_entry};
+  return &e;
+}
+
+}  // namespace pcd

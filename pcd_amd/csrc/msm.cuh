@@ -1,0 +1,452 @@
+// Variable-base multi-scalar multiplication on gfx950 (K3/K4 of SURVEY.md section 8).
+//
+// Replaces ark-ec `VariableBaseMSM::multi_scalar_mul` [upstream msm/variable_base.rs] as called by
+// Groth16's prover under `IC::MainSNARK::prove` / `IC::HelpSNARK::prove`
+// (/root/reference src/ec_cycle_pcd/mod.rs:171,179): sum_i k_i * P_i for affine bases P_i and
+// canonical scalars k_i.  The value is a unique group element, so the GPU is free to organise the
+// bucket method differently from upstream (which parallelises over windows only):
+//
+//   1. msm_count     digits of every scalar -> per-(window,bucket) histogram          (HBM-bound)
+//   2. scan          exclusive prefix sum of the histogram
+//   3. msm_scatter   counting sort of base indices by (window,bucket)                  (HBM-bound)
+//   4. msm_accumulate fixed-size chunks of the sorted list, one lane per chunk: every lane does the
+//                    same number of mixed additions whatever the scalar distribution; runs that
+//                    cross a chunk edge are emitted as "pieces"                        (int-VALU-bound)
+//   5. msm_fixup / msm_big_bucket   pieces of one bucket are summed (tree in LDS for big buckets)
+//   6. msm_tail_level  sum_d d*B_d per window by blocked running sums, log_K(2^c) levels
+//   7. msm_horner    windows combined by c doublings each
+//
+// Zero digits never enter the sorted list (upstream skips zero scalars); a scalar equal to one is a
+// single entry in bucket (window 0, digit 1) exactly as its digits say, and its histogram / scatter
+// atomics are wave-aggregated so that bit-decomposition-heavy witnesses do not serialise on one
+// counter.
+#pragma once
+#include <algorithm>
+#include <vector>
+
+#include "ec.cuh"
+
+namespace pcd {
+
+struct MsmPlan {
+  uint32_t n = 0;
+  int c = 0;           // window bits
+  int W = 0;           // windows
+  uint32_t nkeys = 0;  // W << c
+  uint32_t chunk = 0;  // sorted entries per lane in msm_accumulate
+};
+
+inline int msm_pick_window(size_t n, int scalar_bits) {
+  // minimise  W*n (mixed adds, 11 M) + W*2^(c+1) (full adds, 16 M) over c
+  double best = 1e300;
+  int bc = 8;
+  for (int c = 6; c <= 18; c++) {
+    int W = (scalar_bits + c - 1) / c;
+    double cost = (double)W * (double)n * 11.0 + (double)W * (double)(2u << c) * 16.0 * 1.3;
+    if (cost < best) { best = cost; bc = c; }
+  }
+  return bc;
+}
+
+// ------------------------------------------------------------------------------------------------ digits
+template <int NS>
+PCD_DEV uint32_t msm_digit(const uint32_t* s, int w, int c) {
+  int bit = w * c;
+  int word = bit >> 5, off = bit & 31;
+  uint64_t x = s[word];
+  if (word + 1 < NS) x |= (uint64_t)s[word + 1] << 32;
+  return (uint32_t)(x >> off) & ((1u << c) - 1u);
+}
+
+template <int NS, bool SCATTER>
+__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
+                                                         uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                                         uint32_t* __restrict__ sorted_idx) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool live = i < n;
+  uint32_t s[NS];
+  bool is_one = false;
+  if (live) {
+    uint32_t hi = 0;
+#pragma unroll
+    for (int k = 0; k < NS; k++) { s[k] = scalars[(size_t)i * NS + k]; if (k) hi |= s[k]; }
+    is_one = (hi == 0 && s[0] == 1);
+  }
+  // wave-aggregated handling of the (window 0, digit 1) hot bucket
+  unsigned long long m = __ballot(live && is_one);
+  if (m) {
+    int lane = threadIdx.x & 63;
+    int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&cnt[1], (uint32_t)__popcll(m));
+    if (SCATTER) {
+      base = __shfl(base, leader, 64);
+      if (live && is_one) {
+        uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        sorted_idx[off[1] + base + rank] = i;
+      }
+    }
+  }
+  if (!live || is_one) return;
+  for (int w = 0; w < W; w++) {
+    uint32_t d = msm_digit<NS>(s, w, c);
+    if (d == 0) continue;
+    uint32_t key = ((uint32_t)w << c) | d;
+    uint32_t pos = atomicAdd(&cnt[key], 1u);
+    if (SCATTER) sorted_idx[off[key] + pos] = i;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ scan (exclusive, u32)
+static __global__ void __launch_bounds__(1024) scan_block_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t per_block,
+                                                         uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t sh[1024];
+  uint32_t b = blockIdx.x, lo = b * per_block, hi = min(n, lo + per_block);
+  uint32_t acc = 0;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += in[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) block_sums[b] = sh[0];
+}
+static __global__ void __launch_bounds__(1024) scan_apply(const uint32_t* __restrict__ in, uint32_t n, uint32_t per_block,
+                                                    const uint32_t* __restrict__ block_sums, uint32_t nblocks,
+                                                    uint32_t* __restrict__ out /* n + 1 */) {
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t carry;
+  uint32_t b = blockIdx.x, lo = b * per_block, hi = min(n, lo + per_block);
+  if (threadIdx.x == 0) { uint32_t a = 0; for (uint32_t k = 0; k < b; k++) a += block_sums[k]; carry = a; }
+  __syncthreads();
+  for (uint32_t base = lo; base < hi; base += 1024) {
+    uint32_t i = base + threadIdx.x;
+    uint32_t v = (i < hi) ? in[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {  // Hillis-Steele inclusive scan
+      uint32_t t = ((int)threadIdx.x >= s) ? sh[threadIdx.x - s] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < hi) out[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += sh[1023];
+    __syncthreads();
+  }
+  if (b == nblocks - 1 && threadIdx.x == 0) out[n] = carry;
+}
+
+// ------------------------------------------------------------------------------------------------ accumulate
+// key of sorted position p: largest key with off[key] <= p (skipping empty buckets)
+PCD_DEV uint32_t msm_find_key(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t p) {
+  uint32_t lo = 0, hi = nkeys;  // invariant off[lo] <= p < off[hi]
+  while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (off[mid] <= p) lo = mid; else hi = mid; }
+  return lo;
+}
+
+template <class G>
+__global__ void __launch_bounds__(64) msm_accumulate_kernel(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted_idx,
+                                                            const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t M,
+                                                            uint32_t chunk, uint32_t* __restrict__ buckets,
+                                                            uint32_t* __restrict__ piece_first, uint32_t* __restrict__ piece_last) {
+  typedef typename G::F F;
+  typedef EC<G> E;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t start64 = (uint64_t)t * chunk;
+  if (start64 >= M) return;
+  uint32_t start = (uint32_t)start64, end = (uint32_t)min((uint64_t)M, start64 + chunk);
+  uint32_t key = msm_find_key(off, nkeys, start);
+  uint32_t key_end = off[key + 1];
+  bool open_start = off[key] < start;  // current run began in an earlier chunk
+  Jac<F> acc = Jac<F>::infinity();
+  Aff<F> nxt = Aff<F>::load(bases + (size_t)sorted_idx[start] * Aff<F>::WORDS);
+  for (uint32_t p = start; p < end; p++) {
+    if (p >= key_end) {  // run of `key` is complete
+      if (open_start) { acc.store(piece_first + (size_t)t * Jac<F>::WORDS); open_start = false; }
+      else acc.store(buckets + (size_t)key * Jac<F>::WORDS);
+      acc = Jac<F>::infinity();
+      do { key++; key_end = off[key + 1]; } while (p >= key_end);
+    }
+    Aff<F> cur = nxt;
+    if (p + 1 < end) nxt = Aff<F>::load(bases + (size_t)sorted_idx[p + 1] * Aff<F>::WORDS);
+    acc = E::madd(acc, cur);
+  }
+  bool open_end = key_end > end;
+  if (open_end) acc.store(piece_last + (size_t)t * Jac<F>::WORDS);          // also the "middle piece" case
+  else if (open_start) acc.store(piece_first + (size_t)t * Jac<F>::WORDS);
+  else acc.store(buckets + (size_t)key * Jac<F>::WORDS);
+}
+
+// One lane per chunk: the chunk in which a split bucket STARTS sums that bucket's pieces, unless
+// there are more than `big_limit` of them (then the bucket goes to the big list).
+template <class G>
+__global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t M, uint32_t chunk,
+                                                       uint32_t nchunks, const uint32_t* __restrict__ piece_first,
+                                                       const uint32_t* __restrict__ piece_last, uint32_t* __restrict__ buckets,
+                                                       uint32_t big_limit, uint32_t* __restrict__ big_count,
+                                                       uint32_t* __restrict__ big_list /* (key, t0, t1) */, uint32_t big_cap) {
+  typedef typename G::F F;
+  typedef EC<G> E;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchunks) return;
+  uint64_t end64 = min((uint64_t)M, (uint64_t)(t + 1) * chunk);
+  uint32_t end = (uint32_t)end64, start = t * chunk;
+  uint32_t key = msm_find_key(off, nkeys, end - 1);
+  if (off[key + 1] <= end) return;   // last run closed inside this chunk
+  if (off[key] < start) return;      // bucket started earlier: this chunk is a middle piece
+  uint32_t t1 = (off[key + 1] - 1) / chunk;
+  if (t1 - t > big_limit) {
+    uint32_t slot = atomicAdd(big_count, 1u);
+    if (slot < big_cap) { big_list[3 * slot] = key; big_list[3 * slot + 1] = t; big_list[3 * slot + 2] = t1; }
+    return;
+  }
+  Jac<F> acc = Jac<F>::load(piece_last + (size_t)t * Jac<F>::WORDS);
+  for (uint32_t u = t + 1; u < t1; u++) acc = E::add(acc, Jac<F>::load(piece_last + (size_t)u * Jac<F>::WORDS));
+  acc = E::add(acc, Jac<F>::load(piece_first + (size_t)t1 * Jac<F>::WORDS));
+  acc.store(buckets + (size_t)key * Jac<F>::WORDS);
+}
+
+// One workgroup per big bucket: strided serial sums, then a tree through global scratch.
+template <class G>
+__global__ void __launch_bounds__(256) msm_big_bucket_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ piece_first,
+                                                             const uint32_t* __restrict__ piece_last, uint32_t* __restrict__ buckets,
+                                                             uint32_t* __restrict__ scratch /* gridDim.x * 256 points */) {
+  typedef typename G::F F;
+  typedef EC<G> E;
+  uint32_t key = big_list[3 * blockIdx.x], t0 = big_list[3 * blockIdx.x + 1], t1 = big_list[3 * blockIdx.x + 2];
+  uint32_t* my = scratch + (size_t)blockIdx.x * 256 * Jac<F>::WORDS;
+  Jac<F> acc = Jac<F>::infinity();
+  for (uint32_t u = t0 + threadIdx.x; u <= t1; u += 256) {
+    const uint32_t* src = (u == t1) ? piece_first : piece_last;
+    acc = E::add(acc, Jac<F>::load(src + (size_t)u * Jac<F>::WORDS));
+  }
+  acc.store(my + (size_t)threadIdx.x * Jac<F>::WORDS);
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      Jac<F> o = Jac<F>::load(my + (size_t)(threadIdx.x + s) * Jac<F>::WORDS);
+      acc = E::add(acc, o);
+      acc.store(my + (size_t)threadIdx.x * Jac<F>::WORDS);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) acc.store(buckets + (size_t)key * Jac<F>::WORDS);
+}
+
+// ------------------------------------------------------------------------------------------------ tail: sum_d d * B_d
+// State per window: weighted array A (weights 1..mA) and plain array C;  V = WS(A) + S(C).
+// One level with block size K = 2^k:  block j of A -> T_j (plain sum), L_j (weighted sum, weights 1..K)
+//   V = S(C) + S(L) + WS({K * T_j}_{j>=1});   A' = {2^k T_j}_{j>=1},  C' = blocksums(C) ++ L
+template <class G>
+__global__ void __launch_bounds__(64) msm_tail_level_kernel(const uint32_t* __restrict__ A_in, uint32_t mA, size_t strideA_in,
+                                                            const uint32_t* __restrict__ C_in, uint32_t mC, size_t strideC_in,
+                                                            uint32_t* __restrict__ A_out, size_t strideA_out,
+                                                            uint32_t* __restrict__ C_out, size_t strideC_out, int k) {
+  typedef typename G::F F;
+  typedef EC<G> E;
+  constexpr int PW = Jac<F>::WORDS;
+  uint32_t K = 1u << k;
+  uint32_t JA = (mA + K - 1) >> k, JC = (mC + K - 1) >> k;
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t w = blockIdx.y;
+  if (tid < JA) {
+    const uint32_t* A = A_in + w * strideA_in * PW;
+    Jac<F> run = Jac<F>::infinity(), acc = Jac<F>::infinity();
+    for (int tt = (int)K - 1; tt >= 0; tt--) {
+      uint32_t i = tid * K + tt;
+      if (i < mA) run = E::add(run, Jac<F>::load(A + (size_t)i * PW));
+      acc = E::add(acc, run);
+    }
+    acc.store(C_out + (w * strideC_out + JC + tid) * PW);
+    if (tid >= 1) {
+      for (int d = 0; d < k; d++) run = E::dbl(run);
+      run.store(A_out + (w * strideA_out + tid - 1) * PW);
+    }
+  } else if (tid < JA + JC) {
+    uint32_t j = tid - JA;
+    const uint32_t* Cw = C_in + w * strideC_in * PW;
+    Jac<F> acc = Jac<F>::infinity();
+    for (uint32_t tt = 0; tt < K; tt++) {
+      uint32_t i = j * K + tt;
+      if (i < mC) acc = E::add(acc, Jac<F>::load(Cw + (size_t)i * PW));
+    }
+    acc.store(C_out + (w * strideC_out + j) * PW);
+  }
+}
+
+// total = sum_w 2^(c w) V_w, V_w = C[w * strideC];  plus `extra` points added at the end
+template <class G>
+__global__ void msm_horner_kernel(const uint32_t* __restrict__ C, size_t strideC, int W, int c, uint32_t* __restrict__ out) {
+  typedef typename G::F F;
+  typedef EC<G> E;
+  constexpr int PW = Jac<F>::WORDS;
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Jac<F> total = Jac<F>::load(C + (size_t)(W - 1) * strideC * PW);
+  for (int w = W - 2; w >= 0; w--) {
+    for (int d = 0; d < c; d++) total = E::dbl(total);
+    total = E::add(total, Jac<F>::load(C + (size_t)w * strideC * PW));
+  }
+  total.store(out);
+}
+
+// ------------------------------------------------------------------------------------------------ host driver
+struct MsmWorkspace {
+  // device buffers, grown on demand and reused across calls (no allocation on the hot path once warm)
+  void* buf[16] = {nullptr};
+  size_t cap[16] = {0};
+  hipError_t ensure(int slot, size_t bytes) {
+    if (cap[slot] >= bytes) return hipSuccess;
+    if (buf[slot]) { hipError_t e = hipFree(buf[slot]); if (e != hipSuccess) return e; buf[slot] = nullptr; cap[slot] = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&buf[slot], want);
+    if (e != hipSuccess) return e;
+    cap[slot] = want;
+    return hipSuccess;
+  }
+  void release() { for (int i = 0; i < 16; i++) if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; } }
+};
+
+struct MsmTimings {  // milliseconds, filled when events are requested
+  float digits = 0, scan = 0, scatter = 0, accumulate = 0, fixup = 0, tail = 0, horner = 0, total = 0;
+};
+
+enum { WS_CNT = 0, WS_OFF, WS_BSUM, WS_SORTED, WS_BUCKETS, WS_PFIRST, WS_PLAST, WS_BIG, WS_BIGSCR, WS_A0, WS_A1, WS_C0, WS_C1, WS_OUT, WS_SCAL };
+
+#define PCD_HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+// scalars_dev: n * NS u32 (canonical), bases_dev: n affine points;  out_dev: one Jacobian point.
+template <class G>
+hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const uint32_t* bases_dev, const uint32_t* scalars_dev, uint32_t n,
+                   uint32_t* out_dev, int c_override, uint32_t chunk_override, MsmTimings* tm) {
+  typedef typename G::F F;
+  constexpr int NS = G::FR::N;
+  constexpr int PW = Jac<F>::WORDS;
+  constexpr size_t PB = (size_t)PW * 4;
+  if (n == 0) { Jac<F> inf = Jac<F>::infinity(); return hipMemcpyAsync(out_dev, &inf, PB, hipMemcpyHostToDevice, st); }
+  MsmPlan pl;
+  pl.n = n;
+  pl.c = c_override ? c_override : msm_pick_window(n, G::FR::BITS);
+  pl.W = (G::FR::BITS + pl.c - 1) / pl.c;
+  pl.nkeys = (uint32_t)pl.W << pl.c;
+  pl.chunk = chunk_override ? chunk_override : 32;
+  const uint64_t maxM = (uint64_t)n * pl.W;
+  if (maxM >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+
+  hipEvent_t ev[9];
+  if (tm) for (auto& e : ev) PCD_HIP_TRY(hipEventCreate(&e));
+  auto mark = [&](int i) -> hipError_t { return tm ? hipEventRecord(ev[i], st) : hipSuccess; };
+
+  PCD_HIP_TRY(ws.ensure(WS_CNT, (size_t)pl.nkeys * 4));
+  PCD_HIP_TRY(ws.ensure(WS_OFF, ((size_t)pl.nkeys + 1) * 4));
+  const uint32_t scan_per_block = 16384;
+  const uint32_t scan_blocks = (pl.nkeys + scan_per_block - 1) / scan_per_block;
+  PCD_HIP_TRY(ws.ensure(WS_BSUM, (size_t)scan_blocks * 4));
+  PCD_HIP_TRY(ws.ensure(WS_SORTED, (size_t)maxM * 4));
+  PCD_HIP_TRY(ws.ensure(WS_BUCKETS, (size_t)pl.nkeys * PB));
+  PCD_HIP_TRY(ws.ensure(WS_OUT, PB + 64));
+  uint32_t* cnt = (uint32_t*)ws.buf[WS_CNT];
+  uint32_t* off = (uint32_t*)ws.buf[WS_OFF];
+  uint32_t* bsum = (uint32_t*)ws.buf[WS_BSUM];
+  uint32_t* sorted = (uint32_t*)ws.buf[WS_SORTED];
+  uint32_t* buckets = (uint32_t*)ws.buf[WS_BUCKETS];
+
+  PCD_HIP_TRY(mark(0));
+  // 1. histogram
+  PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)pl.nkeys * 4, st));
+  dim3 gd((n + 255) / 256), bd(256);
+  hipLaunchKernelGGL((msm_digits_kernel<NS, false>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, cnt, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+  PCD_HIP_TRY(mark(1));
+  // 2. scan
+  hipLaunchKernelGGL(scan_block_sums, dim3(scan_blocks), dim3(1024), 0, st, cnt, pl.nkeys, scan_per_block, bsum);
+  hipLaunchKernelGGL(scan_apply, dim3(scan_blocks), dim3(1024), 0, st, cnt, pl.nkeys, scan_per_block, bsum, scan_blocks, off);
+  uint32_t M = 0;
+  PCD_HIP_TRY(hipMemcpyAsync(&M, off + pl.nkeys, 4, hipMemcpyDeviceToHost, st));
+  PCD_HIP_TRY(hipStreamSynchronize(st));  // M sizes the accumulate grid
+  PCD_HIP_TRY(mark(2));
+  if (M == 0) {
+    Jac<F> inf = Jac<F>::infinity();
+    PCD_HIP_TRY(hipMemcpyAsync(out_dev, &inf, PB, hipMemcpyHostToDevice, st));
+    if (tm) { for (auto& e : ev) (void)hipEventDestroy(e); }
+    return hipStreamSynchronize(st);
+  }
+  // 3. scatter (cursor = cnt reset to zero)
+  PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)pl.nkeys * 4, st));
+  hipLaunchKernelGGL((msm_digits_kernel<NS, true>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, cnt, off, sorted);
+  PCD_HIP_TRY(mark(3));
+  // 4. accumulate
+  const uint32_t nchunks = (uint32_t)(((uint64_t)M + pl.chunk - 1) / pl.chunk);
+  PCD_HIP_TRY(ws.ensure(WS_PFIRST, (size_t)nchunks * PB));
+  PCD_HIP_TRY(ws.ensure(WS_PLAST, (size_t)nchunks * PB));
+  const uint32_t big_cap = 4096;
+  PCD_HIP_TRY(ws.ensure(WS_BIG, (size_t)(3 * big_cap + 4) * 4));
+  uint32_t* pfirst = (uint32_t*)ws.buf[WS_PFIRST];
+  uint32_t* plast = (uint32_t*)ws.buf[WS_PLAST];
+  uint32_t* big = (uint32_t*)ws.buf[WS_BIG];
+  uint32_t* big_count = big + 3 * big_cap;
+  PCD_HIP_TRY(hipMemsetAsync(buckets, 0, (size_t)pl.nkeys * PB, st));  // Z = 0: identity
+  PCD_HIP_TRY(hipMemsetAsync(big_count, 0, 4, st));
+  hipLaunchKernelGGL((msm_accumulate_kernel<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, bases_dev, sorted, off, pl.nkeys, M, pl.chunk,
+                     buckets, pfirst, plast);
+  PCD_HIP_TRY(mark(4));
+  // 5. pieces
+  const uint32_t big_limit = 8;
+  hipLaunchKernelGGL((msm_fixup_kernel<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, off, pl.nkeys, M, pl.chunk, nchunks, pfirst, plast,
+                     buckets, big_limit, big_count, big, big_cap);
+  uint32_t nbig = 0;
+  PCD_HIP_TRY(hipMemcpyAsync(&nbig, big_count, 4, hipMemcpyDeviceToHost, st));
+  PCD_HIP_TRY(hipStreamSynchronize(st));
+  if (nbig > big_cap) return hipErrorOutOfMemory;
+  if (nbig) {
+    PCD_HIP_TRY(ws.ensure(WS_BIGSCR, (size_t)nbig * 256 * PB));
+    hipLaunchKernelGGL((msm_big_bucket_kernel<G>), dim3(nbig), dim3(256), 0, st, big, pfirst, plast, buckets, (uint32_t*)ws.buf[WS_BIGSCR]);
+  }
+  PCD_HIP_TRY(mark(5));
+  // 6. tail levels
+  {
+    const uint32_t B = (1u << pl.c) - 1;
+    size_t cap_pts = ((size_t)1 << pl.c);  // generous per-window capacity for A'/C'
+    PCD_HIP_TRY(ws.ensure(WS_A0, (size_t)pl.W * cap_pts * PB / 2 + PB * pl.W * 4));
+    PCD_HIP_TRY(ws.ensure(WS_A1, (size_t)pl.W * cap_pts * PB / 2 + PB * pl.W * 4));
+    PCD_HIP_TRY(ws.ensure(WS_C0, (size_t)pl.W * cap_pts * PB / 2 + PB * pl.W * 4));
+    PCD_HIP_TRY(ws.ensure(WS_C1, (size_t)pl.W * cap_pts * PB / 2 + PB * pl.W * 4));
+    const size_t strideAC = cap_pts / 2 + 4;
+    const uint32_t* A_in = buckets + PW;  // bucket d = 1 of window 0
+    size_t strideA_in = (size_t)1 << pl.c;
+    const uint32_t* C_in = nullptr;
+    size_t strideC_in = 0;
+    uint32_t mA = B, mC = 0;
+    int flip = 0, level = 0;
+    while (mA > 0 || mC > 1) {
+      int k = (level == 0) ? 3 : 2;
+      if (mA == 0 && mC <= 8) k = 3;
+      uint32_t K = 1u << k;
+      uint32_t JA = (mA + K - 1) >> k, JC = (mC + K - 1) >> k;
+      uint32_t* A_out = (uint32_t*)ws.buf[flip ? WS_A1 : WS_A0];
+      uint32_t* C_out = (uint32_t*)ws.buf[flip ? WS_C1 : WS_C0];
+      uint32_t threads = JA + JC;
+      hipLaunchKernelGGL((msm_tail_level_kernel<G>), dim3((threads + 63) / 64, pl.W), dim3(64), 0, st, A_in, mA, strideA_in, C_in, mC,
+                         strideC_in, A_out, strideAC, C_out, strideAC, k);
+      mA = JA ? JA - 1 : 0;
+      mC = JC + JA;
+      A_in = A_out; strideA_in = strideAC;
+      C_in = C_out; strideC_in = strideAC;
+      flip ^= 1;
+      level++;
+    }
+    PCD_HIP_TRY(mark(6));
+    // 7. windows
+    hipLaunchKernelGGL((msm_horner_kernel<G>), dim3(1), dim3(64), 0, st, C_in, strideC_in, pl.W, pl.c, out_dev);
+    PCD_HIP_TRY(mark(7));
+  }
+  PCD_HIP_TRY(hipGetLastError());
+  if (tm) {
+    PCD_HIP_TRY(hipStreamSynchronize(st));
+    auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; };
+    tm->digits = el(0, 1); tm->scan = el(1, 2); tm->scatter = el(2, 3); tm->accumulate = el(3, 4);
+    tm->fixup = el(4, 5); tm->tail = el(5, 6); tm->horner = el(6, 7); tm->total = el(0, 7);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+  }
+  return hipSuccess;
+}
+
+}  // namespace pcd
