@@ -82,6 +82,13 @@ int pcdhip_msm(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const 
 /* Same with scalars already resident on the device (element `scalar_offset` onwards). */
 int pcdhip_msm_dev(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars,
                    size_t scalar_offset, size_t n, uint64_t* out_xyz_mont);
+/* Precomputed window-shifted copies of bases uploaded AFTER this call through this context
+ * (HBM capacity traded against the serial window combine; the proving key of a PCD is fixed for the whole
+ * computation, so the one-time cost amortises over every step):
+ *   -1 (default) one copy per scalar window: a single bucket window, no doubling chain at all;
+ *    0           none (W bucket windows + Horner combine, as upstream);   k >= 2  k copies.
+ * Falls back to fewer copies when device memory does not suffice. */
+int pcdhip_set_precompute(pcdhip_ctx* ctx, int mode);
 /* Tuning / introspection: window bits (0 = automatic), sorted entries per lane (0 = default). */
 int pcdhip_msm_config(pcdhip_ctx* ctx, int window_bits, int chunk);
 /* Per-stage device time of the last MSM (HIP events on the context's stream), milliseconds:

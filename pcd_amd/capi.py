@@ -45,7 +45,7 @@ EXPORTS = [
     "pcdhip_field_limbs", "pcdhip_curve_base_field", "pcdhip_curve_scalar_field", "pcdhip_point_limbs",
     "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
     "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config",
-    "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_to_affine",
+    "pcdhip_set_precompute", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
     "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings",
     "pcdhip_timer_start", "pcdhip_timer_stop",
@@ -144,6 +144,10 @@ class Context:
     def msm_config(self, window_bits=0, chunk=0):
         self._check(lib().pcdhip_msm_config(self._ctx, window_bits, chunk))
 
+    def set_precompute(self, mode):
+        """-1 full (default), 0 none, k >= 2 copies; applies to bases uploaded afterwards."""
+        self._check(lib().pcdhip_set_precompute(self._ctx, int(mode)))
+
     def msm_profile(self, on=True):
         self._check(lib().pcdhip_msm_profile(self._ctx, int(on)))
 
@@ -193,7 +197,7 @@ class Context:
         return s
 
     def witness_map(self, field, r1cs):
-        """R1CSToQAP::witness_map: r1cs has rp_/col_/coeff_{a,b,c}, z, num_inputs (oracle.coracle.R1CS layout)."""
+        """R1CSToQAP::witness_map: r1cs has rp_/col_/coeff_{a,b,c}, z, num_inputs (any object with those numpy arrays)."""
         A = self._csr(r1cs.rp_a, r1cs.col_a, r1cs.coeff_a)
         B = self._csr(r1cs.rp_b, r1cs.col_b, r1cs.coeff_b)
         Cm = self._csr(r1cs.rp_c, r1cs.col_c, r1cs.coeff_c)

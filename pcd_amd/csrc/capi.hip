@@ -208,18 +208,45 @@ int pcdhip_bases_upload(pcdhip_ctx* ctx, int curve_id, int group_id, const uint6
   const size_t pl = (size_t)pcdhip_point_limbs(curve_id, group_id);
   pcdhip_bases* b = new (std::nothrow) pcdhip_bases();
   if (!b) return PCDHIP_E_OOM;
-  b->curve_id = curve_id; b->group_id = group_id; b->n = n; b->dptr = nullptr;
-  hipError_t e = hipMalloc(&b->dptr, std::max<size_t>(n, 1) * pl * 8);
+  b->curve_id = curve_id; b->group_id = group_id; b->n = n; b->dptr = nullptr; b->c = 0; b->groups = 1;
+  const GroupEntry& ge = group_entry(curve_id, group_id);
+  // Precomputed window-shifted copies (HBM capacity traded for the serial window combine): group g
+  // holds 2^(c Wg g) P_i.  Full precomputation (Wg = 1) needs W copies of the query vector.
+  if (ctx->precompute != 0 && n >= 64) {
+    const bool full = ctx->precompute < 0;
+    const int c = ctx->msm_c ? ctx->msm_c : msm_pick_window(n, ge.scalar_bits, full ? 1 : 0);
+    const int W = (ge.scalar_bits + c - 1) / c;
+    b->c = c;
+    b->groups = full ? W : std::min(W, ctx->precompute);
+  }
+  hipError_t e = hipErrorOutOfMemory;
+  while (true) {
+    e = hipMalloc(&b->dptr, std::max<size_t>(n, 1) * pl * 8 * b->groups);
+    if (e == hipSuccess || b->groups == 1) break;
+    (void)hipGetLastError();
+    b->groups = (b->groups + 1) / 2;  // not enough HBM for this many copies: fewer groups, more bucket windows
+  }
   if (e != hipSuccess) { delete b; return fail(ctx, e); }
+  if (b->groups == 1) b->c = 0;
   e = hipMemcpyAsync(b->dptr, xy, n * pl * 8, hipMemcpyHostToDevice, ctx->stream);
   // points at infinity become (0, 0) on device (not on any of the curves: b != 0)
   if (e == hipSuccess && inf) {
     for (size_t i = 0; i < n && e == hipSuccess; i++)
       if (inf[i]) e = hipMemsetAsync((char*)b->dptr + i * pl * 8, 0, pl * 8, ctx->stream);
   }
+  if (e == hipSuccess && b->groups > 1) {
+    const int W = (ge.scalar_bits + b->c - 1) / b->c;
+    const int Wg = (W + b->groups - 1) / b->groups;
+    e = ge.precompute(ctx->stream, b->dptr, (uint32_t)n, b->groups, b->c * Wg);
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { (void)hipFree(b->dptr); delete b; return fail(ctx, e); }
   *out = b;
+  return PCDHIP_OK;
+}
+int pcdhip_set_precompute(pcdhip_ctx* ctx, int mode) {
+  if (!ctx || mode < -1 || mode == 1) return PCDHIP_E_ARG;
+  ctx->precompute = mode;
   return PCDHIP_OK;
 }
 void pcdhip_bases_free(pcdhip_ctx* ctx, pcdhip_bases* bases) {
@@ -253,8 +280,8 @@ static int msm_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset,
   const size_t out_bytes = (size_t)ge.point_words / 2 * 3 * 4;
   TRY(ctx->msm_ws.ensure(WS_OUT, out_bytes + 64));
   uint32_t* out_dev = (uint32_t*)ctx->msm_ws.buf[WS_OUT];
-  TRY(ge.msm(ctx->msm_ws, ctx->stream, bases->dptr + offset * ge.point_words, scalars_dev, (uint32_t)n, out_dev, ctx->msm_c,
-             ctx->msm_chunk, ctx->msm_profile ? &ctx->msm_tm : nullptr));
+  TRY(ge.msm(ctx->msm_ws, ctx->stream, bases->view(offset), scalars_dev, (uint32_t)n, out_dev, ctx->msm_c, ctx->msm_chunk,
+             ctx->msm_profile ? &ctx->msm_tm : nullptr));
   out_dev = (uint32_t*)ctx->msm_ws.buf[WS_OUT];
   TRY(hipMemcpyAsync(out_xyz, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
@@ -533,15 +560,15 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   const uint32_t sw = (uint32_t)limbs * 2;
   const size_t hl = std::min<size_t>(pk->h_query->n, n);
   MsmTimings* tm = nullptr;
-  TRY(g1.msm(ctx->msm_ws, st, pk->h_query->dptr, h_can, (uint32_t)hl, msm_g1, ctx->msm_c, ctx->msm_chunk, tm));
+  TRY(g1.msm(ctx->msm_ws, st, pk->h_query->view(0), h_can, (uint32_t)hl, msm_g1, ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[2], st));
-  TRY(g1.msm(ctx->msm_ws, st, pk->l_query->dptr, z_can + ni * sw, (uint32_t)(m - ni), (uint32_t*)((char*)msm_g1 + j1), ctx->msm_c, ctx->msm_chunk, tm));
+  TRY(g1.msm(ctx->msm_ws, st, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni), (uint32_t*)((char*)msm_g1 + j1), ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[3], st));
-  TRY(g1.msm(ctx->msm_ws, st, pk->a_query->dptr + g1.point_words, z_can + sw, (uint32_t)(m - 1), (uint32_t*)((char*)msm_g1 + 2 * j1), ctx->msm_c, ctx->msm_chunk, tm));
+  TRY(g1.msm(ctx->msm_ws, st, pk->a_query->view(1), z_can + sw, (uint32_t)(m - 1), (uint32_t*)((char*)msm_g1 + 2 * j1), ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[4], st));
-  TRY(g1.msm(ctx->msm_ws, st, pk->b_g1_query->dptr + g1.point_words, z_can + sw, (uint32_t)(m - 1), (uint32_t*)((char*)msm_g1 + 3 * j1), ctx->msm_c, ctx->msm_chunk, tm));
+  TRY(g1.msm(ctx->msm_ws, st, pk->b_g1_query->view(1), z_can + sw, (uint32_t)(m - 1), (uint32_t*)((char*)msm_g1 + 3 * j1), ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[5], st));
-  TRY(g2.msm(ctx->msm_ws, st, pk->b_g2_query->dptr + g2.point_words, z_can + sw, (uint32_t)(m - 1), msm_g2, ctx->msm_c, ctx->msm_chunk, tm));
+  TRY(g2.msm(ctx->msm_ws, st, pk->b_g2_query->view(1), z_can + sw, (uint32_t)(m - 1), msm_g2, ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[6], st));
   // K5: assembly
   TRY(ce.assemble(st, msm_g1, msm_g2, pk->singles, rs_dev, scratch, proof_dev));

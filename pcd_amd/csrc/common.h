@@ -28,7 +28,10 @@ struct pcdhip_buf {
 struct pcdhip_bases {
   int curve_id, group_id;
   size_t n;
-  uint32_t* dptr;  // n affine points, (0,0) = infinity
+  uint32_t* dptr;  // groups * n affine points, (0,0) = infinity; group g holds 2^(c * Wg * g) P_i
+  int c;           // window bits fixed at upload when groups > 1 (0 otherwise)
+  int groups;      // 1 = plain bases
+  pcd::MsmBasesView view(size_t offset) const { return {dptr, (uint32_t)n, (uint32_t)offset, c, groups}; }
 };
 struct pcdhip_g16_pk {
   int curve_id;
@@ -44,6 +47,7 @@ struct pcdhip_ctx {
   std::map<uint64_t, pcd::FftTables> fft_tables;
   int msm_c = 0;
   uint32_t msm_chunk = 0;
+  int precompute = -1;  // bases uploaded through this context: -1 full (one bucket window), 0 none, k > 1 groups
   bool msm_profile = false;
   pcd::MsmTimings msm_tm;
   float fft_ms[8] = {0};
@@ -56,14 +60,17 @@ struct pcdhip_ctx {
 namespace pcd {
 
 // ---- per-group entries (inst_group.hip, one object per group) ------------------------------------
-typedef hipError_t (*MsmFn)(MsmWorkspace&, hipStream_t, const uint32_t* bases, const uint32_t* scalars, uint32_t n,
+typedef hipError_t (*MsmFn)(MsmWorkspace&, hipStream_t, const MsmBasesView& bases, const uint32_t* scalars, uint32_t n,
                             uint32_t* out_dev, int c, uint32_t chunk, MsmTimings* tm);
+typedef hipError_t (*PrecomputeFn)(hipStream_t, uint32_t* pts, uint32_t n, int groups, int shift);
 typedef hipError_t (*PointsSumFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* out_dev);
 typedef hipError_t (*ToAffineFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* aff_dev);
 struct GroupEntry {
   int point_words;  // u32 words per affine point
   int scalar_words; // u32 words per scalar
+  int scalar_bits;
   MsmFn msm;
+  PrecomputeFn precompute;
   PointsSumFn points_sum;
   ToAffineFn to_affine;
 };

@@ -95,15 +95,16 @@ struct Fp {
   PCD_HD Fp neg() const { return is_zero() ? *this : (zero() - *this); }
   PCD_HD Fp dbl() const { return *this + *this; }
 
-  // CIOS Montgomery product, canonical output in [0, p).  Deliberately NOT inlined and with a rolled
-  // row loop: one copy of the multiplier per field per code object keeps the point kernels (11-16
+  // CIOS Montgomery product, canonical output in [0, p).  Deliberately NOT inlined: one fully
+  // unrolled copy of the multiplier per field per code object keeps the point kernels (11-16
   // products per group operation, x3 / x6 for Fq2 / Fq3) at a compilable size; operands travel by
-  // value in VGPRs.
+  // value in VGPRs.  (A rolled row loop reads a.v[i] through scratch: ~500 cycles of exposed latency
+  // per row for a lone wave -- measured 2.5 us per 298-bit product in the serial MSM tail.)
   __host__ __device__ __noinline__ static Fp mul(Fp a, Fp b) {
     uint32_t t[N + 2];
 #pragma unroll
     for (int i = 0; i < N + 2; i++) t[i] = 0;
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; i++) {
       const uint32_t ai = a.v[i];
       uint32_t c = 0;
@@ -189,19 +190,22 @@ struct Fp2 {
   PCD_HD Fp2 operator-(const Fp2& b) const { return {c0 - b.c0, c1 - b.c1}; }
   PCD_HD Fp2 neg() const { return {c0.neg(), c1.neg()}; }
   PCD_HD Fp2 dbl() const { return {c0.dbl(), c1.dbl()}; }
-  // (not inlined, like Fp::mul: bounds the code size of the G2 point kernels)
-  __host__ __device__ __noinline__ static Fp2 mul(Fp2 a, Fp2 b) {
+  // (not inlined, like Fp::mul: bounds the code size of the G2 point kernels; operands by reference --
+  // large by-value aggregates passed on the stack miscompiled for Fp3 on gfx950 / ROCm 7.2)
+  __host__ __device__ __noinline__ static void mul(Fp2& o, const Fp2& a, const Fp2& b) {
     F v0 = a.c0 * b.c0, v1 = a.c1 * b.c1;
     F s = (a.c0 + a.c1) * (b.c0 + b.c1);
-    return {v0 + v1.mul_small(NR), s - v0 - v1};
+    o.c0 = v0 + v1.mul_small(NR);
+    o.c1 = s - v0 - v1;
   }
-  __host__ __device__ __noinline__ static Fp2 sqr_(Fp2 a) {  // complex squaring: 2 base multiplications
+  __host__ __device__ __noinline__ static void sqr_(Fp2& o, const Fp2& a) {  // complex squaring: 2 base multiplications
     F ab = a.c0 * a.c1;
     F t = (a.c0 + a.c1) * (a.c0 + a.c1.mul_small(NR));
-    return {t - ab - ab.mul_small(NR), ab.dbl()};
+    o.c0 = t - ab - ab.mul_small(NR);
+    o.c1 = ab.dbl();
   }
-  PCD_HD Fp2 operator*(const Fp2& b) const { return mul(*this, b); }
-  PCD_HD Fp2 sqr() const { return sqr_(*this); }
+  PCD_HD Fp2 operator*(const Fp2& b) const { Fp2 o; mul(o, *this, b); return o; }
+  PCD_HD Fp2 sqr() const { Fp2 o; sqr_(o, *this); return o; }
   PCD_HD Fp2 mul_small(unsigned k) const { return {c0.mul_small(k), c1.mul_small(k)}; }
   PCD_HD Fp2 mul_base(const F& k) const { return {c0 * k, c1 * k}; }
   PCD_HD Fp2 inv() const {
@@ -229,14 +233,16 @@ struct Fp3 {
   PCD_HD Fp3 operator-(const Fp3& b) const { return {c0 - b.c0, c1 - b.c1, c2 - b.c2}; }
   PCD_HD Fp3 neg() const { return {c0.neg(), c1.neg(), c2.neg()}; }
   PCD_HD Fp3 dbl() const { return {c0.dbl(), c1.dbl(), c2.dbl()}; }
-  __host__ __device__ __noinline__ static Fp3 mul(Fp3 a, Fp3 b) {
+  __host__ __device__ __noinline__ static void mul(Fp3& o, const Fp3& a, const Fp3& b) {
     F ad = a.c0 * b.c0, be = a.c1 * b.c1, cf = a.c2 * b.c2;
     F x = (a.c1 + a.c2) * (b.c1 + b.c2) - be - cf;
     F y = (a.c0 + a.c1) * (b.c0 + b.c1) - ad - be;
     F z = (a.c0 + a.c2) * (b.c0 + b.c2) - ad + be - cf;
-    return {ad + x.mul_small(NR), y + cf.mul_small(NR), z};
+    o.c0 = ad + x.mul_small(NR);
+    o.c1 = y + cf.mul_small(NR);
+    o.c2 = z;
   }
-  __host__ __device__ __noinline__ static Fp3 sqr_(Fp3 a) {  // CH-SQR2: 2 mul + 3 sqr in the base field
+  __host__ __device__ __noinline__ static void sqr_(Fp3& o, const Fp3& a) {  // CH-SQR2: 2 mul + 3 sqr in the base field
     F s0 = a.c0.sqr();
     F ab = a.c0 * a.c1;
     F s1 = ab.dbl();
@@ -244,10 +250,12 @@ struct Fp3 {
     F bc = a.c1 * a.c2;
     F s3 = bc.dbl();
     F s4 = a.c2.sqr();
-    return {s0 + s3.mul_small(NR), s1 + s4.mul_small(NR), s1 + s2 + s3 - s0 - s4};
+    o.c0 = s0 + s3.mul_small(NR);
+    o.c1 = s1 + s4.mul_small(NR);
+    o.c2 = s1 + s2 + s3 - s0 - s4;
   }
-  PCD_HD Fp3 operator*(const Fp3& b) const { return mul(*this, b); }
-  PCD_HD Fp3 sqr() const { return sqr_(*this); }
+  PCD_HD Fp3 operator*(const Fp3& b) const { Fp3 o; mul(o, *this, b); return o; }
+  PCD_HD Fp3 sqr() const { Fp3 o; sqr_(o, *this); return o; }
   PCD_HD Fp3 mul_small(unsigned k) const { return {c0.mul_small(k), c1.mul_small(k), c2.mul_small(k)}; }
   PCD_HD Fp3 mul_base(const F& k) const { return {c0 * k, c1 * k, c2 * k}; }
   PCD_HD Fp3 inv() const {

@@ -28,7 +28,7 @@ namespace {
 
 typedef typename GT::F F;
 
-__global__ void points_sum_kernel(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) points_sum_kernel(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   Jac<F> acc = Jac<F>::infinity();
   for (uint32_t i = 0; i < n; i++) acc = EC<GT>::add(acc, Jac<F>::load(in + (size_t)i * Jac<F>::WORDS));
@@ -41,9 +41,12 @@ __global__ void __launch_bounds__(64) to_affine_kernel(const uint32_t* __restric
   a.store(out + (size_t)i * Aff<F>::WORDS);
 }
 
-hipError_t msm_entry(MsmWorkspace& ws, hipStream_t st, const uint32_t* bases, const uint32_t* scalars, uint32_t n,
+hipError_t msm_entry(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bases, const uint32_t* scalars, uint32_t n,
                      uint32_t* out_dev, int c, uint32_t chunk, MsmTimings* tm) {
   return msm_run<GT>(ws, st, bases, scalars, n, out_dev, c, chunk, tm);
+}
+hipError_t precompute_entry(hipStream_t st, uint32_t* pts, uint32_t n, int groups, int shift) {
+  return msm_precompute<GT>(st, pts, n, groups, shift);
 }
 hipError_t points_sum_entry(hipStream_t st, const uint32_t* jac, uint32_t n, uint32_t* out) {
   hipLaunchKernelGGL(points_sum_kernel, dim3(1), dim3(64), 0, st, jac, n, out);
@@ -60,7 +63,7 @@ hipError_t to_affine_entry(hipStream_t st, const uint32_t* jac, uint32_t n, uint
 #define PCD_CAT_(a, b) a##b
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const GroupEntry* PCD_CAT(pcd_group_entry_, PCD_GROUP_IDX)() {
-  static const GroupEntry e = {Aff<F>::WORDS, GT::FR::N, msm_entry, points_sum_entry, to_affine_entry};
+  static const GroupEntry e = {Aff<F>::WORDS, GT::FR::N, GT::FR::BITS, msm_entry, precompute_entry, points_sum_entry, to_affine_entry};
   return &e;
 }
 

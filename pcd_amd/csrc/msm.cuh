@@ -36,13 +36,15 @@ struct MsmPlan {
   uint32_t chunk = 0;  // sorted entries per lane in msm_accumulate
 };
 
-inline int msm_pick_window(size_t n, int scalar_bits) {
-  // minimise  W*n (mixed adds, 11 M) + W*2^(c+1) (full adds, 16 M) over c
+// minimise  W*n mixed adds (11 M) + Wg * 2^(c+1) full adds (16 M) over c, where Wg = bucket windows:
+// Wg = W without precomputed bases, Wg = ceil(W / groups) with them (full_precompute: Wg = 1).
+inline int msm_pick_window(size_t n, int scalar_bits, int full_precompute) {
   double best = 1e300;
   int bc = 8;
   for (int c = 6; c <= 18; c++) {
     int W = (scalar_bits + c - 1) / c;
-    double cost = (double)W * (double)n * 11.0 + (double)W * (double)(2u << c) * 16.0 * 1.3;
+    int Wg = full_precompute ? 1 : W;
+    double cost = (double)W * (double)n * 11.0 + (double)Wg * (double)(2u << c) * 16.0 * 1.3;
     if (cost < best) { best = cost; bc = c; }
   }
   return bc;
@@ -58,8 +60,12 @@ PCD_DEV uint32_t msm_digit(const uint32_t* s, int w, int c) {
   return (uint32_t)(x >> off) & ((1u << c) - 1u);
 }
 
+// Window w of the scalar belongs to group g = w / Wg and bucket window j = w % Wg: with precomputed
+// bases the point used is 2^(c Wg g) P_i, stored at index g * n_total + i, so all groups share the
+// same Wg bucket windows (Wg = 1: no window combine at all).
 template <int NS, bool SCATTER>
-__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
+__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, int Wg,
+                                                         uint32_t n_total, uint32_t base_offset,
                                                          uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
                                                          uint32_t* __restrict__ sorted_idx) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,17 +89,20 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
       base = __shfl(base, leader, 64);
       if (live && is_one) {
         uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        sorted_idx[off[1] + base + rank] = i;
+        sorted_idx[off[1] + base + rank] = base_offset + i;
       }
     }
   }
   if (!live || is_one) return;
+  int g = 0, j = 0;
   for (int w = 0; w < W; w++) {
     uint32_t d = msm_digit<NS>(s, w, c);
-    if (d == 0) continue;
-    uint32_t key = ((uint32_t)w << c) | d;
-    uint32_t pos = atomicAdd(&cnt[key], 1u);
-    if (SCATTER) sorted_idx[off[key] + pos] = i;
+    if (d != 0) {
+      uint32_t key = ((uint32_t)j << c) | d;
+      uint32_t pos = atomicAdd(&cnt[key], 1u);
+      if (SCATTER) sorted_idx[off[key] + pos] = (uint32_t)g * n_total + base_offset + i;
+    }
+    if (++j == Wg) { j = 0; g++; }
   }
 }
 
@@ -276,7 +285,7 @@ __global__ void __launch_bounds__(64) msm_tail_level_kernel(const uint32_t* __re
 
 // total = sum_w 2^(c w) V_w, V_w = C[w * strideC];  plus `extra` points added at the end
 template <class G>
-__global__ void msm_horner_kernel(const uint32_t* __restrict__ C, size_t strideC, int W, int c, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) msm_horner_kernel(const uint32_t* __restrict__ C, size_t strideC, int W, int c, uint32_t* __restrict__ out) {
   typedef typename G::F F;
   typedef EC<G> E;
   constexpr int PW = Jac<F>::WORDS;
@@ -287,6 +296,31 @@ __global__ void msm_horner_kernel(const uint32_t* __restrict__ C, size_t strideC
     total = E::add(total, Jac<F>::load(C + (size_t)w * strideC * PW));
   }
   total.store(out);
+}
+
+// ------------------------------------------------------------------------------------------------ precomputed bases
+// out[g * n + i] = 2^(shift * g) * P_i  (affine), g = 0 .. groups-1.  One lane per point; one-time cost at
+// key upload (the proving key of a PCD is fixed for the whole computation).
+template <class G>
+__global__ void __launch_bounds__(64) msm_precompute_kernel(uint32_t* __restrict__ pts, uint32_t n, int groups, int shift) {
+  typedef typename G::F F;
+  typedef EC<G> E;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F> p = Aff<F>::load(pts + (size_t)i * Aff<F>::WORDS);
+  Jac<F> q = p.is_inf() ? Jac<F>::infinity() : Jac<F>{p.x, p.y, F::one()};
+  for (int g = 1; g < groups; g++) {
+    for (int d = 0; d < shift; d++) q = E::dbl(q);
+    Aff<F> a = E::to_affine(q);
+    a.store(pts + ((size_t)g * n + i) * Aff<F>::WORDS);
+    if (!q.is_inf()) q = Jac<F>{a.x, a.y, F::one()};  // keep Z = 1: cheaper doublings, same point
+  }
+}
+template <class G>
+hipError_t msm_precompute(hipStream_t st, uint32_t* pts, uint32_t n, int groups, int shift) {
+  if (n == 0 || groups <= 1) return hipSuccess;
+  hipLaunchKernelGGL((msm_precompute_kernel<G>), dim3((n + 63) / 64), dim3(64), 0, st, pts, n, groups, shift);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ host driver
@@ -315,9 +349,18 @@ enum { WS_CNT = 0, WS_OFF, WS_BSUM, WS_SORTED, WS_BUCKETS, WS_PFIRST, WS_PLAST, 
 #define PCD_HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
 // scalars_dev: n * NS u32 (canonical), bases_dev: n affine points;  out_dev: one Jacobian point.
+struct MsmBasesView {
+  const uint32_t* dptr;  // groups * n_total affine points: group g holds 2^(c * Wg * g) P_i
+  uint32_t n_total;      // points per group
+  uint32_t offset;       // first point of this MSM
+  int c;                 // window bits the groups were built for (0: no precomputation, free choice)
+  int groups;            // 1: no precomputation
+};
+
 template <class G>
-hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const uint32_t* bases_dev, const uint32_t* scalars_dev, uint32_t n,
+hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, const uint32_t* scalars_dev, uint32_t n,
                    uint32_t* out_dev, int c_override, uint32_t chunk_override, MsmTimings* tm) {
+  const uint32_t* bases_dev = bv.dptr;
   typedef typename G::F F;
   constexpr int NS = G::FR::N;
   constexpr int PW = Jac<F>::WORDS;
@@ -325,12 +368,13 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const uint32_t* bases_dev, 
   if (n == 0) { Jac<F> inf = Jac<F>::infinity(); return hipMemcpyAsync(out_dev, &inf, PB, hipMemcpyHostToDevice, st); }
   MsmPlan pl;
   pl.n = n;
-  pl.c = c_override ? c_override : msm_pick_window(n, G::FR::BITS);
+  pl.c = bv.groups > 1 ? bv.c : (c_override ? c_override : msm_pick_window(n, G::FR::BITS, 0));
   pl.W = (G::FR::BITS + pl.c - 1) / pl.c;
-  pl.nkeys = (uint32_t)pl.W << pl.c;
+  const int Wg = (pl.W + bv.groups - 1) / bv.groups;  // bucket windows
+  pl.nkeys = (uint32_t)Wg << pl.c;
   pl.chunk = chunk_override ? chunk_override : 32;
   const uint64_t maxM = (uint64_t)n * pl.W;
-  if (maxM >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+  if (maxM >= 0xFFFFFFF0ull || (uint64_t)bv.n_total * bv.groups >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
 
   hipEvent_t ev[9];
   if (tm) for (auto& e : ev) PCD_HIP_TRY(hipEventCreate(&e));
@@ -354,7 +398,8 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const uint32_t* bases_dev, 
   // 1. histogram
   PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)pl.nkeys * 4, st));
   dim3 gd((n + 255) / 256), bd(256);
-  hipLaunchKernelGGL((msm_digits_kernel<NS, false>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, cnt, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+  hipLaunchKernelGGL((msm_digits_kernel<NS, false>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, cnt,
+                     (const uint32_t*)nullptr, (uint32_t*)nullptr);
   PCD_HIP_TRY(mark(1));
   // 2. scan
   hipLaunchKernelGGL(scan_block_sums, dim3(scan_blocks), dim3(1024), 0, st, cnt, pl.nkeys, scan_per_block, bsum);
@@ -371,7 +416,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const uint32_t* bases_dev, 
   }
   // 3. scatter (cursor = cnt reset to zero)
   PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)pl.nkeys * 4, st));
-  hipLaunchKernelGGL((msm_digits_kernel<NS, true>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, cnt, off, sorted);
+  hipLaunchKernelGGL((msm_digits_kernel<NS, true>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, cnt, off, sorted);
   PCD_HIP_TRY(mark(3));
   // 4. accumulate
   const uint32_t nchunks = (uint32_t)(((uint64_t)M + pl.chunk - 1) / pl.chunk);
@@ -405,10 +450,10 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const uint32_t* bases_dev, 
   {
     const uint32_t B = (1u << pl.c) - 1;
     size_t cap_pts = ((size_t)1 << pl.c);  // generous per-window capacity for A'/C'
-    PCD_HIP_TRY(ws.ensure(WS_A0, (size_t)pl.W * cap_pts * PB / 2 + PB * pl.W * 4));
-    PCD_HIP_TRY(ws.ensure(WS_A1, (size_t)pl.W * cap_pts * PB / 2 + PB * pl.W * 4));
-    PCD_HIP_TRY(ws.ensure(WS_C0, (size_t)pl.W * cap_pts * PB / 2 + PB * pl.W * 4));
-    PCD_HIP_TRY(ws.ensure(WS_C1, (size_t)pl.W * cap_pts * PB / 2 + PB * pl.W * 4));
+    PCD_HIP_TRY(ws.ensure(WS_A0, (size_t)Wg * cap_pts * PB / 2 + PB * Wg * 4));
+    PCD_HIP_TRY(ws.ensure(WS_A1, (size_t)Wg * cap_pts * PB / 2 + PB * Wg * 4));
+    PCD_HIP_TRY(ws.ensure(WS_C0, (size_t)Wg * cap_pts * PB / 2 + PB * Wg * 4));
+    PCD_HIP_TRY(ws.ensure(WS_C1, (size_t)Wg * cap_pts * PB / 2 + PB * Wg * 4));
     const size_t strideAC = cap_pts / 2 + 4;
     const uint32_t* A_in = buckets + PW;  // bucket d = 1 of window 0
     size_t strideA_in = (size_t)1 << pl.c;
@@ -424,7 +469,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const uint32_t* bases_dev, 
       uint32_t* A_out = (uint32_t*)ws.buf[flip ? WS_A1 : WS_A0];
       uint32_t* C_out = (uint32_t*)ws.buf[flip ? WS_C1 : WS_C0];
       uint32_t threads = JA + JC;
-      hipLaunchKernelGGL((msm_tail_level_kernel<G>), dim3((threads + 63) / 64, pl.W), dim3(64), 0, st, A_in, mA, strideA_in, C_in, mC,
+      hipLaunchKernelGGL((msm_tail_level_kernel<G>), dim3((threads + 63) / 64, Wg), dim3(64), 0, st, A_in, mA, strideA_in, C_in, mC,
                          strideC_in, A_out, strideAC, C_out, strideAC, k);
       mA = JA ? JA - 1 : 0;
       mC = JC + JA;
@@ -435,7 +480,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const uint32_t* bases_dev, 
     }
     PCD_HIP_TRY(mark(6));
     // 7. windows
-    hipLaunchKernelGGL((msm_horner_kernel<G>), dim3(1), dim3(64), 0, st, C_in, strideC_in, pl.W, pl.c, out_dev);
+    hipLaunchKernelGGL((msm_horner_kernel<G>), dim3(1), dim3(64), 0, st, C_in, strideC_in, Wg, pl.c, out_dev);
     PCD_HIP_TRY(mark(7));
   }
   PCD_HIP_TRY(hipGetLastError());

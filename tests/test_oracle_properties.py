@@ -1,0 +1,55 @@
+"""CPU: size-independent properties of the C++ oracle at sizes the Python oracle cannot reach."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("fid,log_n", [(0, 12), (1, 14), (2, 10), (3, 12)])
+def test_fft_roundtrip_and_linearity(co, fid, log_n):
+    n = 1 << log_n
+    x, y = co.gen_field(fid, n, 1), co.gen_field(fid, n, 2)
+    for coset in (False, True):
+        fx = co.fft(fid, x, coset=coset, nthreads=4)
+        assert np.array_equal(co.fft(fid, fx, inverse=True, coset=coset, nthreads=4), x)
+        fy = co.fft(fid, y, coset=coset, nthreads=4)
+        fxy = co.fft(fid, co.fp_op(fid, "add", x, y), coset=coset, nthreads=4)
+        assert np.array_equal(fxy, co.fp_op(fid, "add", fx, fy))
+
+
+def test_fft_above_two_adicity_is_refused(co):
+    # F298A has 2-adicity 17: a radix-2 domain of 2^18 does not exist (upstream switches to mixed radix)
+    import ctypes as C
+    buf = np.zeros((1, 5), dtype=np.uint64)
+    assert co.lib().orc_fft(0, buf.ctypes.data_as(C.c_void_p), 18, 0, 0, 1) == -3
+
+
+@pytest.mark.parametrize("cid,grp,n", [(0, 1, 3000), (1, 1, 3000), (0, 2, 700), (1, 2, 500), (2, 1, 400), (3, 2, 60)])
+def test_msm_window_independence_and_split(co, cid, grp, n):
+    """The MSM value does not depend on the window size, the thread count, or on splitting the range
+    (the multi-GPU shard + combine path)."""
+    fr = co.CURVE_FR[cid]
+    pts = co.gen_points(cid, grp, n, seed=3)
+    assert all(co.on_curve(cid, grp, p) for p in pts[:: max(1, n // 7)])
+    for dist in (0, 1):
+        sc = co.gen_scalars(fr, n, seed=4, dist=dist)
+        ref, _ = co.to_affine(cid, grp, co.msm(cid, grp, pts, sc, nthreads=4))
+        alt, _ = co.to_affine(cid, grp, co.msm(cid, grp, pts, sc, nthreads=1, c_override=7))
+        assert np.array_equal(ref, alt)
+        h = n // 3
+        parts = co.jac_add(cid, grp, co.msm(cid, grp, pts[:h], sc[:h]), co.msm(cid, grp, pts[h:], sc[h:], nthreads=2))
+        sp, _ = co.to_affine(cid, grp, parts)
+        assert np.array_equal(ref, sp)
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_group_order_and_pairing_bilinearity(co, cid):
+    fr = co.CURVE_FR[cid]
+    k = co.gen_scalars(fr, 2, seed=9)
+    # r * G = O in both groups: scalar r-1 then add G
+    g1, g2 = co.generator(cid, 1), co.generator(cid, 2)
+    a_g1, _ = co.to_affine(cid, 1, co.scalar_mul(cid, 1, g1, k[0]))
+    b_g2, _ = co.to_affine(cid, 2, co.scalar_mul(cid, 2, g2, k[1]))
+    # e(aP, bQ) == e(abP, Q)
+    ab = co.fp_op(fr, "to_canonical", co.fp_op(fr, "mul", co.fp_op(fr, "from_canonical", k[:1]),
+                                               co.fp_op(fr, "from_canonical", k[1:2])))[0]
+    ab_g1, _ = co.to_affine(cid, 1, co.scalar_mul(cid, 1, g1, ab))
+    assert np.array_equal(co.pairing(cid, a_g1[0], b_g2[0]), co.pairing(cid, ab_g1[0], g2))

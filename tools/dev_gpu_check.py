@@ -20,12 +20,15 @@ if which in ("all", "msm"):
                 pts = Co.gen_points(curve, group, n, seed=11)
                 sc = Co.gen_scalars(Co.CURVE_FR[curve], n, seed=5 + n, dist=dist)
                 t = time.time(); want = Co.msm(curve, group, pts, sc, nthreads=8); tc = time.time() - t
-                b = ctx.bases_upload(curve, group, pts)
-                t = time.time(); got = ctx.msm(b, sc); tg = time.time() - t
                 wa, wi = Co.to_affine(curve, group, want)
-                ga, gi = Co.to_affine(curve, group, got)
-                check(f"msm curve={curve} G{group} n={n} dist={dist} cpu={tc:.3f}s gpu={tg:.3f}s", np.array_equal(wa, ga) and np.array_equal(wi, gi))
-                b.free()
+                for mode in (-1, 0, 3):
+                    ctx.set_precompute(mode)
+                    t = time.time(); b = ctx.bases_upload(curve, group, pts); tu = time.time() - t
+                    t = time.time(); got = ctx.msm(b, sc); tg = time.time() - t
+                    ga, gi = Co.to_affine(curve, group, got)
+                    check(f"msm curve={curve} G{group} n={n} dist={dist} precomp={mode} cpu={tc:.3f}s upload={tu:.3f}s gpu={tg:.3f}s", np.array_equal(wa, ga) and np.array_equal(wi, gi))
+                    b.free()
+                ctx.set_precompute(-1)
 if which in ("all", "fft"):
     for field in (0, 1, 2, 3):
         for log_n in (1, 4, 10, 11, 13, 15):
@@ -51,17 +54,22 @@ if which in ("all", "g16"):
         check(f"groth16 verify curve={curve}", Co.groth16_verify(keys, r.z[1:r.num_inputs], got))
 if which in ("all", "perf"):
     ctx.msm_profile(True)
-    for curve, group, logn in ((0, 1, 16), (0, 1, 18), (0, 1, 20), (2, 1, 16)):
+    for curve, group, logn in ((0, 1, 16), (0, 1, 20), (0, 2, 18), (2, 1, 16), (2, 1, 18)):
         n = 1 << logn
         pts = Co.gen_points(curve, group, n, seed=1)
-        for dist in (0, 1):
-            sc = Co.gen_scalars(Co.CURVE_FR[curve], n, seed=3, dist=dist)
-            b = ctx.bases_upload(curve, group, pts)
-            sb = ctx.buf_upload(Co.CURVE_FR[curve], sc)
-            ctx.msm(b, sb)
-            t = time.time(); got = ctx.msm(b, sb); tg = time.time() - t
-            print(f"perf msm curve={curve} n=2^{logn} dist={dist}: {tg*1e3:.2f} ms wall  {ctx.msm_last_timings()}", flush=True)
-            b.free(); sb.free()
+        for mode in (-1, 0):
+            ctx.set_precompute(mode)
+            t = time.time(); b = ctx.bases_upload(curve, group, pts); tu = time.time() - t
+            for dist in (0, 1):
+                sc = Co.gen_scalars(Co.CURVE_FR[curve], n, seed=3, dist=dist)
+                sb = ctx.buf_upload(Co.CURVE_FR[curve], sc)
+                ctx.msm(b, sb)
+                t = time.time(); got = ctx.msm(b, sb); tg = time.time() - t
+                tm = {k: round(v, 3) for k, v in ctx.msm_last_timings().items()}
+                print(f"perf msm curve={curve} G{group} n=2^{logn} dist={dist} precomp={mode} upload={tu:.2f}s: {tg*1e3:.2f} ms wall  {tm}", flush=True)
+                sb.free()
+            b.free()
+        ctx.set_precompute(-1)
     for field, logn in ((1, 16), (1, 20), (3, 20)):
         x = Co.gen_field(field, 1 << logn, seed=1)
         xb = ctx.buf_upload(field, x)
