@@ -142,6 +142,10 @@ typedef struct {
 } pcdhip_g16_pk_host;
 int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* host, pcdhip_g16_pk** out);
 void pcdhip_g16_pk_free(pcdhip_ctx* ctx, pcdhip_g16_pk* pk);
+/* Keep the circuit's constraint matrices (`ConstraintMatrices` from `cs.to_matrices()`, fixed per circuit like
+ * the key) resident on the device; pcdhip_groth16_prove then accepts A = B = C = NULL and only the assignment
+ * z crosses PCIe per proof. */
+int pcdhip_g16_pk_set_r1cs(pcdhip_ctx* ctx, pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C);
 /* proof_out = A (G1 x||y) || B (G2 x||y) || C (G1 x||y), affine Montgomery; inf_out[3]. */
 int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B,
                          const pcdhip_csr* C, const uint64_t* z_mont, const uint64_t* r_mont, const uint64_t* s_mont,

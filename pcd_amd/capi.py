@@ -47,7 +47,7 @@ EXPORTS = [
     "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config",
     "pcdhip_set_precompute", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
-    "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings",
+    "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings",
     "pcdhip_timer_start", "pcdhip_timer_stop",
 ]
 
@@ -212,14 +212,25 @@ class Context:
         self._check(lib().pcdhip_g16_pk_upload(self._ctx, C.byref(host_struct), C.byref(h)))
         return G16Pk(self, h, curve)
 
-    def groth16_prove(self, pk, r1cs, r_mont, s_mont):
-        """create_proof after synthesis -> (proof A||B||C affine limbs, inf flags[3])."""
+    def g16_pk_set_r1cs(self, pk, r1cs):
         A = self._csr(r1cs.rp_a, r1cs.col_a, r1cs.coeff_a)
         B = self._csr(r1cs.rp_b, r1cs.col_b, r1cs.coeff_b)
         Cm = self._csr(r1cs.rp_c, r1cs.col_c, r1cs.coeff_c)
+        self._check(lib().pcdhip_g16_pk_set_r1cs(self._ctx, pk._h, C.byref(A), C.byref(B), C.byref(Cm)))
+
+    def groth16_prove(self, pk, r1cs, r_mont, s_mont, resident_r1cs=False):
+        """create_proof after synthesis -> (proof A||B||C affine limbs, inf flags[3]).  With resident_r1cs the
+        matrices set by g16_pk_set_r1cs are used and only z is uploaded."""
         w1, w2 = point_limbs(pk.curve, G1), point_limbs(pk.curve, G2)
         proof = np.zeros(2 * w1 + w2, dtype=np.uint64)
         inf = np.zeros(3, dtype=np.uint8)
+        if resident_r1cs:
+            self._check(lib().pcdhip_groth16_prove(self._ctx, pk._h, None, None, None, _p(r1cs.z),
+                                                   _p(_u64(r_mont)), _p(_u64(s_mont)), _p(proof), _p(inf)))
+            return proof, inf
+        A = self._csr(r1cs.rp_a, r1cs.col_a, r1cs.coeff_a)
+        B = self._csr(r1cs.rp_b, r1cs.col_b, r1cs.coeff_b)
+        Cm = self._csr(r1cs.rp_c, r1cs.col_c, r1cs.coeff_c)
         self._check(lib().pcdhip_groth16_prove(self._ctx, pk._h, C.byref(A), C.byref(B), C.byref(Cm), _p(r1cs.z),
                                                _p(_u64(r_mont)), _p(_u64(s_mont)), _p(proof), _p(inf)))
         return proof, inf

@@ -385,7 +385,6 @@ int pcdhip_fft_last_timings(pcdhip_ctx* ctx, float out_ms[8]) {
 
 // ------------------------------------------------------------------------------------------------ witness map
 namespace {
-struct DevCsr { const uint64_t* rp; const uint32_t* col; const uint32_t* coeff; uint32_t rows; };
 
 // uploads one CSR matrix into aux slots (rp/col/coeff packed into one allocation per matrix)
 int upload_csr(pcdhip_ctx* ctx, int slot, const pcdhip_csr* m, int limbs, DevCsr* out) {
@@ -407,13 +406,11 @@ int upload_csr(pcdhip_ctx* ctx, int slot, const pcdhip_csr* m, int limbs, DevCsr
   return PCDHIP_OK;
 }
 
-// h (n elements, Montgomery) left in aux slot AUX_A; z_dev: m elements on device
-int witness_map_dev(pcdhip_ctx* ctx, int field_id, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C,
-                    const uint32_t* z_dev, size_t num_inputs, int* log_n_out) {
+// h (n elements, Montgomery) left in aux slot AUX_A; z_dev: m elements on device; mats: A, B, C on device
+int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const uint32_t* z_dev, size_t num_inputs, int* log_n_out) {
   const FieldEntry& fe = field_entry(field_id);
-  const int limbs = kFieldLimbs[field_id];
-  if (A->num_rows != B->num_rows || A->num_rows != C->num_rows) return PCDHIP_E_ARG;
-  const size_t need = A->num_rows + num_inputs;
+  if (mats[0].rows != mats[1].rows || mats[0].rows != mats[2].rows) return PCDHIP_E_ARG;
+  const size_t need = (size_t)mats[0].rows + num_inputs;
   int log_n = 0;
   while (((size_t)1 << log_n) < need) log_n++;
   if (log_n > fe.two_adicity) return PCDHIP_E_SIZE_UNSUPPORTED;
@@ -428,19 +425,11 @@ int witness_map_dev(pcdhip_ctx* ctx, int field_id, const pcdhip_csr* A, const pc
   TRY(ctx->aux_ws.ensure(AUX_FFT_TMP, vb));
   uint32_t *a = (uint32_t*)ctx->aux_ws.buf[AUX_A], *b = (uint32_t*)ctx->aux_ws.buf[AUX_B], *c = (uint32_t*)ctx->aux_ws.buf[AUX_C];
   uint32_t* tmp = (uint32_t*)ctx->aux_ws.buf[AUX_FFT_TMP];
-  DevCsr dm;
   hipStream_t st = ctx->stream;
-  // one matrix resident at a time (the same aux slot is reused)
-  rc = upload_csr(ctx, AUX_CSR_RP, A, limbs, &dm); if (rc) return rc;
-  TRY(fe.spmv(st, dm.rp, dm.col, dm.coeff, dm.rows, z_dev, (uint32_t)num_inputs, 1, n, a));
-  TRY(hipStreamSynchronize(st));
-  rc = upload_csr(ctx, AUX_CSR_RP, B, limbs, &dm); if (rc) return rc;
-  TRY(fe.spmv(st, dm.rp, dm.col, dm.coeff, dm.rows, z_dev, (uint32_t)num_inputs, 0, n, b));
-  TRY(hipStreamSynchronize(st));
-  rc = upload_csr(ctx, AUX_CSR_RP, C, limbs, &dm); if (rc) return rc;
-  TRY(fe.spmv(st, dm.rp, dm.col, dm.coeff, dm.rows, z_dev, (uint32_t)num_inputs, 0, n, c));
-  // 3 x (ifft, coset_fft), pointwise, coset_ifft
   uint32_t* vecs[3] = {a, b, c};
+  for (int k = 0; k < 3; k++)
+    TRY(fe.spmv(st, mats[k].rp, mats[k].col, mats[k].coeff, mats[k].rows, z_dev, (uint32_t)num_inputs, k == 0 ? 1 : 0, n, vecs[k]));
+  // 3 x (ifft, coset_fft), pointwise, coset_ifft
   for (uint32_t* v : vecs) {
     TRY(fe.fft_run(st, *t, v, tmp, log_n, 1, 0, nullptr, nullptr));
     TRY(fe.fft_run(st, *t, v, tmp, log_n, 0, 1, nullptr, nullptr));
@@ -448,6 +437,13 @@ int witness_map_dev(pcdhip_ctx* ctx, int field_id, const pcdhip_csr* A, const pc
   TRY(fe.mul_sub_divz(st, a, b, c, log_n));
   TRY(fe.fft_run(st, *t, a, tmp, log_n, 1, 1, nullptr, nullptr));
   *log_n_out = log_n;
+  return PCDHIP_OK;
+}
+
+int upload_three(pcdhip_ctx* ctx, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C, int limbs, DevCsr out[3]) {
+  const pcdhip_csr* ms[3] = {A, B, C};
+  const int slots[3] = {AUX_CSR_RP, AUX_CSR_COL, AUX_CSR_COEF};  // one aux slot per matrix
+  for (int k = 0; k < 3; k++) { int rc = upload_csr(ctx, slots[k], ms[k], limbs, &out[k]); if (rc) return rc; }
   return PCDHIP_OK;
 }
 }  // namespace
@@ -460,7 +456,10 @@ int pcdhip_groth16_witness_map(pcdhip_ctx* ctx, int field_id, const pcdhip_csr* 
   TRY(ctx->aux_ws.ensure(AUX_Z, zb));
   TRY(hipMemcpyAsync(ctx->aux_ws.buf[AUX_Z], z, zb, hipMemcpyHostToDevice, ctx->stream));
   int log_n = 0;
-  int rc = witness_map_dev(ctx, field_id, A, B, C, (const uint32_t*)ctx->aux_ws.buf[AUX_Z], num_inputs, &log_n);
+  DevCsr mats[3];
+  int rc = upload_three(ctx, A, B, C, kFieldLimbs[field_id], mats);
+  if (rc) return rc;
+  rc = witness_map_dev(ctx, field_id, mats, (const uint32_t*)ctx->aux_ws.buf[AUX_Z], num_inputs, &log_n);
   if (rc) return rc;
   TRY(hipMemcpyAsync(h_out, ctx->aux_ws.buf[AUX_A], ((size_t)1 << log_n) * kFieldLimbs[field_id] * 8, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
@@ -481,11 +480,22 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
   memset(pk, 0, sizeof *pk);
   pk->curve_id = cid; pk->num_vars = h->num_vars; pk->num_inputs = h->num_inputs; pk->domain_size = h->domain_size;
   int rc = 0;
-  rc = rc ? rc : pcdhip_bases_upload(ctx, cid, 1, h->a_query, h->a_inf, h->num_vars, &pk->a_query);
-  rc = rc ? rc : pcdhip_bases_upload(ctx, cid, 1, h->b_g1_query, h->b_g1_inf, h->num_vars, &pk->b_g1_query);
-  rc = rc ? rc : pcdhip_bases_upload(ctx, cid, 2, h->b_g2_query, h->b_g2_inf, h->num_vars, &pk->b_g2_query);
+  // delta is appended to the a / b / l queries: r*delta, s*delta and -rs*delta then ride inside the MSMs as
+  // one more (base, scalar) pair instead of being serial scalar multiplications in the assembly.
+  auto upload_plus = [&](int group, const uint64_t* q, const uint8_t* inf, size_t n, const uint64_t* extra, pcdhip_bases** out) -> int {
+    const size_t pl = (size_t)pcdhip_point_limbs(cid, group);
+    std::vector<uint64_t> tmp((n + 1) * pl);
+    std::vector<uint8_t> tinf(n + 1, 0);
+    if (n) memcpy(tmp.data(), q, n * pl * 8);
+    memcpy(tmp.data() + n * pl, extra, pl * 8);
+    if (inf) memcpy(tinf.data(), inf, n);
+    return pcdhip_bases_upload(ctx, cid, group, tmp.data(), tinf.data(), n + 1, out);
+  };
+  rc = rc ? rc : upload_plus(1, h->a_query, h->a_inf, h->num_vars, h->delta_g1, &pk->a_query);
+  rc = rc ? rc : upload_plus(1, h->b_g1_query, h->b_g1_inf, h->num_vars, h->delta_g1, &pk->b_g1_query);
+  rc = rc ? rc : upload_plus(2, h->b_g2_query, h->b_g2_inf, h->num_vars, h->delta_g2, &pk->b_g2_query);
   rc = rc ? rc : pcdhip_bases_upload(ctx, cid, 1, h->h_query, h->h_inf, h->h_len, &pk->h_query);
-  rc = rc ? rc : pcdhip_bases_upload(ctx, cid, 1, h->l_query, h->l_inf, h->l_len, &pk->l_query);
+  rc = rc ? rc : upload_plus(1, h->l_query, h->l_inf, h->l_len, h->delta_g1, &pk->l_query);
   if (!rc) {
     const size_t w1 = (size_t)pcdhip_point_limbs(cid, 1) * 8, w2 = (size_t)pcdhip_point_limbs(cid, 2) * 8;
     hipError_t e = hipMalloc(&pk->singles, 5 * w1 + 3 * w2);
@@ -505,8 +515,42 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
   *out = pk;
   return PCDHIP_OK;
 }
+int pcdhip_g16_pk_set_r1cs(pcdhip_ctx* ctx, pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C) {
+  if (!ctx || !pk || !A || !B || !C) return PCDHIP_E_ARG;
+  if (A->num_rows != B->num_rows || A->num_rows != C->num_rows || (A->num_rows >> 31)) return PCDHIP_E_ARG;
+  BIND();
+  const int limbs = kFieldLimbs[kCurveFr[pk->curve_id]];
+  const pcdhip_csr* ms[3] = {A, B, C};
+  size_t total = 0, offs[3][3];
+  for (int k = 0; k < 3; k++) {
+    if (!ms[k]->row_ptr) return PCDHIP_E_ARG;
+    const uint64_t nnz = ms[k]->row_ptr[ms[k]->num_rows];
+    if (nnz && (!ms[k]->col || !ms[k]->coeff)) return PCDHIP_E_ARG;
+    offs[k][0] = total; total += (ms[k]->num_rows + 1) * 8;
+    offs[k][1] = total; total += nnz * limbs * 8;
+    offs[k][2] = total; total += (nnz * 4 + 7) / 8 * 8;
+  }
+  if (pk->r1cs_dev) { (void)hipFree(pk->r1cs_dev); pk->r1cs_dev = nullptr; }
+  TRY(hipMalloc(&pk->r1cs_dev, total + 64));
+  char* d = (char*)pk->r1cs_dev;
+  for (int k = 0; k < 3; k++) {
+    const uint64_t nnz = ms[k]->row_ptr[ms[k]->num_rows];
+    TRY(hipMemcpyAsync(d + offs[k][0], ms[k]->row_ptr, (ms[k]->num_rows + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (nnz) {
+      TRY(hipMemcpyAsync(d + offs[k][1], ms[k]->coeff, nnz * limbs * 8, hipMemcpyHostToDevice, ctx->stream));
+      TRY(hipMemcpyAsync(d + offs[k][2], ms[k]->col, nnz * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    pk->rp[k] = (const uint64_t*)(d + offs[k][0]);
+    pk->coeff[k] = (const uint32_t*)(d + offs[k][1]);
+    pk->col[k] = (const uint32_t*)(d + offs[k][2]);
+  }
+  pk->rows = (uint32_t)A->num_rows;
+  TRY(hipStreamSynchronize(ctx->stream));
+  return PCDHIP_OK;
+}
 void pcdhip_g16_pk_free(pcdhip_ctx* ctx, pcdhip_g16_pk* pk) {
   if (!pk) return;
+  if (pk->r1cs_dev) (void)hipFree(pk->r1cs_dev);
   pcdhip_bases_free(ctx, pk->a_query); pcdhip_bases_free(ctx, pk->b_g1_query); pcdhip_bases_free(ctx, pk->b_g2_query);
   pcdhip_bases_free(ctx, pk->h_query); pcdhip_bases_free(ctx, pk->l_query);
   if (pk->singles) (void)hipFree(pk->singles);
@@ -515,7 +559,7 @@ void pcdhip_g16_pk_free(pcdhip_ctx* ctx, pcdhip_g16_pk* pk) {
 
 int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C,
                          const uint64_t* z, const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out, uint8_t* inf_out) {
-  if (!ctx || !pk || !A || !B || !C || !z || !r_mont || !s_mont || !proof_out) return PCDHIP_E_ARG;
+  if (!ctx || !pk || !z || !r_mont || !s_mont || !proof_out) return PCDHIP_E_ARG;
   BIND();
   const int cid = pk->curve_id, fr = kCurveFr[cid];
   const FieldEntry& fe = field_entry(fr);
@@ -528,14 +572,21 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   // z -> device (Montgomery, for the SpMV) and canonical copy (MSM scalars)
   const size_t zb = m * limbs * 8;
   TRY(ctx->aux_ws.ensure(AUX_Z, zb));
-  TRY(ctx->aux_ws.ensure(AUX_Z_CANON, zb));
+  TRY(ctx->aux_ws.ensure(AUX_Z_CANON, zb + 4 * limbs * 8));  // + one slot after z for the delta scalar, + [r, s, -rs]
   uint32_t* z_dev = (uint32_t*)ctx->aux_ws.buf[AUX_Z];
   uint32_t* z_can = (uint32_t*)ctx->aux_ws.buf[AUX_Z_CANON];
   TRY(hipMemcpyAsync(z_dev, z, zb, hipMemcpyHostToDevice, st));
   TRY(fe.convert(st, z_dev, z_can, (uint32_t)m, 0));
   // K1: h
   int log_n = 0;
-  int rc = witness_map_dev(ctx, fr, A, B, C, z_dev, ni, &log_n);
+  DevCsr mats[3];
+  int rc = PCDHIP_OK;
+  if (A && B && C) rc = upload_three(ctx, A, B, C, limbs, mats);
+  else if (!A && !B && !C && pk->r1cs_dev) {
+    for (int k = 0; k < 3; k++) mats[k] = {pk->rp[k], pk->col[k], pk->coeff[k], pk->rows};
+  } else rc = PCDHIP_E_ARG;
+  if (rc) return rc;
+  rc = witness_map_dev(ctx, fr, mats, z_dev, ni, &log_n);
   if (rc) return rc;
   const size_t n = (size_t)1 << log_n;
   TRY(ctx->aux_ws.ensure(AUX_H_CANON, n * limbs * 8));
@@ -560,15 +611,21 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   const uint32_t sw = (uint32_t)limbs * 2;
   const size_t hl = std::min<size_t>(pk->h_query->n, n);
   MsmTimings* tm = nullptr;
+  uint32_t* slot = z_can + m * sw;      // scalar of the appended delta point
+  uint32_t* extra = slot + sw;          // canonical [r, s, -rs]
+  TRY(ce.prepare_scalars(st, rs_dev, extra));
   TRY(g1.msm(ctx->msm_ws, st, pk->h_query->view(0), h_can, (uint32_t)hl, msm_g1, ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[2], st));
-  TRY(g1.msm(ctx->msm_ws, st, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni), (uint32_t*)((char*)msm_g1 + j1), ctx->msm_c, ctx->msm_chunk, tm));
+  TRY(hipMemcpyAsync(slot, extra + 2 * sw, limbs * 8, hipMemcpyDeviceToDevice, st));  // -rs
+  TRY(g1.msm(ctx->msm_ws, st, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni + 1), (uint32_t*)((char*)msm_g1 + j1), ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[3], st));
-  TRY(g1.msm(ctx->msm_ws, st, pk->a_query->view(1), z_can + sw, (uint32_t)(m - 1), (uint32_t*)((char*)msm_g1 + 2 * j1), ctx->msm_c, ctx->msm_chunk, tm));
+  TRY(hipMemcpyAsync(slot, extra, limbs * 8, hipMemcpyDeviceToDevice, st));  // r
+  TRY(g1.msm(ctx->msm_ws, st, pk->a_query->view(1), z_can + sw, (uint32_t)m, (uint32_t*)((char*)msm_g1 + 2 * j1), ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[4], st));
-  TRY(g1.msm(ctx->msm_ws, st, pk->b_g1_query->view(1), z_can + sw, (uint32_t)(m - 1), (uint32_t*)((char*)msm_g1 + 3 * j1), ctx->msm_c, ctx->msm_chunk, tm));
+  TRY(hipMemcpyAsync(slot, extra + sw, limbs * 8, hipMemcpyDeviceToDevice, st));  // s
+  TRY(g1.msm(ctx->msm_ws, st, pk->b_g1_query->view(1), z_can + sw, (uint32_t)m, (uint32_t*)((char*)msm_g1 + 3 * j1), ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[5], st));
-  TRY(g2.msm(ctx->msm_ws, st, pk->b_g2_query->view(1), z_can + sw, (uint32_t)(m - 1), msm_g2, ctx->msm_c, ctx->msm_chunk, tm));
+  TRY(g2.msm(ctx->msm_ws, st, pk->b_g2_query->view(1), z_can + sw, (uint32_t)m, msm_g2, ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[6], st));
   // K5: assembly
   TRY(ce.assemble(st, msm_g1, msm_g2, pk->singles, rs_dev, scratch, proof_dev));

@@ -33,7 +33,16 @@ struct pcdhip_bases {
   int groups;      // 1 = plain bases
   pcd::MsmBasesView view(size_t offset) const { return {dptr, (uint32_t)n, (uint32_t)offset, c, groups}; }
 };
+namespace pcd {
+struct DevCsr { const uint64_t* rp; const uint32_t* col; const uint32_t* coeff; uint32_t rows; };
+}
 struct pcdhip_g16_pk {
+  // constraint matrices kept resident by pcdhip_g16_pk_set_r1cs (fixed per circuit, like the key)
+  void* r1cs_dev;
+  const uint64_t* rp[3];
+  const uint32_t* col[3];
+  const uint32_t* coeff[3];
+  uint32_t rows;
   int curve_id;
   uint64_t num_vars, num_inputs, domain_size;
   pcdhip_bases *a_query, *b_g1_query, *b_g2_query, *h_query, *l_query;
@@ -96,6 +105,8 @@ const FieldEntry& field_entry(int field_id);
 
 // ---- per-curve entries (inst_g16.hip) --------------------------------------------------------------
 struct CurveEntry {
+  // out3 = canonical [r, s, -(r s)] from Montgomery (r, s) on device
+  hipError_t (*prepare_scalars)(hipStream_t, const uint32_t* rs_dev, uint32_t* out3);
   // msm_results: 5 Jacobian points on device in the order h, l, a, b_g1 (G1) then b_g2 (G2, at g2_off words)
   // singles: see pcdhip_g16_pk;  r, s: Fr Montgomery (device);  proof_out: device affine A || B || C
   hipError_t (*assemble)(hipStream_t, const uint32_t* msm_g1, const uint32_t* msm_g2, const uint32_t* singles,

@@ -186,52 +186,51 @@ __global__ void __launch_bounds__(64) msm_accumulate_kernel(const uint32_t* __re
   else acc.store(buckets + (size_t)key * Jac<F>::WORDS);
 }
 
-// One lane per chunk: the chunk in which a split bucket STARTS sums that bucket's pieces, unless
-// there are more than `big_limit` of them (then the bucket goes to the big list).
+// One lane per bucket: a bucket whose sorted run crosses chunk edges is the sum of the pieces its chunks
+// emitted (piece_last of the first and middle chunks, piece_first of the last one).  Buckets with more than
+// `big_limit` pieces (e.g. "scalar = 1" of a bit-heavy witness, or the low buckets that the short top window
+// fills) go to the big list and are summed by one wave each.
 template <class G>
-__global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t M, uint32_t chunk,
-                                                       uint32_t nchunks, const uint32_t* __restrict__ piece_first,
-                                                       const uint32_t* __restrict__ piece_last, uint32_t* __restrict__ buckets,
-                                                       uint32_t big_limit, uint32_t* __restrict__ big_count,
+__global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t chunk,
+                                                       const uint32_t* __restrict__ piece_first, const uint32_t* __restrict__ piece_last,
+                                                       uint32_t* __restrict__ buckets, uint32_t big_limit, uint32_t* __restrict__ big_count,
                                                        uint32_t* __restrict__ big_list /* (key, t0, t1) */, uint32_t big_cap) {
   typedef typename G::F F;
   typedef EC<G> E;
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nchunks) return;
-  uint64_t end64 = min((uint64_t)M, (uint64_t)(t + 1) * chunk);
-  uint32_t end = (uint32_t)end64, start = t * chunk;
-  uint32_t key = msm_find_key(off, nkeys, end - 1);
-  if (off[key + 1] <= end) return;   // last run closed inside this chunk
-  if (off[key] < start) return;      // bucket started earlier: this chunk is a middle piece
-  uint32_t t1 = (off[key + 1] - 1) / chunk;
-  if (t1 - t > big_limit) {
+  uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= nkeys) return;
+  uint32_t lo = off[key], hi = off[key + 1];
+  if (hi == lo) return;
+  uint32_t t0 = lo / chunk, t1 = (hi - 1) / chunk;
+  if (t1 == t0) return;  // the whole run lies inside one chunk: msm_accumulate wrote the bucket itself
+  if (t1 - t0 + 1 > big_limit) {
     uint32_t slot = atomicAdd(big_count, 1u);
-    if (slot < big_cap) { big_list[3 * slot] = key; big_list[3 * slot + 1] = t; big_list[3 * slot + 2] = t1; }
+    if (slot < big_cap) { big_list[3 * slot] = key; big_list[3 * slot + 1] = t0; big_list[3 * slot + 2] = t1; }
     return;
   }
-  Jac<F> acc = Jac<F>::load(piece_last + (size_t)t * Jac<F>::WORDS);
-  for (uint32_t u = t + 1; u < t1; u++) acc = E::add(acc, Jac<F>::load(piece_last + (size_t)u * Jac<F>::WORDS));
+  Jac<F> acc = Jac<F>::load(piece_last + (size_t)t0 * Jac<F>::WORDS);
+  for (uint32_t u = t0 + 1; u < t1; u++) acc = E::add(acc, Jac<F>::load(piece_last + (size_t)u * Jac<F>::WORDS));
   acc = E::add(acc, Jac<F>::load(piece_first + (size_t)t1 * Jac<F>::WORDS));
   acc.store(buckets + (size_t)key * Jac<F>::WORDS);
 }
 
-// One workgroup per big bucket: strided serial sums, then a tree through global scratch.
+// One wave per big bucket: strided serial sums, then a 6-level tree through global scratch.
 template <class G>
-__global__ void __launch_bounds__(256) msm_big_bucket_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ piece_first,
-                                                             const uint32_t* __restrict__ piece_last, uint32_t* __restrict__ buckets,
-                                                             uint32_t* __restrict__ scratch /* gridDim.x * 256 points */) {
+__global__ void __launch_bounds__(64) msm_big_bucket_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ piece_first,
+                                                            const uint32_t* __restrict__ piece_last, uint32_t* __restrict__ buckets,
+                                                            uint32_t* __restrict__ scratch /* gridDim.x * 64 points */) {
   typedef typename G::F F;
   typedef EC<G> E;
   uint32_t key = big_list[3 * blockIdx.x], t0 = big_list[3 * blockIdx.x + 1], t1 = big_list[3 * blockIdx.x + 2];
-  uint32_t* my = scratch + (size_t)blockIdx.x * 256 * Jac<F>::WORDS;
+  uint32_t* my = scratch + (size_t)blockIdx.x * 64 * Jac<F>::WORDS;
   Jac<F> acc = Jac<F>::infinity();
-  for (uint32_t u = t0 + threadIdx.x; u <= t1; u += 256) {
+  for (uint32_t u = t0 + threadIdx.x; u <= t1; u += 64) {
     const uint32_t* src = (u == t1) ? piece_first : piece_last;
     acc = E::add(acc, Jac<F>::load(src + (size_t)u * Jac<F>::WORDS));
   }
   acc.store(my + (size_t)threadIdx.x * Jac<F>::WORDS);
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = 32; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
       Jac<F> o = Jac<F>::load(my + (size_t)(threadIdx.x + s) * Jac<F>::WORDS);
       acc = E::add(acc, o);
@@ -422,7 +421,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   const uint32_t nchunks = (uint32_t)(((uint64_t)M + pl.chunk - 1) / pl.chunk);
   PCD_HIP_TRY(ws.ensure(WS_PFIRST, (size_t)nchunks * PB));
   PCD_HIP_TRY(ws.ensure(WS_PLAST, (size_t)nchunks * PB));
-  const uint32_t big_cap = 4096;
+  const uint32_t big_cap = 1u << 16;
   PCD_HIP_TRY(ws.ensure(WS_BIG, (size_t)(3 * big_cap + 4) * 4));
   uint32_t* pfirst = (uint32_t*)ws.buf[WS_PFIRST];
   uint32_t* plast = (uint32_t*)ws.buf[WS_PLAST];
@@ -435,15 +434,15 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   PCD_HIP_TRY(mark(4));
   // 5. pieces
   const uint32_t big_limit = 8;
-  hipLaunchKernelGGL((msm_fixup_kernel<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, off, pl.nkeys, M, pl.chunk, nchunks, pfirst, plast,
-                     buckets, big_limit, big_count, big, big_cap);
+  hipLaunchKernelGGL((msm_fixup_kernel<G>), dim3((pl.nkeys + 63) / 64), dim3(64), 0, st, off, pl.nkeys, pl.chunk, pfirst, plast, buckets,
+                     big_limit, big_count, big, big_cap);
   uint32_t nbig = 0;
   PCD_HIP_TRY(hipMemcpyAsync(&nbig, big_count, 4, hipMemcpyDeviceToHost, st));
   PCD_HIP_TRY(hipStreamSynchronize(st));
   if (nbig > big_cap) return hipErrorOutOfMemory;
   if (nbig) {
-    PCD_HIP_TRY(ws.ensure(WS_BIGSCR, (size_t)nbig * 256 * PB));
-    hipLaunchKernelGGL((msm_big_bucket_kernel<G>), dim3(nbig), dim3(256), 0, st, big, pfirst, plast, buckets, (uint32_t*)ws.buf[WS_BIGSCR]);
+    PCD_HIP_TRY(ws.ensure(WS_BIGSCR, (size_t)nbig * 64 * PB));
+    hipLaunchKernelGGL((msm_big_bucket_kernel<G>), dim3(nbig), dim3(64), 0, st, big, pfirst, plast, buckets, (uint32_t*)ws.buf[WS_BIGSCR]);
   }
   PCD_HIP_TRY(mark(5));
   // 6. tail levels

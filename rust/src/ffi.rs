@@ -1,0 +1,42 @@
+//! `extern "C"` binding of include/pcdhip.h and the marshalling around `pcdhip_groth16_prove`.
+//! Source only; see INTEGRATION.md.
+use std::os::raw::{c_char, c_int};
+
+#[repr(C)] pub struct pcdhip_ctx { _p: [u8; 0] }
+#[repr(C)] pub struct pcdhip_bases { _p: [u8; 0] }
+#[repr(C)] pub struct pcdhip_g16_pk { _p: [u8; 0] }
+#[repr(C)] pub struct pcdhip_csr { pub num_rows: u64, pub row_ptr: *const u64, pub col: *const u32, pub coeff: *const u64 }
+#[repr(C)]
+pub struct pcdhip_g16_pk_host {
+    pub curve_id: u32, pub _pad: u32, pub num_vars: u64, pub num_inputs: u64, pub domain_size: u64,
+    pub alpha_g1: *const u64, pub beta_g1: *const u64, pub delta_g1: *const u64, pub beta_g2: *const u64, pub delta_g2: *const u64,
+    pub a_query: *const u64, pub a_inf: *const u8, pub b_g1_query: *const u64, pub b_g1_inf: *const u8,
+    pub b_g2_query: *const u64, pub b_g2_inf: *const u8, pub h_query: *const u64, pub h_inf: *const u8, pub h_len: u64,
+    pub l_query: *const u64, pub l_inf: *const u8, pub l_len: u64,
+}
+
+#[link(name = "pcdhip")]
+extern "C" {
+    pub fn pcdhip_init(device_id: c_int, out: *mut *mut pcdhip_ctx) -> c_int;
+    pub fn pcdhip_destroy(ctx: *mut pcdhip_ctx);
+    pub fn pcdhip_strerror(code: c_int) -> *const c_char;
+    pub fn pcdhip_set_precompute(ctx: *mut pcdhip_ctx, mode: c_int) -> c_int;
+    pub fn pcdhip_bases_upload(ctx: *mut pcdhip_ctx, curve: c_int, group: c_int, xy: *const u64, inf: *const u8, n: usize, out: *mut *mut pcdhip_bases) -> c_int;
+    pub fn pcdhip_bases_free(ctx: *mut pcdhip_ctx, b: *mut pcdhip_bases);
+    pub fn pcdhip_msm(ctx: *mut pcdhip_ctx, bases: *const pcdhip_bases, offset: usize, scalars: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn pcdhip_fft(ctx: *mut pcdhip_ctx, field: c_int, data: *mut u64, log_n: u32, inverse: c_int, coset: c_int) -> c_int;
+    pub fn pcdhip_g16_pk_upload(ctx: *mut pcdhip_ctx, host: *const pcdhip_g16_pk_host, out: *mut *mut pcdhip_g16_pk) -> c_int;
+    pub fn pcdhip_g16_pk_set_r1cs(ctx: *mut pcdhip_ctx, pk: *mut pcdhip_g16_pk, a: *const pcdhip_csr, b: *const pcdhip_csr, c: *const pcdhip_csr) -> c_int;
+    pub fn pcdhip_g16_pk_free(ctx: *mut pcdhip_ctx, pk: *mut pcdhip_g16_pk);
+    pub fn pcdhip_groth16_prove(ctx: *mut pcdhip_ctx, pk: *const pcdhip_g16_pk, a: *const pcdhip_csr, b: *const pcdhip_csr, c: *const pcdhip_csr,
+                                z: *const u64, r: *const u64, s: *const u64, proof: *mut u64, inf: *mut u8) -> c_int;
+}
+
+pub enum Error { Arg, SizeUnsupported, NoDevice, Oom, Hip }
+pub(crate) fn check(rc: c_int) -> Result<(), Error> {
+    match rc { 0 => Ok(()), -1 => Err(Error::Arg), -2 => Err(Error::SizeUnsupported), -3 => Err(Error::NoDevice), -4 => Err(Error::Oom), _ => Err(Error::Hip) }
+}
+// groth16_prove::<E>: (1) look the device key up in a process-wide cache keyed by `pk as *const _` (upload +
+// `pcdhip_g16_pk_set_r1cs` on first use); (2) z -> limbs (memcpy); (3) call `pcdhip_groth16_prove` with A = B = C = NULL;
+// (4) unpack A || B || C into `Proof<E>` (`GroupAffine::new(x, y, inf)`).  cpu_prove_with_rs::<E> re-runs upstream
+// `create_proof_with_reduction_and_matrices(pk, r, s, &matrices, ..)` for sizes the library refuses.

@@ -109,9 +109,12 @@ def test_groth16_roundtrip(co, gpu_ctx, cid, nc):
     rs = co.gen_field(fr, 2, seed=8)
     pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
     proof, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
+    gpu_ctx.g16_pk_set_r1cs(pk, r)
+    proof2, inf2 = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
     pk.free()
     want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=16)
     assert np.array_equal(proof, want) and np.array_equal(inf, winf)
+    assert np.array_equal(proof2, want) and np.array_equal(inf2, winf)
     pub = np.ascontiguousarray(r.z[1:r.num_inputs])
     assert co.groth16_verify(keys, pub, proof)
     bad = pub.copy()
