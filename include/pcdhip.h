@@ -154,6 +154,17 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
  * [witness_map, msm_h, msm_l, msm_a, msm_b_g1, msm_b_g2, assembly, total]. */
 int pcdhip_groth16_last_timings(pcdhip_ctx* ctx, float out_ms[8]);
 
+/* ---- K6: pairing ---------------------------------------------------------------------------------
+ * Replaces ark-ec `PairingEngine::product_of_pairings`: gt_out = final_exponentiation(prod_i miller_loop(P_i, Q_i)),
+ * an element of Fq4 (MNT4) / Fq6 (MNT6) in tower order c0, c1 over Fq2 / Fq3, Montgomery limbs.  One lane per pair. */
+int pcdhip_multi_pairing(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy,
+                         const uint8_t* g2_inf, size_t n_pairs, uint64_t* gt_out);
+/* Replaces ark-groth16 `Groth16::verify` (reference call site mod.rs:239):
+ * e(A,B) == e(alpha,beta) e(gamma_abc[0] + sum_i x_i gamma_abc[i], gamma) e(C,delta); public inputs canonical, without the leading 1. */
+int pcdhip_groth16_verify(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, const uint64_t* beta_g2, const uint64_t* gamma_g2,
+                          const uint64_t* delta_g2, const uint64_t* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs,
+                          const uint64_t* public_inputs_canonical, const uint64_t* proof, const uint8_t* proof_inf, int* ok);
+
 /* ---- timing helpers (HIP events on the context's stream, for bench.py) ------------------------- */
 int pcdhip_timer_start(pcdhip_ctx* ctx);
 int pcdhip_timer_stop(pcdhip_ctx* ctx, float* out_ms);

@@ -48,7 +48,7 @@ EXPORTS = [
     "pcdhip_set_precompute", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
     "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings",
-    "pcdhip_timer_start", "pcdhip_timer_stop",
+    "pcdhip_multi_pairing", "pcdhip_groth16_verify", "pcdhip_timer_start", "pcdhip_timer_stop",
 ]
 
 
@@ -239,6 +239,31 @@ class Context:
         out = (C.c_float * 8)()
         self._check(lib().pcdhip_groth16_last_timings(self._ctx, out))
         return dict(zip(["witness_map", "msm_h", "msm_l", "msm_a", "msm_b_g1", "msm_b_g2", "assembly", "total"], list(out)))
+
+    # ---- pairing
+    def multi_pairing(self, curve, g1_xy, g2_xy, g1_inf=None, g2_inf=None):
+        """product_of_pairings: final_exponentiation(prod miller_loop(P_i, Q_i)) -> GT limbs (tower order)."""
+        g1 = _u64(g1_xy).reshape(-1, point_limbs(curve, G1))
+        g2 = _u64(g2_xy).reshape(-1, point_limbs(curve, G2))
+        n = g1.shape[0]
+        out = np.zeros(2 * CURVE_G2_DEG[curve] * FIELD_LIMBS[CURVE_FQ[curve]], dtype=np.uint64)
+        i1 = np.ascontiguousarray(g1_inf, dtype=np.uint8) if g1_inf is not None else None
+        i2 = np.ascontiguousarray(g2_inf, dtype=np.uint8) if g2_inf is not None else None
+        self._check(lib().pcdhip_multi_pairing(self._ctx, curve, _p(g1), _p(i1), _p(g2), _p(i2), C.c_size_t(n), _p(out)))
+        return out
+
+    def groth16_verify(self, curve, alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1, public_inputs_canonical, proof,
+                       gamma_abc_inf=None, proof_inf=None):
+        """Groth16::verify (reference call site src/ec_cycle_pcd/mod.rs:239)."""
+        abc = _u64(gamma_abc_g1).reshape(-1, point_limbs(curve, G1))
+        ok = C.c_int(0)
+        pi = _u64(public_inputs_canonical)
+        gi = np.ascontiguousarray(gamma_abc_inf, dtype=np.uint8) if gamma_abc_inf is not None else None
+        pinf = np.ascontiguousarray(proof_inf, dtype=np.uint8) if proof_inf is not None else None
+        self._check(lib().pcdhip_groth16_verify(self._ctx, curve, _p(_u64(alpha_g1)), _p(_u64(beta_g2)), _p(_u64(gamma_g2)),
+                                                _p(_u64(delta_g2)), _p(abc), _p(gi), C.c_size_t(abc.shape[0]), _p(pi),
+                                                _p(_u64(proof)), _p(pinf), C.byref(ok)))
+        return ok.value == 1
 
     # ---- timing
     def timer_start(self):

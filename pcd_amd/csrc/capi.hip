@@ -16,6 +16,8 @@ PCD_DECL_G(0) PCD_DECL_G(1) PCD_DECL_G(2) PCD_DECL_G(3) PCD_DECL_G(4) PCD_DECL_G
 PCD_DECL_F(0) PCD_DECL_F(1) PCD_DECL_F(2) PCD_DECL_F(3)
 #define PCD_DECL_C(k) const CurveEntry* pcd_curve_entry_##k();
 PCD_DECL_C(0) PCD_DECL_C(1) PCD_DECL_C(2) PCD_DECL_C(3)
+#define PCD_DECL_P(k) const PairingEntry* pcd_pairing_entry_##k();
+PCD_DECL_P(0) PCD_DECL_P(1) PCD_DECL_P(2) PCD_DECL_P(3)
 
 const GroupEntry& group_entry(int curve_id, int group_id) {
   typedef const GroupEntry* (*Fn)();
@@ -31,6 +33,12 @@ const FieldEntry& field_entry(int field_id) {
 const CurveEntry& curve_entry(int curve_id) {
   typedef const CurveEntry* (*Fn)();
   static const Fn tab[4] = {pcd_curve_entry_0, pcd_curve_entry_1, pcd_curve_entry_2, pcd_curve_entry_3};
+  return *tab[curve_id]();
+}
+
+const PairingEntry& pairing_entry(int curve_id) {
+  typedef const PairingEntry* (*Fn)();
+  static const Fn tab[4] = {pcd_pairing_entry_0, pcd_pairing_entry_1, pcd_pairing_entry_2, pcd_pairing_entry_3};
   return *tab[curve_id]();
 }
 
@@ -434,7 +442,7 @@ int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const u
     TRY(fe.fft_run(st, *t, v, tmp, log_n, 1, 0, nullptr, nullptr));
     TRY(fe.fft_run(st, *t, v, tmp, log_n, 0, 1, nullptr, nullptr));
   }
-  TRY(fe.mul_sub_divz(st, a, b, c, log_n));
+  TRY(fe.mul_sub_divz(st, *t, a, b, c, log_n));
   TRY(fe.fft_run(st, *t, a, tmp, log_n, 1, 1, nullptr, nullptr));
   *log_n_out = log_n;
   return PCDHIP_OK;
@@ -645,6 +653,78 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   for (auto& e : ev) (void)hipEventDestroy(e);
   return PCDHIP_OK;
 }
+// ------------------------------------------------------------------------------------------------ pairing
+int pcdhip_multi_pairing(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy,
+                         const uint8_t* g2_inf, size_t n_pairs, uint64_t* gt_out) {
+  if (!ctx || !valid_curve(curve_id) || (n_pairs && (!g1_xy || !g2_xy)) || !gt_out || n_pairs >= (1u << 24)) return PCDHIP_E_ARG;
+  BIND();
+  const PairingEntry& pe = pairing_entry(curve_id);
+  const size_t w1 = (size_t)pcdhip_point_limbs(curve_id, 1) * 8, w2 = (size_t)pcdhip_point_limbs(curve_id, 2) * 8;
+  const size_t gb = (size_t)pe.gt_words * 4;
+  TRY(ctx->aux_ws.ensure(AUX_MISC, n_pairs * (w1 + w2 + gb) + gb + 256));
+  char* d = (char*)ctx->aux_ws.buf[AUX_MISC];
+  uint32_t* g1d = (uint32_t*)d;
+  uint32_t* g2d = (uint32_t*)(d + n_pairs * w1);
+  uint32_t* scr = (uint32_t*)(d + n_pairs * (w1 + w2));
+  uint32_t* out = (uint32_t*)(d + n_pairs * (w1 + w2 + gb));
+  if (n_pairs) {
+    TRY(hipMemcpyAsync(g1d, g1_xy, n_pairs * w1, hipMemcpyHostToDevice, ctx->stream));
+    TRY(hipMemcpyAsync(g2d, g2_xy, n_pairs * w2, hipMemcpyHostToDevice, ctx->stream));
+    for (size_t i = 0; i < n_pairs; i++) {  // flagged infinities -> (0,0)
+      if (g1_inf && g1_inf[i]) TRY(hipMemsetAsync((char*)g1d + i * w1, 0, w1, ctx->stream));
+      if (g2_inf && g2_inf[i]) TRY(hipMemsetAsync((char*)g2d + i * w2, 0, w2, ctx->stream));
+    }
+  }
+  TRY(pe.multi_pairing(ctx->stream, g1d, g2d, (uint32_t)n_pairs, scr, out));
+  TRY(hipMemcpyAsync(gt_out, out, gb, hipMemcpyDeviceToHost, ctx->stream));
+  TRY(hipStreamSynchronize(ctx->stream));
+  return PCDHIP_OK;
+}
+
+int pcdhip_groth16_verify(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, const uint64_t* beta_g2, const uint64_t* gamma_g2,
+                          const uint64_t* delta_g2, const uint64_t* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs,
+                          const uint64_t* public_inputs_canonical, const uint64_t* proof, const uint8_t* proof_inf, int* ok) {
+  if (!ctx || !valid_curve(curve_id) || !alpha_g1 || !beta_g2 || !gamma_g2 || !delta_g2 || !gamma_abc_g1 || num_inputs < 1 ||
+      (num_inputs > 1 && !public_inputs_canonical) || !proof || !ok)
+    return PCDHIP_E_ARG;
+  BIND();
+  *ok = 0;
+  const size_t l1 = (size_t)pcdhip_point_limbs(curve_id, 1), l2 = (size_t)pcdhip_point_limbs(curve_id, 2);
+  const int fr = kCurveFr[curve_id];
+  const size_t sl = (size_t)kFieldLimbs[fr];
+  // acc = gamma_abc[0] + sum_i x_i gamma_abc[i]   (a small MSM through the ordinary path, scalars 1, x_1, ...)
+  std::vector<uint64_t> scal(num_inputs * sl, 0);
+  scal[0] = 1;
+  for (size_t i = 1; i < num_inputs; i++) memcpy(&scal[i * sl], public_inputs_canonical + (i - 1) * sl, sl * 8);
+  const int saved = ctx->precompute;
+  ctx->precompute = 0;
+  pcdhip_bases* gb = nullptr;
+  int rc = pcdhip_bases_upload(ctx, curve_id, 1, gamma_abc_g1, gamma_abc_inf, num_inputs, &gb);
+  ctx->precompute = saved;
+  if (rc) return rc;
+  std::vector<uint64_t> acc_j(l1 / 2 * 3), acc_a(l1);
+  uint8_t acc_inf = 0;
+  rc = pcdhip_msm(ctx, gb, 0, scal.data(), num_inputs, acc_j.data());
+  pcdhip_bases_free(ctx, gb);
+  if (rc) return rc;
+  rc = pcdhip_to_affine(ctx, curve_id, 1, acc_j.data(), 1, acc_a.data(), &acc_inf);
+  if (rc) return rc;
+  // e(A, B) == e(alpha, beta) e(acc, gamma) e(C, delta)
+  const PairingEntry& pe = pairing_entry(curve_id);
+  std::vector<uint64_t> lhs(pe.gt_words / 2), rhs(pe.gt_words / 2);
+  uint8_t inf1[3] = {0, acc_inf, (uint8_t)(proof_inf ? proof_inf[2] : 0)};
+  uint8_t infA = proof_inf ? proof_inf[0] : 0, infB = proof_inf ? proof_inf[1] : 0;
+  rc = pcdhip_multi_pairing(ctx, curve_id, proof, &infA, proof + l1, &infB, 1, lhs.data());
+  if (rc) return rc;
+  std::vector<uint64_t> g1s(3 * l1), g2s(3 * l2);
+  memcpy(&g1s[0], alpha_g1, l1 * 8); memcpy(&g1s[l1], acc_a.data(), l1 * 8); memcpy(&g1s[2 * l1], proof + l1 + l2, l1 * 8);
+  memcpy(&g2s[0], beta_g2, l2 * 8); memcpy(&g2s[l2], gamma_g2, l2 * 8); memcpy(&g2s[2 * l2], delta_g2, l2 * 8);
+  rc = pcdhip_multi_pairing(ctx, curve_id, g1s.data(), inf1, g2s.data(), nullptr, 3, rhs.data());
+  if (rc) return rc;
+  *ok = (lhs == rhs) ? 1 : 0;
+  return PCDHIP_OK;
+}
+
 int pcdhip_groth16_last_timings(pcdhip_ctx* ctx, float out_ms[8]) {
   if (!ctx || !out_ms) return PCDHIP_E_ARG;
   memcpy(out_ms, ctx->g16_ms, sizeof ctx->g16_ms);

@@ -16,6 +16,7 @@ namespace pcd {
 
 struct FftTables {  // per (field, log_n): powers of w, w^-1, g, g^-1 (*1/n folded in), resident for reuse
   uint32_t *tw_fwd = nullptr, *tw_inv = nullptr, *coset = nullptr, *coset_inv_scaled = nullptr;
+  uint32_t consts[6 * 24] = {0};  // host copy of w, w^-1, g, g^-1, 1/n, 1/Z(g) (computed once, on the device)
 };
 
 }  // namespace pcd
@@ -99,7 +100,7 @@ struct FieldEntry {
   hipError_t (*spmv)(hipStream_t, const uint64_t* row_ptr, const uint32_t* col, const uint32_t* coeff, uint32_t rows,
                      const uint32_t* z, uint32_t num_inputs, int append_inputs, uint32_t n, uint32_t* out);
   // a = (a * b - c) / Z(g) on the coset of size 2^log_n
-  hipError_t (*mul_sub_divz)(hipStream_t, uint32_t* a, const uint32_t* b, const uint32_t* c, int log_n);
+  hipError_t (*mul_sub_divz)(hipStream_t, const FftTables& t, uint32_t* a, const uint32_t* b, const uint32_t* c, int log_n);
 };
 const FieldEntry& field_entry(int field_id);
 
@@ -114,5 +115,14 @@ struct CurveEntry {
   size_t assemble_scratch_bytes;
 };
 const CurveEntry& curve_entry(int curve_id);
+
+// ---- per-curve pairing entries (inst_pairing.hip) -----------------------------------------------------
+struct PairingEntry {
+  int gt_words;  // u32 words of one GT element (Fq4 / Fq6)
+  // gt_out = final_exp(prod_i miller(P_i, Q_i)); scratch: n GT elements
+  hipError_t (*multi_pairing)(hipStream_t, const uint32_t* g1_dev, const uint32_t* g2_dev, uint32_t n, uint32_t* scratch,
+                              uint32_t* gt_out);
+};
+const PairingEntry& pairing_entry(int curve_id);
 
 }  // namespace pcd

@@ -1,5 +1,7 @@
 // One object per scalar field (compile with -DPCD_FIELD_IDX=0..3): FFT driver, witness-map helpers.
 #include "common.h"
+#include <string.h>
+
 #include "fft.cuh"
 
 namespace pcd {
@@ -54,6 +56,8 @@ hipError_t get_consts(hipStream_t st, int log_n, DomainConsts* c) {
 hipError_t make_tables(hipStream_t st, int log_n, FftTables* t) {
   DomainConsts c;
   PCD_HIP_TRY(get_consts(st, log_n, &c));
+  static_assert(sizeof(DomainConsts) <= sizeof(t->consts), "consts buffer too small");
+  memcpy(t->consts, &c, sizeof c);
   const uint32_t n = 1u << log_n;
   const size_t bytes = (size_t)n * EW * 4;
   PCD_HIP_TRY(hipMalloc(&t->tw_fwd, bytes));
@@ -76,10 +80,10 @@ hipError_t run(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t* tmp, i
   const int P = (int)plan.size();
   const uint32_t* tw = inverse ? t.tw_inv : t.tw_fwd;
   DomainConsts c;
+  memcpy(&c, t.consts, sizeof c);
   FT scale = FT::one();
   int use_scale = 0;
   if (inverse && !coset) {  // plain 1/n: constant multiply in the last pass
-    PCD_HIP_TRY(get_consts(st, log_n, &c));
     scale = c.ninv;
     use_scale = 1;
   }
@@ -140,9 +144,9 @@ hipError_t spmv(hipStream_t st, const uint64_t* row_ptr, const uint32_t* col, co
   return hipGetLastError();
 }
 
-hipError_t mul_sub_divz(hipStream_t st, uint32_t* a, const uint32_t* b, const uint32_t* c, int log_n) {
+hipError_t mul_sub_divz(hipStream_t st, const FftTables& t, uint32_t* a, const uint32_t* b, const uint32_t* c, int log_n) {
   DomainConsts dc;
-  PCD_HIP_TRY(get_consts(st, log_n, &dc));
+  memcpy(&dc, t.consts, sizeof dc);
   const uint32_t n = 1u << log_n;
   hipLaunchKernelGGL(fft_mul_sub_scale<FT>, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, n, dc.zinv);
   return hipGetLastError();

@@ -1,0 +1,60 @@
+// One object per curve (compile with -DPCD_CURVE_IDX=0..3): pairing kernels (pairing.cuh).
+#include "common.h"
+#include "pairing.cuh"
+
+namespace pcd {
+
+#if PCD_CURVE_IDX == 0
+typedef PC_MNT4_298 PCT;
+#elif PCD_CURVE_IDX == 1
+typedef PC_MNT6_298 PCT;
+#elif PCD_CURVE_IDX == 2
+typedef PC_MNT4_753 PCT;
+#elif PCD_CURVE_IDX == 3
+typedef PC_MNT6_753 PCT;
+#else
+#error "PCD_CURVE_IDX must be 0..3"
+#endif
+
+namespace {
+
+typedef Pairing<PCT> PE;
+typedef typename PE::Fq Fq;
+typedef typename PE::E E;
+typedef typename PE::Fqk Fqk;
+constexpr int A1 = Aff<Fq>::WORDS, A2 = Aff<E>::WORDS, GW = Fqk::WORDS;
+
+// one lane per pair: f_i = miller_loop(P_i, Q_i)
+__global__ void __launch_bounds__(64) miller_kernel(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
+                                                    uint32_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fqk f = PE::miller_loop(Aff<Fq>::load(g1 + (size_t)i * A1), Aff<E>::load(g2 + (size_t)i * A2));
+  f.store(out + (size_t)i * GW);
+}
+// product of the n Miller values, then one final exponentiation
+__global__ void __launch_bounds__(64) final_exp_kernel(const uint32_t* __restrict__ fs, uint32_t n, uint32_t* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  typename PE::Frob t;
+  frob_init<Fq, PE::K, PCT::NR>(t);
+  Fqk f = Fqk::one();
+  for (uint32_t i = 0; i < n; i++) f = f * Fqk::load(fs + (size_t)i * GW);
+  PE::final_exponentiation(f, t).store(out);
+}
+
+hipError_t multi_pairing(hipStream_t st, const uint32_t* g1_dev, const uint32_t* g2_dev, uint32_t n, uint32_t* scratch, uint32_t* gt_out) {
+  if (n) hipLaunchKernelGGL(miller_kernel, dim3((n + 63) / 64), dim3(64), 0, st, g1_dev, g2_dev, n, scratch);
+  hipLaunchKernelGGL(final_exp_kernel, dim3(1), dim3(64), 0, st, scratch, n, gt_out);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+#define PCD_CAT_(a, b) a##b
+#define PCD_CAT(a, b) PCD_CAT_(a, b)
+const PairingEntry* PCD_CAT(pcd_pairing_entry_, PCD_CURVE_IDX)() {
+  static const PairingEntry e = {GW, multi_pairing};
+  return &e;
+}
+
+}  // namespace pcd

@@ -36,3 +36,23 @@ extern "C" int hc_msm_naive(int group_idx, const uint32_t* bases, const uint32_t
   }
   return 0;
 }
+
+#include "../../pcd_amd/csrc/pairing.cuh"
+template <class PC>
+static void pairing_host(const uint32_t* g1, const uint32_t* g2, uint32_t* out) {
+  typedef Pairing<PC> PE;
+  typename PE::Frob t;
+  frob_init<typename PE::Fq, PE::K, PC::NR>(t);
+  auto f = PE::miller_loop(Aff<typename PE::Fq>::load(g1), Aff<typename PE::E>::load(g2));
+  PE::final_exponentiation(f, t).store(out);
+}
+extern "C" int hc_pairing(int curve, const uint32_t* g1, const uint32_t* g2, uint32_t* out) {
+  switch (curve) {
+    case 0: pairing_host<PC_MNT4_298>(g1, g2, out); break;
+    case 1: pairing_host<PC_MNT6_298>(g1, g2, out); break;
+    case 2: pairing_host<PC_MNT4_753>(g1, g2, out); break;
+    case 3: pairing_host<PC_MNT6_753>(g1, g2, out); break;
+    default: return -1;
+  }
+  return 0;
+}

@@ -1,0 +1,76 @@
+"""GPU parity of the HIP pairing (pcdhip_multi_pairing / pcdhip_groth16_verify: ark-ec PairingEngine and
+ark-groth16 verify, reference call site src/ec_cycle_pcd/mod.rs:239) and of the KZG-style prefix MSMs of the
+Marlin configuration (`KZG10::commit` = MSM over a prefix of the resident powers)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_pairing_golden(golden, gpu_ctx, cid):
+    g = golden("pairing")
+    assert np.array_equal(gpu_ctx.multi_pairing(cid, g[f"c{cid}_p"], g[f"c{cid}_q"]), g[f"c{cid}_gt"])
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_pairing_vs_oracle_bilinear_and_product(co, gpu_ctx, cid):
+    fr = co.CURVE_FR[cid]
+    k = co.gen_scalars(fr, 2, seed=31)
+    g1, g2 = co.generator(cid, 1), co.generator(cid, 2)
+    a_g1 = co.to_affine(cid, 1, co.scalar_mul(cid, 1, g1, k[0]))[0][0]
+    b_g2 = co.to_affine(cid, 2, co.scalar_mul(cid, 2, g2, k[1]))[0][0]
+    e_ab = gpu_ctx.multi_pairing(cid, a_g1, b_g2)
+    assert np.array_equal(e_ab, co.pairing(cid, a_g1, b_g2))
+    # e(aP, bQ) = e(abP, Q)
+    ab = co.fp_op(fr, "to_canonical", co.fp_op(fr, "mul", co.fp_op(fr, "from_canonical", k[:1]), co.fp_op(fr, "from_canonical", k[1:2])))[0]
+    ab_g1 = co.to_affine(cid, 1, co.scalar_mul(cid, 1, g1, ab))[0][0]
+    assert np.array_equal(gpu_ctx.multi_pairing(cid, ab_g1, g2), e_ab)
+    # product of pairings with an inverse pair is one: e(aP, bQ) e(-abP, Q) = 1; infinity pairs contribute one
+    neg = co.to_affine(cid, 1, co.scalar_mul(cid, 1, ab_g1, co.fp_op(fr, "to_canonical", co.fp_op(fr, "neg", co.fp_op(fr, "from_canonical", np.array([[1] + [0] * (k.shape[1] - 1)], dtype=np.uint64))))[0]))[0][0]
+    one = gpu_ctx.multi_pairing(cid, np.stack([a_g1, neg, a_g1]), np.stack([b_g2, g2, b_g2]), g1_inf=[0, 0, 1])
+    L = k.shape[1] if cid < 2 else 12
+    assert one.reshape(-1, co.FIELD_N64[co.CURVE_FQ[cid]])[1:].any() == False  # noqa: E712  (c0 = 1, rest 0)
+    assert np.array_equal(gpu_ctx.multi_pairing(cid, np.zeros((0, a_g1.size), dtype=np.uint64), np.zeros((0, b_g2.size), dtype=np.uint64)), one)
+
+
+@pytest.mark.parametrize("cid,nc", [(0, 300), (1, 200)])
+def test_groth16_verify_on_gpu(co, gpu_ctx, cid, nc):
+    """tests/mnt4_groth16.rs:87 / :119 with BOTH prove and verify on the HIP path."""
+    fr = co.CURVE_FR[cid]
+    r = co.synthetic_r1cs(fr, nc, 3, seed=41)
+    keys = co.groth16_setup(cid, r, co.gen_field(fr, 5, seed=42), nthreads=16)
+    rs = co.gen_field(fr, 2, seed=43)
+    pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
+    proof, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
+    pk.free()
+    pub = co.fp_op(fr, "to_canonical", np.ascontiguousarray(r.z[1:r.num_inputs]))
+    args = (cid, keys.alpha_g1, keys.beta_g2, keys.gamma_g2, keys.delta_g2, keys.gamma_abc_g1)
+    assert gpu_ctx.groth16_verify(*args, pub, proof)
+    bad = pub.copy()
+    bad[0, 0] ^= 1
+    assert not gpu_ctx.groth16_verify(*args, bad, proof)
+    bad_proof = proof.copy()
+    w1 = co.point_words(cid, 1)
+    bad_proof[:w1] = keys.alpha_g1  # a valid point, wrong proof
+    assert not gpu_ctx.groth16_verify(*args, pub, bad_proof)
+
+
+def test_kzg_prefix_commitments(co, gpu_ctx):
+    """Marlin/KZG10 shape: one resident `powers_of_g`, commitments are MSMs over prefixes of it (coefficients with
+    leading zeros skipped by the caller: offset), plus a hiding MSM over `powers_of_gamma_g`."""
+    cid, n = 0, 6000
+    fr = co.CURVE_FR[cid]
+    powers = co.gen_points(cid, 1, n, seed=51)
+    gamma_powers = co.gen_points(cid, 1, 1000, seed=52)
+    b = gpu_ctx.bases_upload(cid, 1, powers)
+    bg = gpu_ctx.bases_upload(cid, 1, gamma_powers)
+    for deg, skip in ((999, 0), (4095, 17), (5999, 0), (10, 3)):
+        coeffs = co.gen_scalars(fr, deg + 1 - skip, seed=deg)
+        rnd = co.gen_scalars(fr, 1000, seed=deg + 1)
+        com = gpu_ctx.msm(b, coeffs, offset=skip, n=deg + 1 - skip)
+        hide = gpu_ctx.msm(bg, rnd)
+        got = gpu_ctx.points_sum(cid, 1, np.stack([com, hide]))
+        want = co.jac_add(cid, 1, co.msm(cid, 1, powers[skip:deg + 1], coeffs, nthreads=8), co.msm(cid, 1, gamma_powers, rnd, nthreads=8))
+        assert np.array_equal(co.to_affine(cid, 1, got)[0], co.to_affine(cid, 1, want)[0])
+    b.free(); bg.free()
