@@ -140,7 +140,7 @@ def main():
         out = {
             "metric": "msm_mscalar_mul_per_s", "value": round(value, 3), "unit": "Mscalar-mul/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (10 x 32-bit Montgomery, v_mad_u64_u32)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (11 x 28-bit unsaturated Montgomery limbs, v_mad_u64_u32 with 64-bit column accumulators)",
             "data": "synthetic",
             "config": {"workload": f"MNT4-298 G1 variable-base MSM, n=2^{LOG_N} pairs per GPU, proving-key bases and scalars "
                                    f"resident in HBM, scalar distribution {'uniform' if args.dist == 0 else 'witness-like'}",

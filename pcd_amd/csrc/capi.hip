@@ -211,13 +211,13 @@ void pcdhip_buf_free(pcdhip_ctx* ctx, pcdhip_buf* buf) {
 // ------------------------------------------------------------------------------------------------ MSM
 int pcdhip_bases_upload(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xy, const uint8_t* inf, size_t n,
                         pcdhip_bases** out) {
-  if (!ctx || !out || !valid_curve(curve_id) || !valid_group(group_id) || (!xy && n)) return PCDHIP_E_ARG;
+  if (!ctx || !out || !valid_curve(curve_id) || !valid_group(group_id) || (!xy && n) || n >= (1ull << 31)) return PCDHIP_E_ARG;
   BIND();
-  const size_t pl = (size_t)pcdhip_point_limbs(curve_id, group_id);
+  const GroupEntry& ge = group_entry(curve_id, group_id);
+  const size_t abi_b = (size_t)ge.point_abi_words * 4, int_b = (size_t)ge.point_words * 4;
   pcdhip_bases* b = new (std::nothrow) pcdhip_bases();
   if (!b) return PCDHIP_E_OOM;
   b->curve_id = curve_id; b->group_id = group_id; b->n = n; b->dptr = nullptr; b->c = 0; b->groups = 1;
-  const GroupEntry& ge = group_entry(curve_id, group_id);
   // Precomputed window-shifted copies (HBM capacity traded for the serial window combine): group g
   // holds 2^(c Wg g) P_i.  Full precomputation (Wg = 1) needs W copies of the query vector.
   if (ctx->precompute != 0 && n >= 64) {
@@ -229,19 +229,22 @@ int pcdhip_bases_upload(pcdhip_ctx* ctx, int curve_id, int group_id, const uint6
   }
   hipError_t e = hipErrorOutOfMemory;
   while (true) {
-    e = hipMalloc(&b->dptr, std::max<size_t>(n, 1) * pl * 8 * b->groups);
+    e = hipMalloc(&b->dptr, std::max<size_t>(n, 1) * int_b * b->groups);
     if (e == hipSuccess || b->groups == 1) break;
     (void)hipGetLastError();
     b->groups = (b->groups + 1) / 2;  // not enough HBM for this many copies: fewer groups, more bucket windows
   }
   if (e != hipSuccess) { delete b; return fail(ctx, e); }
   if (b->groups == 1) b->c = 0;
-  e = hipMemcpyAsync(b->dptr, xy, n * pl * 8, hipMemcpyHostToDevice, ctx->stream);
-  // points at infinity become (0, 0) on device (not on any of the curves: b != 0)
+  // stage the C-ABI image, rewrite flagged points to (0, 0) (not on any of the curves: b != 0), convert
+  e = ctx->aux_ws.ensure(AUX_MISC, std::max<size_t>(n, 1) * abi_b);
+  char* stage = (char*)ctx->aux_ws.buf[AUX_MISC];
+  if (e == hipSuccess) e = hipMemcpyAsync(stage, xy, n * abi_b, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && inf) {
     for (size_t i = 0; i < n && e == hipSuccess; i++)
-      if (inf[i]) e = hipMemsetAsync((char*)b->dptr + i * pl * 8, 0, pl * 8, ctx->stream);
+      if (inf[i]) e = hipMemsetAsync(stage + i * abi_b, 0, abi_b, ctx->stream);
   }
+  if (e == hipSuccess) e = ge.points_in(ctx->stream, (const uint32_t*)stage, (uint32_t)n, b->dptr);
   if (e == hipSuccess && b->groups > 1) {
     const int W = (ge.scalar_bits + b->c - 1) / b->c;
     const int Wg = (W + b->groups - 1) / b->groups;
@@ -285,13 +288,14 @@ int pcdhip_msm_last_timings(pcdhip_ctx* ctx, float out_ms[8]) {
 static int msm_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const uint32_t* scalars_dev, size_t n,
                       uint64_t* out_xyz) {
   const GroupEntry& ge = group_entry(bases->curve_id, bases->group_id);
-  const size_t out_bytes = (size_t)ge.point_words / 2 * 3 * 4;
-  TRY(ctx->msm_ws.ensure(WS_OUT, out_bytes + 64));
+  const size_t jac_b = (size_t)ge.point_words / 2 * 3 * 4, jac_abi_b = (size_t)ge.point_abi_words / 2 * 3 * 4;
+  TRY(ctx->msm_ws.ensure(WS_OUT, jac_b + jac_abi_b + 64));
   uint32_t* out_dev = (uint32_t*)ctx->msm_ws.buf[WS_OUT];
+  uint32_t* out_abi = out_dev + jac_b / 4;
   TRY(ge.msm(ctx->msm_ws, ctx->stream, bases->view(offset), scalars_dev, (uint32_t)n, out_dev, ctx->msm_c, ctx->msm_chunk,
              ctx->msm_profile ? &ctx->msm_tm : nullptr));
-  out_dev = (uint32_t*)ctx->msm_ws.buf[WS_OUT];
-  TRY(hipMemcpyAsync(out_xyz, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  TRY(ge.jac_out(ctx->stream, out_dev, 1, out_abi));
+  TRY(hipMemcpyAsync(out_xyz, out_abi, jac_abi_b, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
   return PCDHIP_OK;
 }
@@ -320,7 +324,7 @@ int pcdhip_points_sum(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_
   if (!ctx || !valid_curve(curve_id) || !valid_group(group_id) || (!xyz && n) || !out_xyz) return PCDHIP_E_ARG;
   BIND();
   const GroupEntry& ge = group_entry(curve_id, group_id);
-  const size_t jb = (size_t)ge.point_words / 2 * 3 * 4;
+  const size_t jb = (size_t)ge.point_abi_words / 2 * 3 * 4;
   TRY(ctx->aux_ws.ensure(AUX_MISC, (n + 1) * jb));
   uint32_t* d = (uint32_t*)ctx->aux_ws.buf[AUX_MISC];
   TRY(hipMemcpyAsync(d + jb / 4, xyz, n * jb, hipMemcpyHostToDevice, ctx->stream));
@@ -334,7 +338,7 @@ int pcdhip_to_affine(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t
   if (!ctx || !valid_curve(curve_id) || !valid_group(group_id) || (!xyz && n) || !out_xy) return PCDHIP_E_ARG;
   BIND();
   const GroupEntry& ge = group_entry(curve_id, group_id);
-  const size_t ab = (size_t)ge.point_words * 4, jb = ab / 2 * 3;
+  const size_t ab = (size_t)ge.point_abi_words * 4, jb = ab / 2 * 3;
   TRY(ctx->aux_ws.ensure(AUX_MISC, n * (jb + ab) + 64));
   uint32_t* dj = (uint32_t*)ctx->aux_ws.buf[AUX_MISC];
   uint32_t* da = dj + n * jb / 4;
@@ -363,9 +367,16 @@ int pcdhip_fft_dev(pcdhip_ctx* ctx, pcdhip_buf* data, uint32_t log_n, int invers
   const FftTables* t;
   int rc = get_tables(ctx, data->field_id, (int)log_n, &t);
   if (rc) return rc;
-  TRY(ctx->aux_ws.ensure(AUX_FFT_TMP, ((size_t)1 << log_n) * fe.words * 4));
-  TRY(fe.fft_run(ctx->stream, *t, data->dptr, (uint32_t*)ctx->aux_ws.buf[AUX_FFT_TMP], (int)log_n, inverse, coset, ctx->fft_ms,
-                 &ctx->fft_passes));
+  const uint32_t n = 1u << log_n;
+  const size_t vb = (size_t)n * fe.words * 4;
+  TRY(ctx->aux_ws.ensure(AUX_FFT_X, vb));
+  TRY(ctx->aux_ws.ensure(AUX_FFT_TMP, vb));
+  uint32_t* x = (uint32_t*)ctx->aux_ws.buf[AUX_FFT_X];
+  // C-ABI image -> device image, transform, and back (the witness-map pipeline keeps vectors in the device image
+  // between its seven transforms and pays neither conversion)
+  TRY(fe.convert(ctx->stream, data->dptr, x, n, 0));
+  TRY(fe.fft_run(ctx->stream, *t, x, (uint32_t*)ctx->aux_ws.buf[AUX_FFT_TMP], (int)log_n, inverse, coset, ctx->fft_ms, &ctx->fft_passes));
+  TRY(fe.convert(ctx->stream, x, data->dptr, n, 1));
   TRY(hipStreamSynchronize(ctx->stream));
   return PCDHIP_OK;
 }
@@ -374,10 +385,10 @@ int pcdhip_fft(pcdhip_ctx* ctx, int field_id, uint64_t* data, uint32_t log_n, in
   const FieldEntry& fe = field_entry(field_id);
   if ((int)log_n > fe.two_adicity) return PCDHIP_E_SIZE_UNSUPPORTED;
   BIND();
-  const size_t bytes = ((size_t)1 << log_n) * fe.words * 4;
-  TRY(ctx->aux_ws.ensure(AUX_FFT_X, bytes));
+  const size_t bytes = ((size_t)1 << log_n) * fe.abi_words * 4;
+  TRY(ctx->aux_ws.ensure(AUX_SCAL, bytes));
   pcdhip_buf tmp;
-  tmp.field_id = field_id; tmp.n = (size_t)1 << log_n; tmp.dptr = (uint32_t*)ctx->aux_ws.buf[AUX_FFT_X];
+  tmp.field_id = field_id; tmp.n = (size_t)1 << log_n; tmp.dptr = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
   TRY(hipMemcpyAsync(tmp.dptr, data, bytes, hipMemcpyHostToDevice, ctx->stream));
   int rc = pcdhip_fft_dev(ctx, &tmp, log_n, inverse, coset);
   if (rc) return rc;
@@ -394,24 +405,40 @@ int pcdhip_fft_last_timings(pcdhip_ctx* ctx, float out_ms[8]) {
 // ------------------------------------------------------------------------------------------------ witness map
 namespace {
 
-// uploads one CSR matrix into aux slots (rp/col/coeff packed into one allocation per matrix)
-int upload_csr(pcdhip_ctx* ctx, int slot, const pcdhip_csr* m, int limbs, DevCsr* out) {
+// device layout of one CSR matrix inside `d`: row_ptr | coeff (device image) | col;  `stage` holds the ABI coefficients
+size_t csr_bytes(const pcdhip_csr* m, const FieldEntry& fe, size_t off[3]) {
+  const uint64_t nnz = m->row_ptr[m->num_rows];
+  off[0] = 0;
+  off[1] = (m->num_rows + 1) * 8;
+  off[2] = off[1] + nnz * fe.words * 4;
+  return off[2] + (nnz * 4 + 7) / 8 * 8;
+}
+int upload_csr_to(pcdhip_ctx* ctx, const pcdhip_csr* m, const FieldEntry& fe, char* d, DevCsr* out) {
   if (!m || !m->row_ptr || (m->num_rows >> 31)) return PCDHIP_E_ARG;
   const uint64_t nnz = m->row_ptr[m->num_rows];
   if (nnz && (!m->col || !m->coeff)) return PCDHIP_E_ARG;
-  const size_t b_rp = (m->num_rows + 1) * 8, b_coef = nnz * limbs * 8, b_col = nnz * 4;
-  TRY(ctx->aux_ws.ensure(slot, b_rp + b_coef + b_col + 64));
-  char* d = (char*)ctx->aux_ws.buf[slot];
-  TRY(hipMemcpyAsync(d, m->row_ptr, b_rp, hipMemcpyHostToDevice, ctx->stream));
+  if (nnz >> 31) return PCDHIP_E_ARG;
+  size_t off[3];
+  csr_bytes(m, fe, off);
+  TRY(hipMemcpyAsync(d + off[0], m->row_ptr, (m->num_rows + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   if (nnz) {
-    TRY(hipMemcpyAsync(d + b_rp, m->coeff, b_coef, hipMemcpyHostToDevice, ctx->stream));
-    TRY(hipMemcpyAsync(d + b_rp + b_coef, m->col, b_col, hipMemcpyHostToDevice, ctx->stream));
+    TRY(ctx->aux_ws.ensure(AUX_SCAL, nnz * fe.abi_words * 4));
+    TRY(hipMemcpyAsync(ctx->aux_ws.buf[AUX_SCAL], m->coeff, nnz * fe.abi_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_SCAL], (uint32_t*)(d + off[1]), (uint32_t)nnz, 0));
+    TRY(hipMemcpyAsync(d + off[2], m->col, nnz * 4, hipMemcpyHostToDevice, ctx->stream));
+    TRY(hipStreamSynchronize(ctx->stream));  // the staging slot is reused by the next matrix
   }
-  out->rp = (const uint64_t*)d;
-  out->coeff = (const uint32_t*)(d + b_rp);
-  out->col = (const uint32_t*)(d + b_rp + b_coef);
+  out->rp = (const uint64_t*)(d + off[0]);
+  out->coeff = (const uint32_t*)(d + off[1]);
+  out->col = (const uint32_t*)(d + off[2]);
   out->rows = (uint32_t)m->num_rows;
   return PCDHIP_OK;
+}
+int upload_csr(pcdhip_ctx* ctx, int slot, const pcdhip_csr* m, const FieldEntry& fe, DevCsr* out) {
+  if (!m || !m->row_ptr) return PCDHIP_E_ARG;
+  size_t off[3];
+  TRY(ctx->aux_ws.ensure(slot, csr_bytes(m, fe, off) + 64));
+  return upload_csr_to(ctx, m, fe, (char*)ctx->aux_ws.buf[slot], out);
 }
 
 // h (n elements, Montgomery) left in aux slot AUX_A; z_dev: m elements on device; mats: A, B, C on device
@@ -448,10 +475,10 @@ int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const u
   return PCDHIP_OK;
 }
 
-int upload_three(pcdhip_ctx* ctx, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C, int limbs, DevCsr out[3]) {
+int upload_three(pcdhip_ctx* ctx, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C, const FieldEntry& fe, DevCsr out[3]) {
   const pcdhip_csr* ms[3] = {A, B, C};
   const int slots[3] = {AUX_CSR_RP, AUX_CSR_COL, AUX_CSR_COEF};  // one aux slot per matrix
-  for (int k = 0; k < 3; k++) { int rc = upload_csr(ctx, slots[k], ms[k], limbs, &out[k]); if (rc) return rc; }
+  for (int k = 0; k < 3; k++) { int rc = upload_csr(ctx, slots[k], ms[k], fe, &out[k]); if (rc) return rc; }
   return PCDHIP_OK;
 }
 }  // namespace
@@ -459,17 +486,23 @@ int upload_three(pcdhip_ctx* ctx, const pcdhip_csr* A, const pcdhip_csr* B, cons
 int pcdhip_groth16_witness_map(pcdhip_ctx* ctx, int field_id, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C,
                                const uint64_t* z, size_t num_vars, size_t num_inputs, uint64_t* h_out) {
   if (!ctx || !valid_field(field_id) || !A || !B || !C || !z || !h_out || num_inputs == 0 || num_inputs > num_vars) return PCDHIP_E_ARG;
+  if (num_vars >> 31) return PCDHIP_E_ARG;
   BIND();
-  const size_t zb = num_vars * kFieldLimbs[field_id] * 8;
-  TRY(ctx->aux_ws.ensure(AUX_Z, zb));
-  TRY(hipMemcpyAsync(ctx->aux_ws.buf[AUX_Z], z, zb, hipMemcpyHostToDevice, ctx->stream));
+  const FieldEntry& fe = field_entry(field_id);
+  TRY(ctx->aux_ws.ensure(AUX_Z, num_vars * fe.words * 4));
+  TRY(ctx->aux_ws.ensure(AUX_Z_CANON, num_vars * fe.abi_words * 4));
+  TRY(hipMemcpyAsync(ctx->aux_ws.buf[AUX_Z_CANON], z, num_vars * fe.abi_words * 4, hipMemcpyHostToDevice, ctx->stream));
+  TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_Z_CANON], (uint32_t*)ctx->aux_ws.buf[AUX_Z], (uint32_t)num_vars, 0));
   int log_n = 0;
   DevCsr mats[3];
-  int rc = upload_three(ctx, A, B, C, kFieldLimbs[field_id], mats);
+  int rc = upload_three(ctx, A, B, C, fe, mats);
   if (rc) return rc;
   rc = witness_map_dev(ctx, field_id, mats, (const uint32_t*)ctx->aux_ws.buf[AUX_Z], num_inputs, &log_n);
   if (rc) return rc;
-  TRY(hipMemcpyAsync(h_out, ctx->aux_ws.buf[AUX_A], ((size_t)1 << log_n) * kFieldLimbs[field_id] * 8, hipMemcpyDeviceToHost, ctx->stream));
+  const uint32_t n = 1u << log_n;
+  TRY(ctx->aux_ws.ensure(AUX_H_CANON, (size_t)n * fe.abi_words * 4));
+  TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_A], (uint32_t*)ctx->aux_ws.buf[AUX_H_CANON], n, 1));
+  TRY(hipMemcpyAsync(h_out, ctx->aux_ws.buf[AUX_H_CANON], (size_t)n * fe.abi_words * 4, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
   return PCDHIP_OK;
 }
@@ -506,8 +539,10 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
   rc = rc ? rc : upload_plus(1, h->l_query, h->l_inf, h->l_len, h->delta_g1, &pk->l_query);
   if (!rc) {
     const size_t w1 = (size_t)pcdhip_point_limbs(cid, 1) * 8, w2 = (size_t)pcdhip_point_limbs(cid, 2) * 8;
-    hipError_t e = hipMalloc(&pk->singles, 5 * w1 + 3 * w2);
-    char* d = (char*)pk->singles;
+    const CurveEntry& ce = curve_entry(cid);
+    hipError_t e = hipMalloc(&pk->singles, ce.singles_bytes);
+    if (e == hipSuccess) e = ctx->aux_ws.ensure(AUX_MISC, ce.singles_abi_bytes);
+    char* d = (char*)ctx->aux_ws.buf[AUX_MISC];  // C-ABI staging
     const uint64_t* g1s[5] = {h->alpha_g1, h->beta_g1, h->delta_g1, h->a_query, h->b_g1_query};
     for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipMemcpyAsync(d + i * w1, g1s[i], w1, hipMemcpyHostToDevice, ctx->stream);
     const uint64_t* g2s[3] = {h->beta_g2, h->delta_g2, h->b_g2_query};
@@ -516,6 +551,7 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
     if (e == hipSuccess && h->a_inf && h->a_inf[0]) e = hipMemsetAsync(d + 3 * w1, 0, w1, ctx->stream);
     if (e == hipSuccess && h->b_g1_inf && h->b_g1_inf[0]) e = hipMemsetAsync(d + 4 * w1, 0, w1, ctx->stream);
     if (e == hipSuccess && h->b_g2_inf && h->b_g2_inf[0]) e = hipMemsetAsync(d + 5 * w1 + 2 * w2, 0, w2, ctx->stream);
+    if (e == hipSuccess) e = ce.singles_in(ctx->stream, (const uint32_t*)d, pk->singles);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(ctx, e);
   }
@@ -526,31 +562,19 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
 int pcdhip_g16_pk_set_r1cs(pcdhip_ctx* ctx, pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C) {
   if (!ctx || !pk || !A || !B || !C) return PCDHIP_E_ARG;
   if (A->num_rows != B->num_rows || A->num_rows != C->num_rows || (A->num_rows >> 31)) return PCDHIP_E_ARG;
+  if (!A->row_ptr || !B->row_ptr || !C->row_ptr) return PCDHIP_E_ARG;
   BIND();
-  const int limbs = kFieldLimbs[kCurveFr[pk->curve_id]];
+  const FieldEntry& fe = field_entry(kCurveFr[pk->curve_id]);
   const pcdhip_csr* ms[3] = {A, B, C};
-  size_t total = 0, offs[3][3];
-  for (int k = 0; k < 3; k++) {
-    if (!ms[k]->row_ptr) return PCDHIP_E_ARG;
-    const uint64_t nnz = ms[k]->row_ptr[ms[k]->num_rows];
-    if (nnz && (!ms[k]->col || !ms[k]->coeff)) return PCDHIP_E_ARG;
-    offs[k][0] = total; total += (ms[k]->num_rows + 1) * 8;
-    offs[k][1] = total; total += nnz * limbs * 8;
-    offs[k][2] = total; total += (nnz * 4 + 7) / 8 * 8;
-  }
+  size_t total = 0, base[3], off[3];
+  for (int k = 0; k < 3; k++) { base[k] = total; total += csr_bytes(ms[k], fe, off) + 64; }
   if (pk->r1cs_dev) { (void)hipFree(pk->r1cs_dev); pk->r1cs_dev = nullptr; }
   TRY(hipMalloc(&pk->r1cs_dev, total + 64));
-  char* d = (char*)pk->r1cs_dev;
   for (int k = 0; k < 3; k++) {
-    const uint64_t nnz = ms[k]->row_ptr[ms[k]->num_rows];
-    TRY(hipMemcpyAsync(d + offs[k][0], ms[k]->row_ptr, (ms[k]->num_rows + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (nnz) {
-      TRY(hipMemcpyAsync(d + offs[k][1], ms[k]->coeff, nnz * limbs * 8, hipMemcpyHostToDevice, ctx->stream));
-      TRY(hipMemcpyAsync(d + offs[k][2], ms[k]->col, nnz * 4, hipMemcpyHostToDevice, ctx->stream));
-    }
-    pk->rp[k] = (const uint64_t*)(d + offs[k][0]);
-    pk->coeff[k] = (const uint32_t*)(d + offs[k][1]);
-    pk->col[k] = (const uint32_t*)(d + offs[k][2]);
+    DevCsr dc;
+    int rc = upload_csr_to(ctx, ms[k], fe, (char*)pk->r1cs_dev + base[k], &dc);
+    if (rc) return rc;
+    pk->rp[k] = dc.rp; pk->coeff[k] = dc.coeff; pk->col[k] = dc.col;
   }
   pk->rows = (uint32_t)A->num_rows;
   TRY(hipStreamSynchronize(ctx->stream));
@@ -571,25 +595,28 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   BIND();
   const int cid = pk->curve_id, fr = kCurveFr[cid];
   const FieldEntry& fe = field_entry(fr);
-  const int limbs = kFieldLimbs[fr];
   const size_t m = pk->num_vars, ni = pk->num_inputs;
+  const uint32_t sw = (uint32_t)fe.abi_words;  // words of a canonical scalar == words of an ABI element
+  const size_t sb = (size_t)sw * 4;
   hipStream_t st = ctx->stream;
   hipEvent_t ev[8];
   for (auto& e : ev) TRY(hipEventCreate(&e));
   TRY(hipEventRecord(ev[0], st));
-  // z -> device (Montgomery, for the SpMV) and canonical copy (MSM scalars)
-  const size_t zb = m * limbs * 8;
-  TRY(ctx->aux_ws.ensure(AUX_Z, zb));
-  TRY(ctx->aux_ws.ensure(AUX_Z_CANON, zb + 4 * limbs * 8));  // + one slot after z for the delta scalar, + [r, s, -rs]
+  // z (C-ABI Montgomery) -> device image for the SpMV, and canonical words for the MSMs
+  TRY(ctx->aux_ws.ensure(AUX_Z, m * fe.words * 4));
+  TRY(ctx->aux_ws.ensure(AUX_SCAL, m * sb));
+  TRY(ctx->aux_ws.ensure(AUX_Z_CANON, (m + 4) * sb));  // + one slot after z for the delta scalar, + [r, s, -rs]
   uint32_t* z_dev = (uint32_t*)ctx->aux_ws.buf[AUX_Z];
+  uint32_t* z_abi = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
   uint32_t* z_can = (uint32_t*)ctx->aux_ws.buf[AUX_Z_CANON];
-  TRY(hipMemcpyAsync(z_dev, z, zb, hipMemcpyHostToDevice, st));
-  TRY(fe.convert(st, z_dev, z_can, (uint32_t)m, 0));
+  TRY(hipMemcpyAsync(z_abi, z, m * sb, hipMemcpyHostToDevice, st));
+  TRY(fe.convert(st, z_abi, z_dev, (uint32_t)m, 0));
+  TRY(fe.convert(st, z_abi, z_can, (uint32_t)m, 3));
   // K1: h
   int log_n = 0;
   DevCsr mats[3];
   int rc = PCDHIP_OK;
-  if (A && B && C) rc = upload_three(ctx, A, B, C, limbs, mats);
+  if (A && B && C) { TRY(hipStreamSynchronize(st)); rc = upload_three(ctx, A, B, C, fe, mats); }  // (staging slot AUX_SCAL is reused)
   else if (!A && !B && !C && pk->r1cs_dev) {
     for (int k = 0; k < 3; k++) mats[k] = {pk->rp[k], pk->col[k], pk->coeff[k], pk->rows};
   } else rc = PCDHIP_E_ARG;
@@ -597,26 +624,24 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   rc = witness_map_dev(ctx, fr, mats, z_dev, ni, &log_n);
   if (rc) return rc;
   const size_t n = (size_t)1 << log_n;
-  TRY(ctx->aux_ws.ensure(AUX_H_CANON, n * limbs * 8));
+  TRY(ctx->aux_ws.ensure(AUX_H_CANON, n * sb));
   uint32_t* h_can = (uint32_t*)ctx->aux_ws.buf[AUX_H_CANON];
-  TRY(fe.convert(st, (const uint32_t*)ctx->aux_ws.buf[AUX_A], h_can, (uint32_t)n, 0));
+  TRY(fe.convert(st, (const uint32_t*)ctx->aux_ws.buf[AUX_A], h_can, (uint32_t)n, 2));
   TRY(hipEventRecord(ev[1], st));
-  // K3/K4: five MSMs, results stay on device
+  // K3/K4: five MSMs, results stay on device (device image)
   const GroupEntry& g1 = group_entry(cid, 1);
   const GroupEntry& g2 = group_entry(cid, 2);
   const size_t j1 = (size_t)g1.point_words / 2 * 3 * 4, j2 = (size_t)g2.point_words / 2 * 3 * 4;
-  const size_t a1 = (size_t)g1.point_words * 4, a2 = (size_t)g2.point_words * 4;
   const CurveEntry& ce = curve_entry(cid);
-  TRY(ctx->aux_ws.ensure(AUX_G16, 4 * j1 + j2 + 2 * limbs * 8 + 2 * a1 + a2 + ce.assemble_scratch_bytes + 256));
+  TRY(ctx->aux_ws.ensure(AUX_G16, 4 * j1 + j2 + 2 * sb + ce.proof_abi_bytes + ce.assemble_scratch_bytes + 256));
   char* gbase = (char*)ctx->aux_ws.buf[AUX_G16];
   uint32_t* msm_g1 = (uint32_t*)gbase;
   uint32_t* msm_g2 = (uint32_t*)(gbase + 4 * j1);
   uint32_t* rs_dev = (uint32_t*)(gbase + 4 * j1 + j2);
-  uint32_t* proof_dev = (uint32_t*)(gbase + 4 * j1 + j2 + 2 * limbs * 8);
-  uint32_t* scratch = (uint32_t*)(gbase + 4 * j1 + j2 + 2 * limbs * 8 + 2 * a1 + a2);
-  TRY(hipMemcpyAsync(rs_dev, r_mont, limbs * 8, hipMemcpyHostToDevice, st));
-  TRY(hipMemcpyAsync((char*)rs_dev + limbs * 8, s_mont, limbs * 8, hipMemcpyHostToDevice, st));
-  const uint32_t sw = (uint32_t)limbs * 2;
+  uint32_t* proof_dev = (uint32_t*)(gbase + 4 * j1 + j2 + 2 * sb);
+  uint32_t* scratch = (uint32_t*)(gbase + 4 * j1 + j2 + 2 * sb + ce.proof_abi_bytes);
+  TRY(hipMemcpyAsync(rs_dev, r_mont, sb, hipMemcpyHostToDevice, st));
+  TRY(hipMemcpyAsync((char*)rs_dev + sb, s_mont, sb, hipMemcpyHostToDevice, st));
   const size_t hl = std::min<size_t>(pk->h_query->n, n);
   MsmTimings* tm = nullptr;
   uint32_t* slot = z_can + m * sw;      // scalar of the appended delta point
@@ -624,23 +649,24 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   TRY(ce.prepare_scalars(st, rs_dev, extra));
   TRY(g1.msm(ctx->msm_ws, st, pk->h_query->view(0), h_can, (uint32_t)hl, msm_g1, ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[2], st));
-  TRY(hipMemcpyAsync(slot, extra + 2 * sw, limbs * 8, hipMemcpyDeviceToDevice, st));  // -rs
+  TRY(hipMemcpyAsync(slot, extra + 2 * sw, sb, hipMemcpyDeviceToDevice, st));  // -rs
   TRY(g1.msm(ctx->msm_ws, st, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni + 1), (uint32_t*)((char*)msm_g1 + j1), ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[3], st));
-  TRY(hipMemcpyAsync(slot, extra, limbs * 8, hipMemcpyDeviceToDevice, st));  // r
+  TRY(hipMemcpyAsync(slot, extra, sb, hipMemcpyDeviceToDevice, st));  // r
   TRY(g1.msm(ctx->msm_ws, st, pk->a_query->view(1), z_can + sw, (uint32_t)m, (uint32_t*)((char*)msm_g1 + 2 * j1), ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[4], st));
-  TRY(hipMemcpyAsync(slot, extra + sw, limbs * 8, hipMemcpyDeviceToDevice, st));  // s
+  TRY(hipMemcpyAsync(slot, extra + sw, sb, hipMemcpyDeviceToDevice, st));  // s
   TRY(g1.msm(ctx->msm_ws, st, pk->b_g1_query->view(1), z_can + sw, (uint32_t)m, (uint32_t*)((char*)msm_g1 + 3 * j1), ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[5], st));
   TRY(g2.msm(ctx->msm_ws, st, pk->b_g2_query->view(1), z_can + sw, (uint32_t)m, msm_g2, ctx->msm_c, ctx->msm_chunk, tm));
   TRY(hipEventRecord(ev[6], st));
-  // K5: assembly
+  // K5: assembly (writes the proof in the C-ABI image)
   TRY(ce.assemble(st, msm_g1, msm_g2, pk->singles, rs_dev, scratch, proof_dev));
   TRY(hipEventRecord(ev[7], st));
-  TRY(hipMemcpyAsync(proof_out, proof_dev, 2 * a1 + a2, hipMemcpyDeviceToHost, st));
+  TRY(hipMemcpyAsync(proof_out, proof_dev, ce.proof_abi_bytes, hipMemcpyDeviceToHost, st));
   TRY(hipStreamSynchronize(st));
   if (inf_out) {
+    const size_t a1 = (size_t)g1.point_abi_words * 4, a2 = (size_t)g2.point_abi_words * 4;
     const size_t offs[3] = {0, a1 / 8, (a1 + a2) / 8}, lens[3] = {a1 / 8, a2 / 8, a1 / 8};
     for (int i = 0; i < 3; i++) {
       uint64_t o = 0;
@@ -660,13 +686,13 @@ int pcdhip_multi_pairing(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, c
   BIND();
   const PairingEntry& pe = pairing_entry(curve_id);
   const size_t w1 = (size_t)pcdhip_point_limbs(curve_id, 1) * 8, w2 = (size_t)pcdhip_point_limbs(curve_id, 2) * 8;
-  const size_t gb = (size_t)pe.gt_words * 4;
-  TRY(ctx->aux_ws.ensure(AUX_MISC, n_pairs * (w1 + w2 + gb) + gb + 256));
+  const size_t gb = (size_t)pe.gt_words * 4, gi = (size_t)pe.gt_internal_words * 4;
+  TRY(ctx->aux_ws.ensure(AUX_MISC, n_pairs * (w1 + w2 + gi) + gb + 256));
   char* d = (char*)ctx->aux_ws.buf[AUX_MISC];
   uint32_t* g1d = (uint32_t*)d;
   uint32_t* g2d = (uint32_t*)(d + n_pairs * w1);
   uint32_t* scr = (uint32_t*)(d + n_pairs * (w1 + w2));
-  uint32_t* out = (uint32_t*)(d + n_pairs * (w1 + w2 + gb));
+  uint32_t* out = (uint32_t*)(d + n_pairs * (w1 + w2 + gi));
   if (n_pairs) {
     TRY(hipMemcpyAsync(g1d, g1_xy, n_pairs * w1, hipMemcpyHostToDevice, ctx->stream));
     TRY(hipMemcpyAsync(g2d, g2_xy, n_pairs * w2, hipMemcpyHostToDevice, ctx->stream));

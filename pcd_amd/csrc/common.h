@@ -16,7 +16,7 @@ namespace pcd {
 
 struct FftTables {  // per (field, log_n): powers of w, w^-1, g, g^-1 (*1/n folded in), resident for reuse
   uint32_t *tw_fwd = nullptr, *tw_inv = nullptr, *coset = nullptr, *coset_inv_scaled = nullptr;
-  uint32_t consts[6 * 24] = {0};  // host copy of w, w^-1, g, g^-1, 1/n, 1/Z(g) (computed once, on the device)
+  uint32_t consts[6 * 32] = {0};  // host copy of w, w^-1, g, g^-1, 1/n, 1/Z(g) (computed once, on the device)
 };
 
 }  // namespace pcd
@@ -76,26 +76,32 @@ typedef hipError_t (*PrecomputeFn)(hipStream_t, uint32_t* pts, uint32_t n, int g
 typedef hipError_t (*PointsSumFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* out_dev);
 typedef hipError_t (*ToAffineFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* aff_dev);
 struct GroupEntry {
-  int point_words;  // u32 words per affine point
-  int scalar_words; // u32 words per scalar
+  int point_words;      // u32 words per affine point, device-internal image (Jacobian = 3/2 of it)
+  int point_abi_words;  // u32 words per affine point at the C-ABI
+  int scalar_words;     // u32 words per canonical scalar
   int scalar_bits;
   MsmFn msm;
   PrecomputeFn precompute;
-  PointsSumFn points_sum;
-  ToAffineFn to_affine;
+  hipError_t (*points_in)(hipStream_t, const uint32_t* abi_dev, uint32_t n, uint32_t* internal_dev);  // affine, ABI -> internal
+  hipError_t (*jac_out)(hipStream_t, const uint32_t* internal_dev, uint32_t n, uint32_t* abi_dev);   // Jacobian, internal -> ABI
+  PointsSumFn points_sum;  // ABI in, ABI out
+  ToAffineFn to_affine;    // ABI in, ABI out
 };
 const GroupEntry& group_entry(int curve_id, int group_id);  // group_id 1 / 2
 
 // ---- per-field entries (inst_field.hip) ------------------------------------------------------------
 struct FieldEntry {
-  int words;  // u32 words per element
+  int words;      // u32 words per element, device-internal image
+  int abi_words;  // u32 words per element at the C-ABI
   int two_adicity;
   // fills tables for a domain of 2^log_n (allocates into `t`)
   hipError_t (*fft_make_tables)(hipStream_t, int log_n, FftTables* t);
   // x -> result in `x` (uses `tmp` as the ping-pong partner; both n elements)
   hipError_t (*fft_run)(hipStream_t, const FftTables& t, uint32_t* x, uint32_t* tmp, int log_n, int inverse, int coset,
                         float* pass_ms, int* npasses);
-  hipError_t (*convert)(hipStream_t, const uint32_t* in, uint32_t* out, uint32_t n, int to_mont);
+  // mode 0: ABI Montgomery -> internal, 1: internal -> ABI Montgomery, 2: internal -> canonical words,
+  // 3: ABI Montgomery -> canonical words
+  hipError_t (*convert)(hipStream_t, const uint32_t* in, uint32_t* out, uint32_t n, int mode);
   // a[i] = <A_i, z> for the rows, a[nc + j] = z[j] for inputs when `append_inputs`, zero padding to n
   hipError_t (*spmv)(hipStream_t, const uint64_t* row_ptr, const uint32_t* col, const uint32_t* coeff, uint32_t rows,
                      const uint32_t* z, uint32_t num_inputs, int append_inputs, uint32_t n, uint32_t* out);
@@ -108,8 +114,11 @@ const FieldEntry& field_entry(int field_id);
 struct CurveEntry {
   // out3 = canonical [r, s, -(r s)] from Montgomery (r, s) on device
   hipError_t (*prepare_scalars)(hipStream_t, const uint32_t* rs_dev, uint32_t* out3);
-  // msm_results: 5 Jacobian points on device in the order h, l, a, b_g1 (G1) then b_g2 (G2, at g2_off words)
-  // singles: see pcdhip_g16_pk;  r, s: Fr Montgomery (device);  proof_out: device affine A || B || C
+  // singles_abi (5 G1 + 3 G2 affine points, C-ABI image) -> device-internal image
+  hipError_t (*singles_in)(hipStream_t, const uint32_t* singles_abi, uint32_t* singles_internal);
+  size_t singles_abi_bytes, singles_bytes, proof_abi_bytes;
+  // msm_results: Jacobian points on device (internal image) in the order h, l, a, b_g1 (G1) and b_g2 (G2)
+  // singles: see pcdhip_g16_pk (internal);  rs: r, s Fr ABI Montgomery (device);  proof_out: C-ABI affine A || B || C
   hipError_t (*assemble)(hipStream_t, const uint32_t* msm_g1, const uint32_t* msm_g2, const uint32_t* singles,
                          const uint32_t* rs_dev, uint32_t* scratch, uint32_t* proof_out);
   size_t assemble_scratch_bytes;
@@ -118,7 +127,8 @@ const CurveEntry& curve_entry(int curve_id);
 
 // ---- per-curve pairing entries (inst_pairing.hip) -----------------------------------------------------
 struct PairingEntry {
-  int gt_words;  // u32 words of one GT element (Fq4 / Fq6)
+  int gt_words;           // u32 words of one GT element (Fq4 / Fq6) at the C-ABI
+  int gt_internal_words;  // ... in the device image (scratch sizing)
   // gt_out = final_exp(prod_i miller(P_i, Q_i)); scratch: n GT elements
   hipError_t (*multi_pairing)(hipStream_t, const uint32_t* g1_dev, const uint32_t* g2_dev, uint32_t n, uint32_t* scratch,
                               uint32_t* gt_out);

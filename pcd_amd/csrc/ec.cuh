@@ -6,8 +6,9 @@
 // add-2007-bl, dbl-2007-bl); results are compared with the oracle on affine coordinates only,
 // since projective representatives are not unique.
 //
-// Affine infinity is encoded as (0, 0) on device: (0,0) is not on any of the eight curves
-// (b != 0), and pcdhip_bases_upload rewrites flagged points to it.
+// Affine infinity is encoded as literal zeros (0, 0) on device: (0,0) is not on any of the eight curves
+// (b != 0), and pcdhip_bases_upload rewrites flagged points to it.  Coordinates live in the device-internal
+// field image (fp.cuh); from_abi / to_abi convert at the C-ABI.
 #pragma once
 #include "fp.cuh"
 
@@ -18,18 +19,24 @@ struct Jac {
   F X, Y, Z;
   PCD_HD static Jac infinity() { return {F::zero(), F::one(), F::zero()}; }
   PCD_HD bool is_inf() const { return Z.is_zero(); }
-  static constexpr int WORDS = 3 * F::WORDS;
+  static constexpr int WORDS = 3 * F::WORDS;          // device-internal image
+  static constexpr int ABI_WORDS = 3 * F::ABI_WORDS;  // C-ABI image (X || Y || Z, upstream Montgomery limbs)
   PCD_HD static Jac load(const uint32_t* p) { return {F::load(p), F::load(p + F::WORDS), F::load(p + 2 * F::WORDS)}; }
   PCD_HD void store(uint32_t* p) const { X.store(p); Y.store(p + F::WORDS); Z.store(p + 2 * F::WORDS); }
+  PCD_HD static Jac from_abi(const uint32_t* w) { return {F::from_abi(w), F::from_abi(w + F::ABI_WORDS), F::from_abi(w + 2 * F::ABI_WORDS)}; }
+  PCD_HD void to_abi(uint32_t* w) const { X.to_abi(w); Y.to_abi(w + F::ABI_WORDS); Z.to_abi(w + 2 * F::ABI_WORDS); }
 };
 
 template <class F>
 struct Aff {
   F x, y;
   static constexpr int WORDS = 2 * F::WORDS;
-  PCD_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+  static constexpr int ABI_WORDS = 2 * F::ABI_WORDS;
+  PCD_HD bool is_inf() const { return x.is_raw_zero() && y.is_raw_zero(); }  // (0,0) is stored as literal zeros
   PCD_HD static Aff load(const uint32_t* p) { return {F::load(p), F::load(p + F::WORDS)}; }
   PCD_HD void store(uint32_t* p) const { x.store(p); y.store(p + F::WORDS); }
+  PCD_HD static Aff from_abi(const uint32_t* w) { return {F::from_abi(w), F::from_abi(w + F::ABI_WORDS)}; }
+  PCD_HD void to_abi(uint32_t* w) const { x.to_abi(w); y.to_abi(w + F::ABI_WORDS); }
 };
 
 // ------------------------------------------------------------------------------------------------ group configs
@@ -95,12 +102,13 @@ struct EC {
     F Z1Z1 = p.Z.sqr();
     F U2 = q.x * Z1Z1;
     F S2 = q.y * p.Z * Z1Z1;
-    if (p.X == U2 && p.Y == S2) return dbl(p);
     F H = U2 - p.X;
+    F r = S2 - p.Y;
+    if (H.is_zero()) return r.is_zero() ? dbl(p) : J::infinity();  // same point / opposite points
     F HH = H.sqr();
     F I = HH.dbl().dbl();
     F Jv = H * I;
-    F r = (S2 - p.Y).dbl();
+    r = r.dbl();
     F V = p.X * I;
     J o;
     o.X = r.sqr() - Jv - V.dbl();
@@ -115,11 +123,12 @@ struct EC {
     F Z1Z1 = p.Z.sqr(), Z2Z2 = q.Z.sqr();
     F U1 = p.X * Z2Z2, U2 = q.X * Z1Z1;
     F S1 = p.Y * q.Z * Z2Z2, S2 = q.Y * p.Z * Z1Z1;
-    if (U1 == U2 && S1 == S2) return dbl(p);
     F H = U2 - U1;
+    F r = S2 - S1;
+    if (H.is_zero()) return r.is_zero() ? dbl(p) : J::infinity();
     F I = H.dbl().sqr();
     F Jv = H * I;
-    F r = (S2 - S1).dbl();
+    r = r.dbl();
     F V = U1 * I;
     J o;
     o.X = r.sqr() - Jv - V.dbl();

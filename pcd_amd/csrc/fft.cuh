@@ -111,14 +111,17 @@ __global__ void __launch_bounds__(256) fft_mul_sub_scale(uint32_t* __restrict__ 
   r.store(a + (size_t)i * F::WORDS);
 }
 
-// Montgomery -> canonical (scalars handed to the MSM) / canonical -> Montgomery
-template <class F, bool TO_MONT>
+// C-ABI <-> device image of field-element vectors.  MODE 0: ABI Montgomery -> internal, 1: internal -> ABI
+// Montgomery, 2: internal -> canonical words (`into_repr()`, the scalars handed to the MSM), 3: ABI Montgomery ->
+// canonical words.
+template <class F, int MODE>
 __global__ void __launch_bounds__(256) fp_convert_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  F v = F::load(in + (size_t)i * F::WORDS);
-  v = TO_MONT ? v.to_mont() : v.from_mont();
-  v.store(out + (size_t)i * F::WORDS);
+  if (MODE == 0) F::from_abi(in + (size_t)i * F::ABI_WORDS).store(out + (size_t)i * F::WORDS);
+  else if (MODE == 1) F::load(in + (size_t)i * F::WORDS).to_abi(out + (size_t)i * F::ABI_WORDS);
+  else if (MODE == 2) F::load(in + (size_t)i * F::WORDS).to_canonical_words(out + (size_t)i * F::ABI_WORDS);
+  else F::from_abi(in + (size_t)i * F::ABI_WORDS).to_canonical_words(out + (size_t)i * F::ABI_WORDS);
 }
 
 }  // namespace pcd

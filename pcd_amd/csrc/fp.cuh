@@ -1,17 +1,24 @@
-// Device prime-field arithmetic for the four MNT scalar/base fields (gfx950).
+// Device prime-field arithmetic for the four MNT scalar/base fields (gfx950), second design.
 //
 // Replaces, on device, ark-ff `Fp320` / `Fp768` as used by the prover arithmetic reached from
-// /root/reference src/ec_cycle_pcd/mod.rs:171,179 (SNARK::prove).  Elements are Montgomery
-// residues with R = 2^(32 N) (N = 10 / 24 u32 limbs == 5 / 12 u64 limbs, little-endian), i.e. the
-// in-memory image of the upstream field types, so the C-ABI needs no conversion.
+// /root/reference src/ec_cycle_pcd/mod.rs:171,179 (SNARK::prove).
 //
-// Instruction-rate facts this file is written against (profiles/r01_k0_int_rates.txt, MI355X):
-// v_mad_u64_u32 issues at half the v_add_u32 rate and so does every carry op (v_addc_co_u32), so
-// the product loops keep a 64-bit running value per mad and avoid separate carry instructions.
+// Representation (device-internal; the C-ABI keeps the upstream image, see from_abi / to_abi):
+//   * N unsaturated 28-bit limbs in 32-bit words (N = 11 for the 298-bit fields, 27 for the 753-bit ones),
+//   * Montgomery residues with R' = 2^(28 N)  (2^308 / 2^756),
+//   * every value normalised (limbs < 2^28) and kept in [0, 2p), not [0, p).
+// Why (profiles/r01_k0_int_rates.txt, MI355X): v_mad_u64_u32 issues at half the v_add_u32 rate and so does
+// every carry instruction (v_addc_co_u32, v_lshl_add_u64), so a saturated 32-bit CIOS product pays one carry
+// op per multiply (2 half-rate ops per limb product, plus the v_mov traffic hipcc adds: 27 % of the mad peak
+// in round 1's first kernel).  With 28-bit limbs a whole column of the product sums into ONE 64-bit register
+// by plain `acc += a*b` (2 N 2^56 < 2^64): one v_mad_u64_u32 per limb product and nothing else; the carry is a
+// shift per column.  R' > 4p makes the Montgomery product closed on [0, 2p) without a final subtraction;
+// additions are limb-wise v_add_u32 plus one normalising pass.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "params28_gen.h"
 #include "params_gen.h"
 
 namespace pcd {
@@ -19,25 +26,30 @@ namespace pcd {
 #define PCD_DEV __device__ __forceinline__
 #define PCD_HD __host__ __device__ __forceinline__
 
-// ------------------------------------------------------------------------------------------------
-#define PCD_DEF_FIELD(NAME, PFX)                                                             \
-  struct NAME {                                                                              \
-    static constexpr int ID = PFX##_ID;                                                      \
-    static constexpr int N = PFX##_N32;                                                      \
-    static constexpr int BITS = PFX##_BITS;                                                  \
-    static constexpr int TWO_ADICITY = PFX##_TWO_ADICITY;                                    \
-    static constexpr uint32_t INV = PFX##_INV32;                                             \
-    PCD_HD static uint32_t mod(int i) { constexpr uint32_t m[N] = PFX##_MOD; return m[i]; }  \
-    PCD_HD static uint32_t r1(int i) { constexpr uint32_t m[N] = PFX##_R; return m[i]; }     \
-    PCD_HD static uint32_t r2(int i) { constexpr uint32_t m[N] = PFX##_R2; return m[i]; }    \
-    PCD_HD static uint32_t gen(int i) { constexpr uint32_t m[N] = PFX##_GEN_MONT; return m[i]; }   \
-    PCD_HD static uint32_t root(int i) { constexpr uint32_t m[N] = PFX##_ROOT_MONT; return m[i]; } \
-    PCD_HD static uint32_t modm2(int i) { constexpr uint32_t m[N] = PFX##_MOD_MINUS_2; return m[i]; } \
+#define PCD_DEF_FIELD(NAME, PFX, PFX28)                                                                       \
+  struct NAME {                                                                                               \
+    static constexpr int ID = PFX##_ID;                                                                       \
+    static constexpr int N = PFX28##_N;    /* 28-bit limbs */                                                 \
+    static constexpr int N32 = PFX##_N32;  /* 32-bit words of the ABI image */                                \
+    static constexpr int BITS = PFX##_BITS;                                                                   \
+    static constexpr int TWO_ADICITY = PFX##_TWO_ADICITY;                                                     \
+    static constexpr uint32_t INV = PFX28##_INV;                                                              \
+    static constexpr int EST_SHIFT = PFX28##_EST_SHIFT;                                                       \
+    static constexpr uint32_t EST_RECIP = PFX28##_EST_RECIP;                                                  \
+    PCD_HD static uint32_t mod(int i) { constexpr uint32_t m[N] = PFX28##_MOD; return m[i]; }                 \
+    PCD_HD static uint32_t mod2(int i) { constexpr uint32_t m[N] = PFX28##_MOD2; return m[i]; }               \
+    PCD_HD static uint32_t one(int i) { constexpr uint32_t m[N] = PFX28##_ONE; return m[i]; }                 \
+    PCD_HD static uint32_t r2(int i) { constexpr uint32_t m[N] = PFX28##_R2; return m[i]; }                   \
+    PCD_HD static uint32_t cin(int i) { constexpr uint32_t m[N] = PFX28##_CIN; return m[i]; }                 \
+    PCD_HD static uint32_t cout(int i) { constexpr uint32_t m[N] = PFX28##_COUT; return m[i]; }               \
+    PCD_HD static uint32_t gen(int i) { constexpr uint32_t m[N] = PFX28##_GEN; return m[i]; }                 \
+    PCD_HD static uint32_t root(int i) { constexpr uint32_t m[N] = PFX28##_ROOT; return m[i]; }               \
+    PCD_HD static uint32_t modm2(int i) { constexpr uint32_t m[N32] = PFX##_MOD_MINUS_2; return m[i]; }       \
   };
-PCD_DEF_FIELD(F298A, PCD_F298A)
-PCD_DEF_FIELD(F298B, PCD_F298B)
-PCD_DEF_FIELD(F753A, PCD_F753A)
-PCD_DEF_FIELD(F753B, PCD_F753B)
+PCD_DEF_FIELD(F298A, PCD_F298A, PCD28_F298A)
+PCD_DEF_FIELD(F298B, PCD_F298B, PCD28_F298B)
+PCD_DEF_FIELD(F753A, PCD_F753A, PCD28_F753A)
+PCD_DEF_FIELD(F753B, PCD_F753B, PCD28_F753B)
 
 template <class P>
 struct Fp {
@@ -45,102 +57,134 @@ struct Fp {
   typedef Fp<P> Base;
   static constexpr int N = P::N;
   static constexpr int DEG = 1;
-  static constexpr int WORDS = N;  // u32 words per element
+  static constexpr int WORDS = N;           // u32 words per element in device memory
+  static constexpr int ABI_WORDS = P::N32;  // u32 words per element at the C-ABI
+  static constexpr uint32_t MASK = 0x0FFFFFFFu;
   uint32_t v[N];
 
   PCD_HD static Fp zero() { Fp r; for (int i = 0; i < N; i++) r.v[i] = 0; return r; }
-  PCD_HD static Fp one() { Fp r; for (int i = 0; i < N; i++) r.v[i] = P::r1(i); return r; }
+  PCD_HD static Fp one() { Fp r; for (int i = 0; i < N; i++) r.v[i] = P::one(i); return r; }
   PCD_HD static Fp r2() { Fp r; for (int i = 0; i < N; i++) r.v[i] = P::r2(i); return r; }
   PCD_HD static Fp generator() { Fp r; for (int i = 0; i < N; i++) r.v[i] = P::gen(i); return r; }
   PCD_HD static Fp two_adic_root() { Fp r; for (int i = 0; i < N; i++) r.v[i] = P::root(i); return r; }
 
-  PCD_HD bool is_zero() const { uint32_t o = 0; for (int i = 0; i < N; i++) o |= v[i]; return o == 0; }
-  PCD_HD bool operator==(const Fp& b) const { uint32_t o = 0; for (int i = 0; i < N; i++) o |= v[i] ^ b.v[i]; return o == 0; }
+  PCD_HD bool is_raw_zero() const { uint32_t o = 0; for (int i = 0; i < N; i++) o |= v[i]; return o == 0; }
+  // value = 0 mod p  <=>  value in {0, p}
+  PCD_HD bool is_zero() const {
+    uint32_t o = 0, q = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) { o |= v[i]; q |= v[i] ^ P::mod(i); }
+    return o == 0 || q == 0;
+  }
+  PCD_HD bool operator==(const Fp& b) const { return (*this - b).is_zero(); }
   PCD_HD bool operator!=(const Fp& b) const { return !(*this == b); }
 
-  // r = (a >= p) ? a - p : a      (a < 2p)
-  PCD_HD void reduce_once() {
-    uint32_t d[N];
-    uint64_t borrow = 0;
+  // t: signed limb values of an integer in [0, 2c), c = p (MODP) or 2p; returns it reduced to [0, c): the
+  // normalised value and value - c come out of two independent carry chains, the sign of the second selects.
+  template <bool MODP>
+  PCD_HD static Fp norm_reduce(const int32_t* t) {
+    Fp s, d;
+    int32_t cs = 0, cd = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      uint64_t x = (uint64_t)v[i] - P::mod(i) - borrow;
-      d[i] = (uint32_t)x;
-      borrow = (x >> 32) & 1;
+      int32_t x = t[i] + cs;
+      int32_t y = t[i] - (int32_t)(MODP ? P::mod(i) : P::mod2(i)) + cd;
+      if (i < N - 1) {
+        s.v[i] = (uint32_t)x & MASK; cs = x >> 28;
+        d.v[i] = (uint32_t)y & MASK; cd = y >> 28;
+      } else {
+        s.v[i] = (uint32_t)x;
+        d.v[i] = (uint32_t)y;
+      }
     }
-    if (!borrow) {
-#pragma unroll
-      for (int i = 0; i < N; i++) v[i] = d[i];
-    }
+    return ((int32_t)d.v[N - 1] < 0) ? s : d;
   }
   PCD_HD Fp operator+(const Fp& b) const {
-    Fp r;
-    uint64_t c = 0;
+    int32_t t[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) { uint64_t x = (uint64_t)v[i] + b.v[i] + c; r.v[i] = (uint32_t)x; c = x >> 32; }
-    r.reduce_once();  // the top limb has >= 15 spare bits: no carry out of limb N-1
-    return r;
+    for (int i = 0; i < N; i++) t[i] = (int32_t)(v[i] + b.v[i]);
+    return norm_reduce<false>(t);
   }
-  PCD_HD Fp operator-(const Fp& b) const {
-    Fp r;
-    uint64_t borrow = 0;
+  PCD_HD Fp operator-(const Fp& b) const {  // a - b + 2p in (0, 4p)
+    int32_t t[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) { uint64_t x = (uint64_t)v[i] - b.v[i] - borrow; r.v[i] = (uint32_t)x; borrow = (x >> 32) & 1; }
-    uint32_t mask = (uint32_t)0 - (uint32_t)borrow;
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) { uint64_t x = (uint64_t)r.v[i] + (P::mod(i) & mask) + c; r.v[i] = (uint32_t)x; c = x >> 32; }
-    return r;
+    for (int i = 0; i < N; i++) t[i] = (int32_t)v[i] - (int32_t)b.v[i] + (int32_t)P::mod2(i);
+    return norm_reduce<false>(t);
   }
-  PCD_HD Fp neg() const { return is_zero() ? *this : (zero() - *this); }
+  PCD_HD Fp neg() const { return zero() - *this; }
   PCD_HD Fp dbl() const { return *this + *this; }
+  // the representative in [0, p)
+  PCD_HD Fp canonical() const {
+    int32_t t[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = (int32_t)v[i];
+    return norm_reduce<true>(t);
+  }
 
-  // CIOS Montgomery product, canonical output in [0, p).  Deliberately NOT inlined: one fully
-  // unrolled copy of the multiplier per field per code object keeps the point kernels (11-16
-  // products per group operation, x3 / x6 for Fq2 / Fq3) at a compilable size; operands travel by
-  // value in VGPRs.  (A rolled row loop reads a.v[i] through scratch: ~500 cycles of exposed latency
-  // per row for a lone wave -- measured 2.5 us per 298-bit product in the serial MSM tail.)
+  // Montgomery product (product scanning, reduction interleaved): inputs and output in [0, 2p).
+  // NOT inlined: one fully unrolled copy per field per code object (2 N^2 v_mad_u64_u32 + ~6 N others).
   __host__ __device__ __noinline__ static Fp mul(Fp a, Fp b) {
-    uint32_t t[N + 2];
+    uint32_t m[N];
+    uint64_t acc = 0;
 #pragma unroll
-    for (int i = 0; i < N + 2; i++) t[i] = 0;
+    for (int k = 0; k < N; k++) {
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      const uint32_t ai = a.v[i];
-      uint32_t c = 0;
+      for (int i = 0; i <= k; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
 #pragma unroll
-      for (int j = 0; j < N; j++) { uint64_t x = (uint64_t)ai * b.v[j] + t[j] + c; t[j] = (uint32_t)x; c = (uint32_t)(x >> 32); }
-      uint64_t x = (uint64_t)t[N] + c;
-      t[N] = (uint32_t)x;
-      t[N + 1] = (uint32_t)(x >> 32);
-      uint32_t m = t[0] * P::INV;
-      x = (uint64_t)m * P::mod(0) + t[0];
-      c = (uint32_t)(x >> 32);
-#pragma unroll
-      for (int j = 1; j < N; j++) { x = (uint64_t)m * P::mod(j) + t[j] + c; t[j - 1] = (uint32_t)x; c = (uint32_t)(x >> 32); }
-      x = (uint64_t)t[N] + c;
-      t[N - 1] = (uint32_t)x;
-      t[N] = t[N + 1] + (uint32_t)(x >> 32);
+      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::mod(k - i);
+      m[k] = ((uint32_t)acc * P::INV) & MASK;
+      acc += (uint64_t)m[k] * P::mod(0);
+      acc >>= 28;
     }
     Fp r;
 #pragma unroll
-    for (int i = 0; i < N; i++) r.v[i] = t[i];
-    r.reduce_once();  // t < 2p since p < 2^(32N - 1)
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::mod(k - i);
+      r.v[k - N] = (uint32_t)acc & MASK;
+      acc >>= 28;
+    }
+    r.v[N - 1] = (uint32_t)acc;
     return r;
   }
   PCD_HD Fp operator*(const Fp& b) const { return mul(*this, b); }
-  PCD_HD Fp sqr() const { return *this * *this; }
+  PCD_HD Fp sqr() const { return mul(*this, *this); }
 
+  // multiplication by a small non-negative integer (curve / tower constants, k < 2^8)
   PCD_HD Fp mul_small(unsigned k) const {
-    Fp acc = zero(), base = *this;
-    while (k) { if (k & 1) acc = acc + base; k >>= 1; if (k) base = base.dbl(); }
-    return acc;
+    if (k == 0) return zero();
+    if (k == 1) return *this;
+    if (k == 2) return dbl();
+    if (k == 3) return dbl() + *this;
+    if (k == 4) return dbl().dbl();
+    uint32_t t[N];
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) { c += (uint64_t)v[i] * k; t[i] = (uint32_t)c & MASK; c >>= 28; }
+    c += (uint64_t)v[N - 1] * k;  // top limb, kept whole
+    // q <= floor(value / p), and value - q p < 2p + tiny
+    uint64_t top2 = (c << 28) | t[N - 2];
+    uint32_t est = (uint32_t)(top2 >> P::EST_SHIFT);
+    uint32_t q = (uint32_t)(((uint64_t)est * P::EST_RECIP) >> 32);
+    int32_t r[N];
+    int64_t cc = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+      cc += (int64_t)t[i] - (int64_t)((uint64_t)q * P::mod(i));
+      r[i] = (int32_t)((uint32_t)cc & MASK);
+      cc >>= 28;
+    }
+    cc += (int64_t)c - (int64_t)((uint64_t)q * P::mod(N - 1));
+    r[N - 1] = (int32_t)cc;  // < 4p / 2^(28(N-1)): small
+    return norm_reduce<false>(r);
   }
   // a^(p-2) (inverse; zero maps to zero)
   PCD_HD Fp inv() const {
     Fp r = one();
     bool started = false;
-    for (int i = N * 32 - 1; i >= 0; i--) {
+    for (int i = P::N32 * 32 - 1; i >= 0; i--) {
       if (started) r = r.sqr();
       if ((P::modm2(i >> 5) >> (i & 31)) & 1) { r = started ? r * *this : *this; started = true; }
     }
@@ -151,15 +195,15 @@ struct Fp {
     while (e) { if (e & 1) r = r * b; e >>= 1; if (e) b = b.sqr(); }
     return r;
   }
-  PCD_HD static Fp from_u64(uint64_t x) {
+  PCD_HD static Fp from_u64(uint64_t x) {  // small integer -> internal Montgomery form
     Fp r = zero();
-    r.v[0] = (uint32_t)x;
-    r.v[1] = (uint32_t)(x >> 32);
+    r.v[0] = (uint32_t)x & MASK;
+    r.v[1] = (uint32_t)(x >> 28) & MASK;
+    r.v[2] = (uint32_t)(x >> 56);
     return r * r2();
   }
-  PCD_HD Fp from_mont() const { Fp o = zero(); o.v[0] = 1; return *this * o; }  // -> canonical limbs
-  PCD_HD Fp to_mont() const { return *this * r2(); }                          // canonical -> Montgomery
 
+  // ---- device memory (internal image)
   PCD_HD static Fp load(const uint32_t* p) {
     Fp r;
 #pragma unroll
@@ -170,6 +214,47 @@ struct Fp {
 #pragma unroll
     for (int i = 0; i < N; i++) p[i] = v[i];
   }
+
+  // ---- C-ABI image: N32 little-endian 32-bit words (== L u64 limbs)
+  PCD_HD static Fp unpack32(const uint32_t* w) {  // plain integer < 2^(28 N), no Montgomery change
+    Fp r;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const int bit = 28 * j, q = bit >> 5, s = bit & 31;
+      uint32_t lo = (q < P::N32) ? (w[q] >> s) : 0u;
+      if (s > 4 && q + 1 < P::N32) lo |= w[q + 1] << (32 - s);
+      r.v[j] = lo & MASK;
+    }
+    return r;
+  }
+  PCD_HD void pack32(uint32_t* w) const {  // limbs must be normalised and the value < 2^(32 N32)
+#pragma unroll
+    for (int k = 0; k < P::N32; k++) {
+      const int bit = 32 * k, j = bit / 28, s = bit - 28 * j;  // word k = bits [32k, 32k+32)
+      uint64_t x = (j < N) ? ((uint64_t)v[j] >> s) : 0;
+      if (j + 1 < N) x |= (uint64_t)v[j + 1] << (28 - s);
+      if (j + 2 < N && 56 - s < 32) x |= (uint64_t)v[j + 2] << (56 - s);
+      w[k] = (uint32_t)x;
+    }
+  }
+  // ABI Montgomery (x R, R = 2^(32 N32)) <-> internal (x R')
+  PCD_HD static Fp from_abi(const uint32_t* w) {
+    Fp c;
+    for (int i = 0; i < N; i++) c.v[i] = P::cin(i);
+    return unpack32(w) * c;
+  }
+  PCD_HD void to_abi(uint32_t* w) const {
+    Fp c;
+    for (int i = 0; i < N; i++) c.v[i] = P::cout(i);
+    (*this * c).canonical().pack32(w);
+  }
+  // internal -> canonical integer words (`into_repr()`), and back
+  PCD_HD void to_canonical_words(uint32_t* w) const {
+    Fp o = zero();
+    o.v[0] = 1;
+    (*this * o).canonical().pack32(w);
+  }
+  PCD_HD static Fp from_canonical_words(const uint32_t* w) { return unpack32(w) * r2(); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -180,9 +265,11 @@ struct Fp2 {
   typedef F Base;
   static constexpr int DEG = 2;
   static constexpr int WORDS = 2 * F::WORDS;
+  static constexpr int ABI_WORDS = 2 * F::ABI_WORDS;
   F c0, c1;
   PCD_HD static Fp2 zero() { return {F::zero(), F::zero()}; }
   PCD_HD static Fp2 one() { return {F::one(), F::zero()}; }
+  PCD_HD bool is_raw_zero() const { return c0.is_raw_zero() && c1.is_raw_zero(); }
   PCD_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
   PCD_HD bool operator==(const Fp2& b) const { return c0 == b.c0 && c1 == b.c1; }
   PCD_HD bool operator!=(const Fp2& b) const { return !(*this == b); }
@@ -214,6 +301,8 @@ struct Fp2 {
   }
   PCD_HD static Fp2 load(const uint32_t* p) { return {F::load(p), F::load(p + F::WORDS)}; }
   PCD_HD void store(uint32_t* p) const { c0.store(p); c1.store(p + F::WORDS); }
+  PCD_HD static Fp2 from_abi(const uint32_t* w) { return {F::from_abi(w), F::from_abi(w + F::ABI_WORDS)}; }
+  PCD_HD void to_abi(uint32_t* w) const { c0.to_abi(w); c1.to_abi(w + F::ABI_WORDS); }
 };
 
 // F[u]/(u^3 - NR)   (ark-ff Fp3; G2 coordinates of MNT6)
@@ -223,9 +312,11 @@ struct Fp3 {
   typedef F Base;
   static constexpr int DEG = 3;
   static constexpr int WORDS = 3 * F::WORDS;
+  static constexpr int ABI_WORDS = 3 * F::ABI_WORDS;
   F c0, c1, c2;
   PCD_HD static Fp3 zero() { return {F::zero(), F::zero(), F::zero()}; }
   PCD_HD static Fp3 one() { return {F::one(), F::zero(), F::zero()}; }
+  PCD_HD bool is_raw_zero() const { return c0.is_raw_zero() && c1.is_raw_zero() && c2.is_raw_zero(); }
   PCD_HD bool is_zero() const { return c0.is_zero() && c1.is_zero() && c2.is_zero(); }
   PCD_HD bool operator==(const Fp3& b) const { return c0 == b.c0 && c1 == b.c1 && c2 == b.c2; }
   PCD_HD bool operator!=(const Fp3& b) const { return !(*this == b); }
@@ -267,6 +358,8 @@ struct Fp3 {
   }
   PCD_HD static Fp3 load(const uint32_t* p) { return {F::load(p), F::load(p + F::WORDS), F::load(p + 2 * F::WORDS)}; }
   PCD_HD void store(uint32_t* p) const { c0.store(p); c1.store(p + F::WORDS); c2.store(p + 2 * F::WORDS); }
+  PCD_HD static Fp3 from_abi(const uint32_t* w) { return {F::from_abi(w), F::from_abi(w + F::ABI_WORDS), F::from_abi(w + 2 * F::ABI_WORDS)}; }
+  PCD_HD void to_abi(uint32_t* w) const { c0.to_abi(w); c1.to_abi(w + F::ABI_WORDS); c2.to_abi(w + 2 * F::ABI_WORDS); }
 };
 
 }  // namespace pcd

@@ -116,10 +116,16 @@ hipError_t run(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t* tmp, i
   return hipSuccess;
 }
 
-hipError_t convert(hipStream_t st, const uint32_t* in, uint32_t* out, uint32_t n, int to_mont) {
+hipError_t convert(hipStream_t st, const uint32_t* in, uint32_t* out, uint32_t n, int mode) {
   if (n == 0) return hipSuccess;
-  if (to_mont) hipLaunchKernelGGL((fp_convert_kernel<FT, true>), dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
-  else hipLaunchKernelGGL((fp_convert_kernel<FT, false>), dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
+  dim3 gd((n + 255) / 256), bd(256);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((fp_convert_kernel<FT, 0>), gd, bd, 0, st, in, out, n); break;
+    case 1: hipLaunchKernelGGL((fp_convert_kernel<FT, 1>), gd, bd, 0, st, in, out, n); break;
+    case 2: hipLaunchKernelGGL((fp_convert_kernel<FT, 2>), gd, bd, 0, st, in, out, n); break;
+    case 3: hipLaunchKernelGGL((fp_convert_kernel<FT, 3>), gd, bd, 0, st, in, out, n); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 
@@ -157,7 +163,7 @@ hipError_t mul_sub_divz(hipStream_t st, const FftTables& t, uint32_t* a, const u
 #define PCD_CAT_(a, b) a##b
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const FieldEntry* PCD_CAT(pcd_field_entry_, PCD_FIELD_IDX)() {
-  static const FieldEntry e = {EW, FT::Params::TWO_ADICITY, make_tables, run, convert, spmv, mul_sub_divz};
+  static const FieldEntry e = {EW, FT::ABI_WORDS, FT::Params::TWO_ADICITY, make_tables, run, convert, spmv, mul_sub_divz};
   return &e;
 }
 

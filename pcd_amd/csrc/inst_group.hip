@@ -28,17 +28,19 @@ namespace {
 
 typedef typename GT::F F;
 
-__global__ void __launch_bounds__(64) points_sum_kernel(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+// host-facing utilities: inputs and outputs in the C-ABI image
+__global__ void __launch_bounds__(64) points_sum_kernel(const uint32_t* __restrict__ in_abi, uint32_t n, uint32_t* __restrict__ out_abi) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   Jac<F> acc = Jac<F>::infinity();
-  for (uint32_t i = 0; i < n; i++) acc = EC<GT>::add(acc, Jac<F>::load(in + (size_t)i * Jac<F>::WORDS));
-  acc.store(out);
+  for (uint32_t i = 0; i < n; i++) acc = EC<GT>::add(acc, Jac<F>::from_abi(in_abi + (size_t)i * Jac<F>::ABI_WORDS));
+  if (acc.is_inf()) acc = Jac<F>::infinity();
+  acc.to_abi(out_abi);
 }
-__global__ void __launch_bounds__(64) to_affine_kernel(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) to_affine_kernel(const uint32_t* __restrict__ in_abi, uint32_t n, uint32_t* __restrict__ out_abi) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Aff<F> a = EC<GT>::to_affine(Jac<F>::load(in + (size_t)i * Jac<F>::WORDS));
-  a.store(out + (size_t)i * Aff<F>::WORDS);
+  Aff<F> a = EC<GT>::to_affine(Jac<F>::from_abi(in_abi + (size_t)i * Jac<F>::ABI_WORDS));
+  a.to_abi(out_abi + (size_t)i * Aff<F>::ABI_WORDS);
 }
 
 hipError_t msm_entry(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bases, const uint32_t* scalars, uint32_t n,
@@ -47,6 +49,16 @@ hipError_t msm_entry(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bases
 }
 hipError_t precompute_entry(hipStream_t st, uint32_t* pts, uint32_t n, int groups, int shift) {
   return msm_precompute<GT>(st, pts, n, groups, shift);
+}
+hipError_t points_in_entry(hipStream_t st, const uint32_t* abi, uint32_t n, uint32_t* out) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((points_abi_to_internal_kernel<GT>), dim3((n + 63) / 64), dim3(64), 0, st, abi, n, out);
+  return hipGetLastError();
+}
+hipError_t jac_out_entry(hipStream_t st, const uint32_t* in, uint32_t n, uint32_t* abi) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((jac_internal_to_abi_kernel<GT>), dim3((n + 63) / 64), dim3(64), 0, st, in, n, abi);
+  return hipGetLastError();
 }
 hipError_t points_sum_entry(hipStream_t st, const uint32_t* jac, uint32_t n, uint32_t* out) {
   hipLaunchKernelGGL(points_sum_kernel, dim3(1), dim3(64), 0, st, jac, n, out);
@@ -63,7 +75,8 @@ hipError_t to_affine_entry(hipStream_t st, const uint32_t* jac, uint32_t n, uint
 #define PCD_CAT_(a, b) a##b
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const GroupEntry* PCD_CAT(pcd_group_entry_, PCD_GROUP_IDX)() {
-  static const GroupEntry e = {Aff<F>::WORDS, GT::FR::N, GT::FR::BITS, msm_entry, precompute_entry, points_sum_entry, to_affine_entry};
+  static const GroupEntry e = {Aff<F>::WORDS, Aff<F>::ABI_WORDS, GT::FR::N32, GT::FR::BITS, msm_entry, precompute_entry,
+                               points_in_entry, jac_out_entry, points_sum_entry, to_affine_entry};
   return &e;
 }
 

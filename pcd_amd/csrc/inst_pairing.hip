@@ -22,14 +22,14 @@ typedef Pairing<PCT> PE;
 typedef typename PE::Fq Fq;
 typedef typename PE::E E;
 typedef typename PE::Fqk Fqk;
-constexpr int A1 = Aff<Fq>::WORDS, A2 = Aff<E>::WORDS, GW = Fqk::WORDS;
+constexpr int A1A = Aff<Fq>::ABI_WORDS, A2A = Aff<E>::ABI_WORDS, GW = Fqk::WORDS, GWA = Fqk::ABI_WORDS;
 
-// one lane per pair: f_i = miller_loop(P_i, Q_i)
+// one lane per pair: f_i = miller_loop(P_i, Q_i); points arrive in the C-ABI image
 __global__ void __launch_bounds__(64) miller_kernel(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
                                                     uint32_t* __restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Fqk f = PE::miller_loop(Aff<Fq>::load(g1 + (size_t)i * A1), Aff<E>::load(g2 + (size_t)i * A2));
+  Fqk f = PE::miller_loop(Aff<Fq>::from_abi(g1 + (size_t)i * A1A), Aff<E>::from_abi(g2 + (size_t)i * A2A));
   f.store(out + (size_t)i * GW);
 }
 // product of the n Miller values, then one final exponentiation
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64) final_exp_kernel(const uint32_t* __restric
   frob_init<Fq, PE::K, PCT::NR>(t);
   Fqk f = Fqk::one();
   for (uint32_t i = 0; i < n; i++) f = f * Fqk::load(fs + (size_t)i * GW);
-  PE::final_exponentiation(f, t).store(out);
+  PE::final_exponentiation(f, t).to_abi(out);
 }
 
 hipError_t multi_pairing(hipStream_t st, const uint32_t* g1_dev, const uint32_t* g2_dev, uint32_t n, uint32_t* scratch, uint32_t* gt_out) {
@@ -53,7 +53,7 @@ hipError_t multi_pairing(hipStream_t st, const uint32_t* g1_dev, const uint32_t*
 #define PCD_CAT_(a, b) a##b
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const PairingEntry* PCD_CAT(pcd_pairing_entry_, PCD_CURVE_IDX)() {
-  static const PairingEntry e = {GW, multi_pairing};
+  static const PairingEntry e = {GWA, GW, multi_pairing};
   return &e;
 }
 

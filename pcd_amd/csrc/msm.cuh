@@ -297,6 +297,24 @@ __global__ void __launch_bounds__(64) msm_horner_kernel(const uint32_t* __restri
   total.store(out);
 }
 
+// ------------------------------------------------------------------------------------------------ C-ABI <-> device image
+template <class G>
+__global__ void __launch_bounds__(64) points_abi_to_internal_kernel(const uint32_t* __restrict__ abi, uint32_t n, uint32_t* __restrict__ out) {
+  typedef typename G::F F;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F>::from_abi(abi + (size_t)i * Aff<F>::ABI_WORDS).store(out + (size_t)i * Aff<F>::WORDS);
+}
+template <class G>
+__global__ void __launch_bounds__(64) jac_internal_to_abi_kernel(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ abi) {
+  typedef typename G::F F;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Jac<F> p = Jac<F>::load(in + (size_t)i * Jac<F>::WORDS);
+  if (p.is_inf()) p = Jac<F>::infinity();  // canonical (0 : 1 : 0)
+  p.to_abi(abi + (size_t)i * Jac<F>::ABI_WORDS);
+}
+
 // ------------------------------------------------------------------------------------------------ precomputed bases
 // out[g * n + i] = 2^(shift * g) * P_i  (affine), g = 0 .. groups-1.  One lane per point; one-time cost at
 // key upload (the proving key of a PCD is fixed for the whole computation).
@@ -361,7 +379,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
                    uint32_t* out_dev, int c_override, uint32_t chunk_override, MsmTimings* tm) {
   const uint32_t* bases_dev = bv.dptr;
   typedef typename G::F F;
-  constexpr int NS = G::FR::N;
+  constexpr int NS = G::FR::N32;  // canonical scalar words
   constexpr int PW = Jac<F>::WORDS;
   constexpr size_t PB = (size_t)PW * 4;
   if (n == 0) { Jac<F> inf = Jac<F>::infinity(); return hipMemcpyAsync(out_dev, &inf, PB, hipMemcpyHostToDevice, st); }

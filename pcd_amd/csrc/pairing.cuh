@@ -37,8 +37,10 @@ struct FpT2 {
     return {c0 * n, (c1 * n).neg()};
   }
   PCD_HD bool operator==(const FpT2& b) const { return c0 == b.c0 && c1 == b.c1; }
+  static constexpr int ABI_WORDS = 2 * E::ABI_WORDS;
   PCD_HD static FpT2 load(const uint32_t* p) { return {E::load(p), E::load(p + E::WORDS)}; }
   PCD_HD void store(uint32_t* p) const { c0.store(p); c1.store(p + E::WORDS); }
+  PCD_HD void to_abi(uint32_t* w) const { c0.to_abi(w); c1.to_abi(w + E::ABI_WORDS); }
 };
 template <class F, unsigned NR>
 PCD_HD Fp2<F, NR> ext_mul_by_u(const Fp2<F, NR>& x) { return {x.c1.mul_small(NR), x.c0}; }
@@ -56,16 +58,21 @@ template <class F, int K, unsigned NR>
 PCD_HD void frob_init(FrobTable<F, K>& t) {
   typedef typename F::Params P;
   // e = (q - 1) / K, long division on 32-bit limbs
-  uint32_t e[F::N];
+  // q - 1 = (q - 2) + 1 from the 32-bit words of the exponent table (the +1 may ripple: q = 1 mod 2^32 for
+  // the fields with 2-adicity >= 32), then long division by K
+  constexpr int NW = P::N32;
+  uint32_t qm1[NW], e[NW];
+  uint64_t carry = 1;
+  for (int i = 0; i < NW; i++) { uint64_t x = (uint64_t)P::modm2(i) + carry; qm1[i] = (uint32_t)x; carry = x >> 32; }
   uint64_t rem = 0;
-  for (int i = F::N - 1; i >= 0; i--) {
-    uint64_t cur = (rem << 32) | (uint64_t)(P::mod(i) - (i == 0 ? 1u : 0u));
+  for (int i = NW - 1; i >= 0; i--) {
+    uint64_t cur = (rem << 32) | (uint64_t)qm1[i];
     e[i] = (uint32_t)(cur / K);
     rem = cur % K;
   }
   F base = F::from_u64(NR), r = F::one();
   bool started = false;
-  for (int i = F::N * 32 - 1; i >= 0; i--) {
+  for (int i = NW * 32 - 1; i >= 0; i--) {
     if (started) r = r.sqr();
     if ((e[i >> 5] >> (i & 31)) & 1) { r = started ? r * base : base; started = true; }
   }

@@ -9,9 +9,9 @@ static void msm_naive(const uint32_t* bases, const uint32_t* scalars, int n, uin
   typedef typename G::F F;
   typedef EC<G> E;
   Jac<F> acc = Jac<F>::infinity();
-  constexpr int NS = G::FR::N;
+  constexpr int NS = G::FR::N32;
   for (int i = 0; i < n; i++) {
-    Aff<F> p = Aff<F>::load(bases + (size_t)i * Aff<F>::WORDS);
+    Aff<F> p = Aff<F>::from_abi(bases + (size_t)i * Aff<F>::ABI_WORDS);
     if (p.is_inf()) continue;
     Jac<F> q = E::mul(Jac<F>{p.x, p.y, F::one()}, scalars + (size_t)i * NS, NS);
     acc = E::add(acc, q);
@@ -19,7 +19,32 @@ static void msm_naive(const uint32_t* bases, const uint32_t* scalars, int n, uin
     acc = E::madd(acc, p);
     acc = E::add(acc, E::neg(Jac<F>{p.x, p.y, F::one()}));
   }
-  acc.store(out);
+  acc.to_abi(out);
+}
+
+// field-level checks: out[0..] = a*b, a+b, a-b, inv(a), a*17 (mul_small), canonical words of a  (ABI images)
+template <class P>
+static void field_ops(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  typedef Fp<P> F;
+  F x = F::from_abi(a), y = F::from_abi(b);
+  constexpr int W = F::ABI_WORDS;
+  (x * y).to_abi(out);
+  (x + y).to_abi(out + W);
+  (x - y).to_abi(out + 2 * W);
+  x.inv().to_abi(out + 3 * W);
+  x.mul_small(17).to_abi(out + 4 * W);
+  x.to_canonical_words(out + 5 * W);
+  ((x + y + y - x - x).dbl().neg().mul_small(121) * F::from_canonical_words(out + 5 * W)).to_abi(out + 6 * W);
+}
+extern "C" int hc_field_ops(int field, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  switch (field) {
+    case 0: field_ops<F298A>(a, b, out); break;
+    case 1: field_ops<F298B>(a, b, out); break;
+    case 2: field_ops<F753A>(a, b, out); break;
+    case 3: field_ops<F753B>(a, b, out); break;
+    default: return -1;
+  }
+  return 0;
 }
 
 extern "C" int hc_msm_naive(int group_idx, const uint32_t* bases, const uint32_t* scalars, int n, uint32_t* out) {
@@ -43,8 +68,8 @@ static void pairing_host(const uint32_t* g1, const uint32_t* g2, uint32_t* out) 
   typedef Pairing<PC> PE;
   typename PE::Frob t;
   frob_init<typename PE::Fq, PE::K, PC::NR>(t);
-  auto f = PE::miller_loop(Aff<typename PE::Fq>::load(g1), Aff<typename PE::E>::load(g2));
-  PE::final_exponentiation(f, t).store(out);
+  auto f = PE::miller_loop(Aff<typename PE::Fq>::from_abi(g1), Aff<typename PE::E>::from_abi(g2));
+  PE::final_exponentiation(f, t).to_abi(out);
 }
 extern "C" int hc_pairing(int curve, const uint32_t* g1, const uint32_t* g2, uint32_t* out) {
   switch (curve) {

@@ -1,0 +1,72 @@
+"""CPU: the __host__ __device__ field / curve / pairing templates of pcd_amd/csrc (the code the HIP kernels are
+made of) compiled for the HOST by tests/hostcheck/hostcheck.hip and checked against the oracles.  This is a
+test harness only -- the product has no CPU path -- but it lets the 28-bit-limb arithmetic, the C-ABI <-> device
+image conversions, the group law and the pairing formulas be verified in a GPU-less container."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HC = os.path.join(ROOT, "tests", "hostcheck")
+
+
+@pytest.fixture(scope="module")
+def hc():
+    so = os.path.join(HC, "libhostcheck.so")
+    srcs = [os.path.join(HC, "hostcheck.hip")] + [os.path.join(ROOT, "pcd_amd", "csrc", f) for f in
+                                                  ("fp.cuh", "ec.cuh", "pairing.cuh", "params_gen.h", "params28_gen.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared",
+                               os.path.join(HC, "hostcheck.hip"), "-o", so], stderr=subprocess.DEVNULL)
+    return C.CDLL(so)
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+def test_field_ops_and_abi_conversion(hc, fid):
+    from oracle import pyoracle as O
+    f = O.FIELDS[fid]
+    rnd = random.Random(5 + fid)
+    cases = [(0, 0), (f.p - 1, f.p - 1), (1, f.p - 1), (f.p - 1, 0), (2, 1)] + [(rnd.randrange(f.p), rnd.randrange(f.p)) for _ in range(60)]
+    for a, b in cases:
+        A, B = O.pack_fp(f, [a])[0], O.pack_fp(f, [b])[0]
+        out = np.zeros(7 * f.n64, dtype=np.uint64)
+        assert hc.hc_field_ops(fid, P(A), P(B), P(out)) == 0
+        got = out.reshape(7, f.n64)
+        exp = [a * b % f.p, (a + b) % f.p, (a - b) % f.p, pow(a, -1, f.p) if a else 0, a * 17 % f.p]
+        assert O.unpack_fp(f, got[:5]) == exp, (a, b)
+        assert O.unpack_fp(f, got[5:6], mont=False)[0] == a
+        assert O.unpack_fp(f, got[6:7])[0] == ((-(2 * ((a + b + b - a - a) % f.p))) * 121 * a) % f.p
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+@pytest.mark.parametrize("grp", [1, 2])
+def test_group_law(hc, co, cid, grp):
+    n = 6
+    pts = co.gen_points(cid, grp, n, seed=3)
+    pts[4] = pts[3]
+    sc = co.gen_scalars(co.CURVE_FR[cid], n, seed=4)
+    sc[1] = 0
+    sc[1, 0] = 1
+    sc[3] = sc[4]
+    out = np.zeros(3 * co.point_words(cid, grp) // 2, dtype=np.uint64)
+    assert hc.hc_msm_naive(cid * 2 + grp - 1, P(pts), P(sc), n, P(out)) == 0
+    want, _ = co.to_affine(cid, grp, co.msm(cid, grp, pts, sc))
+    got, _ = co.to_affine(cid, grp, out)
+    assert np.array_equal(want, got)
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_pairing(hc, golden, cid):
+    g = golden("pairing")
+    p, q = np.ascontiguousarray(g[f"c{cid}_p"]), np.ascontiguousarray(g[f"c{cid}_q"])
+    out = np.zeros_like(g[f"c{cid}_gt"])
+    assert hc.hc_pairing(cid, P(p), P(q), P(out)) == 0
+    assert np.array_equal(out, g[f"c{cid}_gt"])
