@@ -108,12 +108,19 @@ int pcdhip_to_affine(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t
  * In place, natural order in and out, Montgomery form. */
 int pcdhip_fft(pcdhip_ctx* ctx, int field_id, uint64_t* data_mont, uint32_t log_n, int inverse, int coset);
 int pcdhip_fft_dev(pcdhip_ctx* ctx, pcdhip_buf* data, uint32_t log_n, int inverse, int coset);
+/* K2m: ark-poly `GeneralEvaluationDomain` transforms on a domain of n = 2^a q^b elements (b <= 2; q = 7 for field
+ * F298A, 5 for F753A: `MixedRadixEvaluationDomain`, what upstream selects for the HELP proof of a PCD step once its
+ * circuit exceeds 2^17 / 2^15 rows); b = 0 is the radix-2 domain.  group_gen = GENERATOR^((p-1)/n). */
+int pcdhip_fft_general(pcdhip_ctx* ctx, int field_id, uint64_t* data_mont, size_t n, int inverse, int coset);
+/* Size `GeneralEvaluationDomain::new(min_size)` would pick (0 if none exists): the witness map uses it. */
+size_t pcdhip_domain_size(int field_id, size_t min_size);
 /* Per-pass device time of the last transform; returns the number of passes written (<= 8). */
 int pcdhip_fft_last_timings(pcdhip_ctx* ctx, float out_ms[8]);
 
 /* ---- K1: Groth16 witness map -------------------------------------------------------------------
  * Replaces ark-groth16 `R1CSToQAP::witness_map` (libsnark reduction): h = (A z o B z - C z) / Z on
- * the domain of size n = 2^ceil(log2(num_constraints + num_inputs)); writes n elements of h. */
+ * the domain `GeneralEvaluationDomain::new(num_constraints + num_inputs)` (radix-2, or mixed-radix for the help
+ * fields beyond their 2-adicity; n = pcdhip_domain_size(...)); writes n elements of h. */
 typedef struct {
   uint64_t num_rows;        /* = num_constraints */
   const uint64_t* row_ptr;  /* num_rows + 1 */

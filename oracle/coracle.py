@@ -36,6 +36,7 @@ def lib():
             build()
         _LIB = C.CDLL(so)
         _LIB.orc_synthetic_r1cs_num_vars.restype = C.c_size_t
+        _LIB.orc_domain_size.restype = C.c_size_t
     return _LIB
 
 
@@ -143,6 +144,20 @@ def fft(field, data, inverse=False, coset=False, nthreads=1):
     return data
 
 
+SMALL_SUBGROUP = {0: (7, 2), 2: (5, 2)}  # field id -> (q, adicity) of ark-ff SMALL_SUBGROUP_BASE (help fields only)
+
+
+def fft_general(field, data, m, inverse=False, coset=False, nthreads=1):
+    """transform of size n = m * 2^a (m = 1: radix-2; m = q or q^2: MixedRadixEvaluationDomain)."""
+    data = _u64(data).copy()
+    n = data.shape[0]
+    a = (n // m).bit_length() - 1
+    assert m << a == n
+    rc = lib().orc_fft_general(field, _p(data), C.c_size_t(m), a, int(inverse), int(coset), nthreads)
+    assert rc == 0, rc
+    return data
+
+
 class R1CS:
     """CSR triple + assignment in the C-ABI layout."""
 
@@ -186,8 +201,13 @@ def synthetic_r1cs(field, nc, num_inputs, seed):
     return R1CS(field, num_inputs, rp_ab, col_a, ca, rp_ab.copy(), col_b, cb, rp_c, col_c, cc, z)
 
 
+def domain_size(field, min_size):
+    """size of GeneralEvaluationDomain::new(min_size): radix-2, or mixed radix beyond the field's 2-adicity."""
+    return lib().orc_domain_size(field, C.c_size_t(min_size))
+
+
 def witness_map(r, nthreads=1):
-    n = 1 << r.domain_log
+    n = domain_size(r.field, r.num_constraints + r.num_inputs)
     h = np.zeros((n, FIELD_N64[r.field]), dtype=np.uint64)
     rc = lib().orc_witness_map(r.field, C.c_size_t(r.num_constraints), C.c_size_t(r.num_inputs), *r.csr_args(),
                                _p(r.z), nthreads, _p(h))

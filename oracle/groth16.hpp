@@ -69,12 +69,10 @@ struct Csr {
 inline int domain_log_for(size_t need) { int l = 0; while (((size_t)1 << l) < need) l++; return l; }
 
 // R1CSToQAP::witness_map -- libsnark reduction (Appendix A.2). Returns n coefficients of h.
-template <class Fr>
-std::vector<Fr> witness_map(const Csr<Fr>& A, const Csr<Fr>& B, const Csr<Fr>& C, const Fr* z,
-                            size_t num_inputs, int nthreads) {
+template <class Fr, class Dom>
+std::vector<Fr> witness_map_on(const Dom& dom, const Csr<Fr>& A, const Csr<Fr>& B, const Csr<Fr>& C, const Fr* z,
+                               size_t num_inputs, int nthreads) {
   size_t nc = A.rows;
-  int log_n = domain_log_for(nc + num_inputs);
-  Radix2Domain<Fr> dom(log_n);
   size_t n = dom.n;
   std::vector<Fr> a(n, Fr::zero()), b(n, Fr::zero()), c(n, Fr::zero());
   Radix2Domain<Fr>::parallel_for(nc, nthreads, [&](size_t lo, size_t hi) {
@@ -90,6 +88,18 @@ std::vector<Fr> witness_map(const Csr<Fr>& A, const Csr<Fr>& B, const Csr<Fr>& C
   });
   dom.coset_ifft(a.data(), nthreads);
   return a;
+}
+// domain = GeneralEvaluationDomain::new(num_constraints + num_inputs): radix-2 if it fits the 2-adicity, else mixed radix
+template <class Fr>
+std::vector<Fr> witness_map(const Csr<Fr>& A, const Csr<Fr>& B, const Csr<Fr>& C, const Fr* z, size_t num_inputs, int nthreads) {
+  typedef typename Fr::Params P;
+  size_t need = A.rows + num_inputs;
+  int log_n = domain_log_for(need);
+  if (log_n <= P::TWO_ADICITY) return witness_map_on(Radix2Domain<Fr>(log_n), A, B, C, z, num_inputs, nthreads);
+  size_t q = (P::ID == 0) ? 7 : (P::ID == 2) ? 5 : 0, m = 0;
+  int a = 0;
+  if (!q || !best_mixed_domain_size(need, q, 2, P::TWO_ADICITY, &m, &a)) return {};
+  return witness_map_on(MixedDomain<Fr>(m, a), A, B, C, z, num_inputs, nthreads);
 }
 
 // ------------------------------------------------------------------------------------------------ keys / proof

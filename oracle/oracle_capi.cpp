@@ -263,6 +263,21 @@ int orc_fft(int field, u64* data, int log_n, int inverse, int coset, int nthread
   return 0;
 }
 
+// general-size transform: n = m * 2^a with m in {1, q, q^2} (mixed-radix domain); m = 1 is the radix-2 domain
+int orc_fft_general(int field, u64* data, size_t m, int a, int inverse, int coset, int nthreads) {
+  if (m == 1) return orc_fft(field, data, a, inverse, coset, nthreads);
+  DISPATCH_FIELD(field, {
+    if (a > F::Params::TWO_ADICITY) return -3;
+    MixedDomain<F> dom(m, a);
+    F* x = reinterpret_cast<F*>(data);
+    if (!inverse && !coset) dom.fft(x, nthreads);
+    else if (inverse && !coset) dom.ifft(x, nthreads);
+    else if (!inverse && coset) dom.coset_fft(x, nthreads);
+    else dom.coset_ifft(x, nthreads);
+  });
+  return 0;
+}
+
 // Synthetic banded R1CS (same construction as pyoracle.synthetic_r1cs, different RNG):
 //   z = [1, inputs (num_inputs-1), 4 free witnesses, one product variable per constraint]
 //   row j: <A_j,z> * <B_j,z> = z[new_j];  A_j, B_j: 3 random coefficients on the 8 latest variables.
@@ -306,7 +321,18 @@ int orc_witness_map(int field, size_t nc, size_t num_inputs, const u64* rp_a, co
   DISPATCH_FIELD(field, {
     auto h = witness_map<F>(mk_csr<F>(nc, rp_a, col_a, coeff_a), mk_csr<F>(nc, rp_b, col_b, coeff_b),
                             mk_csr<F>(nc, rp_c, col_c, coeff_c), reinterpret_cast<const F*>(z), num_inputs, nthreads);
+    if (h.empty()) return -3;
     memcpy(h_out, h.data(), h.size() * sizeof(F));
+  });
+  return 0;
+}
+size_t orc_domain_size(int field, size_t min_size) {
+  DISPATCH_FIELD(field, {
+    int log_n = domain_log_for(min_size);
+    if (log_n <= F::Params::TWO_ADICITY) return (size_t)1 << log_n;
+    size_t q = (field == 0) ? 7 : (field == 2) ? 5 : 0, m = 0;
+    int a = 0;
+    return q ? best_mixed_domain_size(min_size, q, 2, F::Params::TWO_ADICITY, &m, &a) : 0;
   });
   return 0;
 }

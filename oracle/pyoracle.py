@@ -60,6 +60,12 @@ class Field:
         assert log_n <= self.two_adicity
         return pow(self.root, 1 << (self.two_adicity - log_n), self.p)
 
+    def domain_root_general(self, n):
+        """generator^((p-1)/n): the group generator of a radix-2 OR mixed-radix domain of size n (upstream:
+        TWO_ADIC_ROOT / LARGE_SUBGROUP_ROOT_OF_UNITY are both powers of GENERATOR)."""
+        assert (self.p - 1) % n == 0
+        return pow(self.generator, (self.p - 1) // n, self.p)
+
 
 FIELDS = [Field(d) for d in PARAMS["fields"]]
 
@@ -272,6 +278,41 @@ def fft(fld, xs, inverse=False, coset=False):
                 out[j] = out[j] * cur % p
                 cur = cur * ginv % p
     return out
+
+
+def dft_general(fld, xs, inverse=False, coset=False):
+    """Naive DFT over the size-n subgroup for ANY n | p-1 (mixed-radix domains n = 2^a q^b of
+    ark-poly MixedRadixEvaluationDomain), same conventions as `fft`."""
+    n = len(xs)
+    p, g = fld.p, fld.generator
+    w = fld.domain_root_general(n)
+    xs = list(xs)
+    if coset and not inverse:
+        xs = [x * pow(g, j, p) % p for j, x in enumerate(xs)]
+    if inverse:
+        w = pow(w, -1, p)
+    pw = [pow(w, i, p) for i in range(n)]
+    out = [sum(xs[j] * pw[(j * k) % n] for j in range(n)) % p for k in range(n)]
+    if inverse:
+        ninv = pow(n, -1, p)
+        out = [v * ninv % p for v in out]
+        if coset:
+            ginv = pow(g, -1, p)
+            out = [v * pow(ginv, j, p) % p for j, v in enumerate(out)]
+    return out
+
+
+def best_mixed_domain_size(fld, min_size, q, q_adicity=2):
+    """ark-poly `best_mixed_domain_size`: smallest 2^a q^b >= min_size with b <= q_adicity, a <= two-adicity."""
+    best = None
+    for b in range(q_adicity + 1):
+        r, a = q ** b, 0
+        while r < min_size:
+            r *= 2
+            a += 1
+        if a <= fld.two_adicity and (best is None or r < best):
+            best = r
+    return best
 
 
 # ----------------------------------------------------------------------------- R1CS / QAP / Groth16

@@ -46,7 +46,7 @@ EXPORTS = [
     "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
     "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config",
     "pcdhip_set_precompute", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_to_affine",
-    "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
+    "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
     "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings",
     "pcdhip_multi_pairing", "pcdhip_groth16_verify", "pcdhip_timer_start", "pcdhip_timer_stop",
 ]
@@ -63,6 +63,7 @@ def lib():
         _LIB.pcdhip_strerror.restype = C.c_char_p
         _LIB.pcdhip_last_hip_error.restype = C.c_char_p
         _LIB.pcdhip_destroy.restype = None
+        _LIB.pcdhip_domain_size.restype = C.c_size_t
         for name in ("pcdhip_buf_free", "pcdhip_bases_free", "pcdhip_g16_pk_free"):
             getattr(_LIB, name).restype = None
     return _LIB
@@ -183,6 +184,12 @@ class Context:
         self._check(lib().pcdhip_fft(self._ctx, field, _p(data), log_n, int(inverse), int(coset)))
         return data
 
+    def fft_general(self, field, data, inverse=False, coset=False):
+        """GeneralEvaluationDomain transform on n = 2^a q^b elements (mixed radix for the help fields)."""
+        data = _u64(data).copy()
+        self._check(lib().pcdhip_fft_general(self._ctx, field, _p(data), C.c_size_t(data.shape[0]), int(inverse), int(coset)))
+        return data
+
     def fft_last_timings(self):
         out = (C.c_float * 8)()
         k = lib().pcdhip_fft_last_timings(self._ctx, out)
@@ -201,7 +208,7 @@ class Context:
         A = self._csr(r1cs.rp_a, r1cs.col_a, r1cs.coeff_a)
         B = self._csr(r1cs.rp_b, r1cs.col_b, r1cs.coeff_b)
         Cm = self._csr(r1cs.rp_c, r1cs.col_c, r1cs.coeff_c)
-        n = 1 << r1cs.domain_log
+        n = lib().pcdhip_domain_size(field, C.c_size_t(r1cs.num_constraints + r1cs.num_inputs))
         h = np.zeros((n, FIELD_LIMBS[field]), dtype=np.uint64)
         self._check(lib().pcdhip_groth16_witness_map(self._ctx, field, C.byref(A), C.byref(B), C.byref(Cm), _p(r1cs.z),
                                                      C.c_size_t(r1cs.num_vars), C.c_size_t(r1cs.num_inputs), _p(h)))

@@ -70,6 +70,71 @@ int fail(pcdhip_ctx* ctx, hipError_t e) {
 enum { AUX_FFT_X = 0, AUX_FFT_TMP, AUX_A, AUX_B, AUX_C, AUX_Z, AUX_CSR_RP, AUX_CSR_COL, AUX_CSR_COEF, AUX_SCAL, AUX_OUT,
        AUX_G16, AUX_Z_CANON, AUX_H_CANON, AUX_MISC };
 
+// Evaluation domain as ark-poly `GeneralEvaluationDomain::new(min_size)` picks it: radix-2 when 2^ceil(log2 min_size)
+// fits the field's 2-adicity, otherwise the mixed-radix size 2^a q^b (b <= 2) of `best_mixed_domain_size`.
+struct Dom { uint32_t n, m; int a; };
+const uint32_t kSmallSubgroupBase[4] = {7, 0, 5, 0};  // ark-ff SMALL_SUBGROUP_BASE (adicity 2) of the two help fields
+
+int split_domain(int field_id, size_t n, Dom* d) {  // n = m * 2^a with m in {1, q, q^2}?
+  if (n == 0 || n >= (1ull << 31)) return PCDHIP_E_ARG;
+  const uint32_t q = kSmallSubgroupBase[field_id];
+  uint32_t m = 1;
+  size_t r = n;
+  for (int b = 0; b < 2 && q && r % q == 0; b++) { r /= q; m *= q; }
+  if (r & (r - 1)) return PCDHIP_E_SIZE_UNSUPPORTED;
+  int a = 0;
+  while (((size_t)1 << a) < r) a++;
+  if (a > field_entry(field_id).two_adicity) return PCDHIP_E_SIZE_UNSUPPORTED;
+  d->n = (uint32_t)n; d->m = m; d->a = a;
+  return PCDHIP_OK;
+}
+int pick_domain(int field_id, size_t min_size, Dom* d) {
+  const FieldEntry& fe = field_entry(field_id);
+  int log_n = 0;
+  while (((size_t)1 << log_n) < min_size) log_n++;
+  if (log_n <= fe.two_adicity) { d->n = 1u << log_n; d->m = 1; d->a = log_n; return PCDHIP_OK; }
+  const uint32_t q = kSmallSubgroupBase[field_id];
+  if (!q) return PCDHIP_E_SIZE_UNSUPPORTED;
+  size_t best = 0;
+  for (int b = 0; b <= 2; b++) {
+    size_t r = 1;
+    for (int i = 0; i < b; i++) r *= q;
+    const size_t mm = r;
+    int aa = 0;
+    while (r < min_size) { r *= 2; aa++; }
+    if (aa <= fe.two_adicity && r < (1ull << 31) && (best == 0 || r < best)) { best = r; d->n = (uint32_t)r; d->m = (uint32_t)mm; d->a = aa; }
+  }
+  return best ? PCDHIP_OK : PCDHIP_E_SIZE_UNSUPPORTED;
+}
+
+int get_tables(pcdhip_ctx* ctx, int field_id, int log_n, const FftTables** out);
+int get_mixed_tables(pcdhip_ctx* ctx, int field_id, const Dom& d, const FftTables** out) {
+  uint64_t key = (1ull << 63) | ((uint64_t)field_id << 32) | d.n;
+  auto it = ctx->fft_tables.find(key);
+  if (it == ctx->fft_tables.end()) {
+    FftTables t;
+    TRY(field_entry(field_id).mixed_make_tables(ctx->stream, d.n, d.m, &t));
+    it = ctx->fft_tables.emplace(key, t).first;
+  }
+  *out = &it->second;
+  return PCDHIP_OK;
+}
+// v (d.n elements, device image) transformed in place
+int domain_transform(pcdhip_ctx* ctx, int field_id, const Dom& d, uint32_t* v, uint32_t* tmp, int inverse, int coset, float* pass_ms,
+                     int* npasses) {
+  const FieldEntry& fe = field_entry(field_id);
+  const FftTables* t2;
+  int rc = get_tables(ctx, field_id, d.a, &t2);
+  if (rc) return rc;
+  if (d.m == 1) { TRY(fe.fft_run(ctx->stream, *t2, v, tmp, d.a, inverse, coset, pass_ms, npasses)); return PCDHIP_OK; }
+  const FftTables* t;
+  rc = get_mixed_tables(ctx, field_id, d, &t);
+  if (rc) return rc;
+  TRY(fe.mixed_run(ctx->stream, *t, *t2, v, tmp, d.m, d.a, inverse, coset));
+  if (npasses) *npasses = 0;
+  return PCDHIP_OK;
+}
+
 int get_tables(pcdhip_ctx* ctx, int field_id, int log_n, const FftTables** out) {
   uint64_t key = ((uint64_t)field_id << 32) | (uint32_t)log_n;
   auto it = ctx->fft_tables.find(key);
@@ -358,43 +423,61 @@ int pcdhip_to_affine(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t
 }
 
 // ------------------------------------------------------------------------------------------------ FFT
-int pcdhip_fft_dev(pcdhip_ctx* ctx, pcdhip_buf* data, uint32_t log_n, int inverse, int coset) {
-  if (!ctx || !data || log_n > 30) return PCDHIP_E_ARG;
+static int fft_dev_general(pcdhip_ctx* ctx, pcdhip_buf* data, const Dom& d, int inverse, int coset) {
   const FieldEntry& fe = field_entry(data->field_id);
-  if ((int)log_n > fe.two_adicity) return PCDHIP_E_SIZE_UNSUPPORTED;
-  if (data->n < ((size_t)1 << log_n)) return PCDHIP_E_ARG;
-  BIND();
-  const FftTables* t;
-  int rc = get_tables(ctx, data->field_id, (int)log_n, &t);
-  if (rc) return rc;
-  const uint32_t n = 1u << log_n;
-  const size_t vb = (size_t)n * fe.words * 4;
+  if (data->n < d.n) return PCDHIP_E_ARG;
+  const size_t vb = (size_t)d.n * fe.words * 4;
   TRY(ctx->aux_ws.ensure(AUX_FFT_X, vb));
   TRY(ctx->aux_ws.ensure(AUX_FFT_TMP, vb));
   uint32_t* x = (uint32_t*)ctx->aux_ws.buf[AUX_FFT_X];
   // C-ABI image -> device image, transform, and back (the witness-map pipeline keeps vectors in the device image
   // between its seven transforms and pays neither conversion)
-  TRY(fe.convert(ctx->stream, data->dptr, x, n, 0));
-  TRY(fe.fft_run(ctx->stream, *t, x, (uint32_t*)ctx->aux_ws.buf[AUX_FFT_TMP], (int)log_n, inverse, coset, ctx->fft_ms, &ctx->fft_passes));
-  TRY(fe.convert(ctx->stream, x, data->dptr, n, 1));
+  TRY(fe.convert(ctx->stream, data->dptr, x, d.n, 0));
+  int rc = domain_transform(ctx, data->field_id, d, x, (uint32_t*)ctx->aux_ws.buf[AUX_FFT_TMP], inverse, coset, ctx->fft_ms, &ctx->fft_passes);
+  if (rc) return rc;
+  TRY(fe.convert(ctx->stream, x, data->dptr, d.n, 1));
+  TRY(hipStreamSynchronize(ctx->stream));
+  return PCDHIP_OK;
+}
+int pcdhip_fft_dev(pcdhip_ctx* ctx, pcdhip_buf* data, uint32_t log_n, int inverse, int coset) {
+  if (!ctx || !data || log_n > 30) return PCDHIP_E_ARG;
+  if ((int)log_n > field_entry(data->field_id).two_adicity) return PCDHIP_E_SIZE_UNSUPPORTED;
+  BIND();
+  Dom d = {1u << log_n, 1, (int)log_n};
+  return fft_dev_general(ctx, data, d, inverse, coset);
+}
+static int fft_host_general(pcdhip_ctx* ctx, int field_id, uint64_t* data, const Dom& d, int inverse, int coset) {
+  const FieldEntry& fe = field_entry(field_id);
+  const size_t bytes = (size_t)d.n * fe.abi_words * 4;
+  TRY(ctx->aux_ws.ensure(AUX_SCAL, bytes));
+  pcdhip_buf tmp;
+  tmp.field_id = field_id; tmp.n = d.n; tmp.dptr = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
+  TRY(hipMemcpyAsync(tmp.dptr, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+  int rc = fft_dev_general(ctx, &tmp, d, inverse, coset);
+  if (rc) return rc;
+  TRY(hipMemcpyAsync(data, tmp.dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
   return PCDHIP_OK;
 }
 int pcdhip_fft(pcdhip_ctx* ctx, int field_id, uint64_t* data, uint32_t log_n, int inverse, int coset) {
   if (!ctx || !data || !valid_field(field_id) || log_n > 30) return PCDHIP_E_ARG;
-  const FieldEntry& fe = field_entry(field_id);
-  if ((int)log_n > fe.two_adicity) return PCDHIP_E_SIZE_UNSUPPORTED;
+  if ((int)log_n > field_entry(field_id).two_adicity) return PCDHIP_E_SIZE_UNSUPPORTED;
   BIND();
-  const size_t bytes = ((size_t)1 << log_n) * fe.abi_words * 4;
-  TRY(ctx->aux_ws.ensure(AUX_SCAL, bytes));
-  pcdhip_buf tmp;
-  tmp.field_id = field_id; tmp.n = (size_t)1 << log_n; tmp.dptr = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
-  TRY(hipMemcpyAsync(tmp.dptr, data, bytes, hipMemcpyHostToDevice, ctx->stream));
-  int rc = pcdhip_fft_dev(ctx, &tmp, log_n, inverse, coset);
+  Dom d = {1u << log_n, 1, (int)log_n};
+  return fft_host_general(ctx, field_id, data, d, inverse, coset);
+}
+int pcdhip_fft_general(pcdhip_ctx* ctx, int field_id, uint64_t* data, size_t n, int inverse, int coset) {
+  if (!ctx || !data || !valid_field(field_id)) return PCDHIP_E_ARG;
+  Dom d;
+  int rc = split_domain(field_id, n, &d);
   if (rc) return rc;
-  TRY(hipMemcpyAsync(data, tmp.dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  TRY(hipStreamSynchronize(ctx->stream));
-  return PCDHIP_OK;
+  BIND();
+  return fft_host_general(ctx, field_id, data, d, inverse, coset);
+}
+size_t pcdhip_domain_size(int field_id, size_t min_size) {
+  if (!valid_field(field_id) || min_size == 0) return 0;
+  Dom d;
+  return pick_domain(field_id, min_size, &d) == PCDHIP_OK ? d.n : 0;
 }
 int pcdhip_fft_last_timings(pcdhip_ctx* ctx, float out_ms[8]) {
   if (!ctx || !out_ms) return PCDHIP_E_ARG;
@@ -441,19 +524,15 @@ int upload_csr(pcdhip_ctx* ctx, int slot, const pcdhip_csr* m, const FieldEntry&
   return upload_csr_to(ctx, m, fe, (char*)ctx->aux_ws.buf[slot], out);
 }
 
-// h (n elements, Montgomery) left in aux slot AUX_A; z_dev: m elements on device; mats: A, B, C on device
-int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const uint32_t* z_dev, size_t num_inputs, int* log_n_out) {
+// h (d.n elements, device image) left in aux slot AUX_A; z_dev: m elements on device; mats: A, B, C on device
+int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const uint32_t* z_dev, size_t num_inputs, Dom* dom_out) {
   const FieldEntry& fe = field_entry(field_id);
   if (mats[0].rows != mats[1].rows || mats[0].rows != mats[2].rows) return PCDHIP_E_ARG;
-  const size_t need = (size_t)mats[0].rows + num_inputs;
-  int log_n = 0;
-  while (((size_t)1 << log_n) < need) log_n++;
-  if (log_n > fe.two_adicity) return PCDHIP_E_SIZE_UNSUPPORTED;
-  const uint32_t n = 1u << log_n;
-  const size_t vb = (size_t)n * fe.words * 4;
-  const FftTables* t;
-  int rc = get_tables(ctx, field_id, log_n, &t);
+  Dom d;
+  int rc = pick_domain(field_id, (size_t)mats[0].rows + num_inputs, &d);
   if (rc) return rc;
+  const uint32_t n = d.n;
+  const size_t vb = (size_t)n * fe.words * 4;
   TRY(ctx->aux_ws.ensure(AUX_A, vb));
   TRY(ctx->aux_ws.ensure(AUX_B, vb));
   TRY(ctx->aux_ws.ensure(AUX_C, vb));
@@ -466,12 +545,20 @@ int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const u
     TRY(fe.spmv(st, mats[k].rp, mats[k].col, mats[k].coeff, mats[k].rows, z_dev, (uint32_t)num_inputs, k == 0 ? 1 : 0, n, vecs[k]));
   // 3 x (ifft, coset_fft), pointwise, coset_ifft
   for (uint32_t* v : vecs) {
-    TRY(fe.fft_run(st, *t, v, tmp, log_n, 1, 0, nullptr, nullptr));
-    TRY(fe.fft_run(st, *t, v, tmp, log_n, 0, 1, nullptr, nullptr));
+    rc = domain_transform(ctx, field_id, d, v, tmp, 1, 0, nullptr, nullptr); if (rc) return rc;
+    rc = domain_transform(ctx, field_id, d, v, tmp, 0, 1, nullptr, nullptr); if (rc) return rc;
   }
-  TRY(fe.mul_sub_divz(st, *t, a, b, c, log_n));
-  TRY(fe.fft_run(st, *t, a, tmp, log_n, 1, 1, nullptr, nullptr));
-  *log_n_out = log_n;
+  if (d.m == 1) {
+    const FftTables* t;
+    rc = get_tables(ctx, field_id, d.a, &t); if (rc) return rc;
+    TRY(fe.mul_sub_divz(st, *t, a, b, c, d.a));
+  } else {
+    const FftTables* t;
+    rc = get_mixed_tables(ctx, field_id, d, &t); if (rc) return rc;
+    TRY(fe.mixed_mul_sub_divz(st, *t, a, b, c, n));
+  }
+  rc = domain_transform(ctx, field_id, d, a, tmp, 1, 1, nullptr, nullptr); if (rc) return rc;
+  *dom_out = d;
   return PCDHIP_OK;
 }
 
@@ -493,13 +580,13 @@ int pcdhip_groth16_witness_map(pcdhip_ctx* ctx, int field_id, const pcdhip_csr* 
   TRY(ctx->aux_ws.ensure(AUX_Z_CANON, num_vars * fe.abi_words * 4));
   TRY(hipMemcpyAsync(ctx->aux_ws.buf[AUX_Z_CANON], z, num_vars * fe.abi_words * 4, hipMemcpyHostToDevice, ctx->stream));
   TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_Z_CANON], (uint32_t*)ctx->aux_ws.buf[AUX_Z], (uint32_t)num_vars, 0));
-  int log_n = 0;
+  Dom dom;
   DevCsr mats[3];
   int rc = upload_three(ctx, A, B, C, fe, mats);
   if (rc) return rc;
-  rc = witness_map_dev(ctx, field_id, mats, (const uint32_t*)ctx->aux_ws.buf[AUX_Z], num_inputs, &log_n);
+  rc = witness_map_dev(ctx, field_id, mats, (const uint32_t*)ctx->aux_ws.buf[AUX_Z], num_inputs, &dom);
   if (rc) return rc;
-  const uint32_t n = 1u << log_n;
+  const uint32_t n = dom.n;
   TRY(ctx->aux_ws.ensure(AUX_H_CANON, (size_t)n * fe.abi_words * 4));
   TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_A], (uint32_t*)ctx->aux_ws.buf[AUX_H_CANON], n, 1));
   TRY(hipMemcpyAsync(h_out, ctx->aux_ws.buf[AUX_H_CANON], (size_t)n * fe.abi_words * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -613,7 +700,7 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   TRY(fe.convert(st, z_abi, z_dev, (uint32_t)m, 0));
   TRY(fe.convert(st, z_abi, z_can, (uint32_t)m, 3));
   // K1: h
-  int log_n = 0;
+  Dom dom;
   DevCsr mats[3];
   int rc = PCDHIP_OK;
   if (A && B && C) { TRY(hipStreamSynchronize(st)); rc = upload_three(ctx, A, B, C, fe, mats); }  // (staging slot AUX_SCAL is reused)
@@ -621,9 +708,9 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
     for (int k = 0; k < 3; k++) mats[k] = {pk->rp[k], pk->col[k], pk->coeff[k], pk->rows};
   } else rc = PCDHIP_E_ARG;
   if (rc) return rc;
-  rc = witness_map_dev(ctx, fr, mats, z_dev, ni, &log_n);
+  rc = witness_map_dev(ctx, fr, mats, z_dev, ni, &dom);
   if (rc) return rc;
-  const size_t n = (size_t)1 << log_n;
+  const size_t n = dom.n;
   TRY(ctx->aux_ws.ensure(AUX_H_CANON, n * sb));
   uint32_t* h_can = (uint32_t*)ctx->aux_ws.buf[AUX_H_CANON];
   TRY(fe.convert(st, (const uint32_t*)ctx->aux_ws.buf[AUX_A], h_can, (uint32_t)n, 2));

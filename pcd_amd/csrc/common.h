@@ -107,6 +107,11 @@ struct FieldEntry {
                      const uint32_t* z, uint32_t num_inputs, int append_inputs, uint32_t n, uint32_t* out);
   // a = (a * b - c) / Z(g) on the coset of size 2^log_n
   hipError_t (*mul_sub_divz)(hipStream_t, const FftTables& t, uint32_t* a, const uint32_t* b, const uint32_t* c, int log_n);
+  // mixed-radix domain n = m * 2^a (ark-poly MixedRadixEvaluationDomain): tables, transform, pointwise step
+  hipError_t (*mixed_make_tables)(hipStream_t, uint32_t n, uint32_t m, FftTables* t);
+  hipError_t (*mixed_run)(hipStream_t, const FftTables& t, const FftTables& t2, uint32_t* x, uint32_t* tmp, uint32_t m, int a,
+                          int inverse, int coset);
+  hipError_t (*mixed_mul_sub_divz)(hipStream_t, const FftTables& t, uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t n);
 };
 const FieldEntry& field_entry(int field_id);
 

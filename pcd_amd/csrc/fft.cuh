@@ -111,6 +111,49 @@ __global__ void __launch_bounds__(256) fft_mul_sub_scale(uint32_t* __restrict__ 
   r.store(a + (size_t)i * F::WORDS);
 }
 
+// ---- mixed-radix domains n = m * 2^a, m = q or q^2 (ark-poly MixedRadixEvaluationDomain, K2m of SURVEY.md 8a) ----
+// X[k1 + m k2] = sum_{j2} w_n^{j2 k1} [ sum_{j1} x[N2 j1 + j2] w_m^{j1 k1} ] w_{N2}^{j2 k2},  N2 = 2^a:
+//   step 1 (this kernel): m-point DFTs down the columns + twiddle, y[k1][j2] row-major;
+//   step 2: the m rows go through the radix-2 passes above (root w_n^m);  step 3: interleaving store.
+// One lane per column j2; the m x m inner products re-read the column from L2.
+template <class F>
+__global__ void __launch_bounds__(64) fft_mixed_columns_kernel(const uint32_t* __restrict__ x, uint32_t* __restrict__ y,
+                                                               const uint32_t* __restrict__ tw /* w_n^j, j < N2 */, uint32_t N2, uint32_t m,
+                                                               const F wm, const uint32_t* __restrict__ pre) {
+  constexpr int EW = F::WORDS;
+  uint32_t j2 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j2 >= N2) return;
+  F t = F::load(tw + (size_t)j2 * EW);
+  F twk = F::one(), wk = F::one();
+  for (uint32_t k1 = 0; k1 < m; k1++) {
+    F acc = F::zero(), pw = F::one();
+    for (uint32_t j1 = 0; j1 < m; j1++) {
+      size_t j = (size_t)N2 * j1 + j2;
+      F v = F::load(x + j * EW);
+      if (pre) v = v * F::load(pre + j * EW);
+      acc = acc + (j1 ? v * pw : v);
+      pw = pw * wk;
+    }
+    if (k1) acc = acc * twk;
+    acc.store(y + ((size_t)k1 * N2 + j2) * EW);
+    twk = twk * t;
+    wk = wk * wm;
+  }
+}
+// step 3: out[k1 + m k2] = z[k1][k2] (* post[o]) (* scale)
+template <class F>
+__global__ void __launch_bounds__(256) fft_mixed_interleave_kernel(const uint32_t* __restrict__ z, uint32_t* __restrict__ out, uint32_t N2,
+                                                                   uint32_t m, const uint32_t* __restrict__ post, int use_scale, const F scale_c) {
+  constexpr int EW = F::WORDS;
+  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= N2 * m) return;
+  uint32_t k1 = o % m, k2 = o / m;
+  F v = F::load(z + ((size_t)k1 * N2 + k2) * EW);
+  if (post) v = v * F::load(post + (size_t)o * EW);
+  if (use_scale) v = v * scale_c;
+  v.store(out + (size_t)o * EW);
+}
+
 // C-ABI <-> device image of field-element vectors.  MODE 0: ABI Montgomery -> internal, 1: internal -> ABI
 // Montgomery, 2: internal -> canonical words (`into_repr()`, the scalars handed to the MSM), 3: ABI Montgomery ->
 // canonical words.

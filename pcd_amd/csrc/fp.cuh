@@ -149,8 +149,40 @@ struct Fp {
     r.v[N - 1] = (uint32_t)acc;
     return r;
   }
+  // Montgomery square: the a_i a_j (i < j) products are taken once with a doubled operand (limbs < 2^29, column
+  // sums still < 2^62): N(N+1)/2 + N^2 mads instead of 2 N^2.
+  __host__ __device__ __noinline__ static Fp sqr_(Fp a) {
+    uint32_t m[N], a2[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) a2[i] = a.v[i] << 1;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+      for (int i = 0; 2 * i < k; i++) acc += (uint64_t)a2[i] * a.v[k - i];
+      if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::mod(k - i);
+      m[k] = ((uint32_t)acc * P::INV) & MASK;
+      acc += (uint64_t)m[k] * P::mod(0);
+      acc >>= 28;
+    }
+    Fp r;
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+      for (int i = k - N + 1; 2 * i < k; i++) acc += (uint64_t)a2[i] * a.v[k - i];
+      if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::mod(k - i);
+      r.v[k - N] = (uint32_t)acc & MASK;
+      acc >>= 28;
+    }
+    r.v[N - 1] = (uint32_t)acc;
+    return r;
+  }
   PCD_HD Fp operator*(const Fp& b) const { return mul(*this, b); }
-  PCD_HD Fp sqr() const { return mul(*this, *this); }
+  PCD_HD Fp sqr() const { return sqr_(*this); }
 
   // multiplication by a small non-negative integer (curve / tower constants, k < 2^8)
   PCD_HD Fp mul_small(unsigned k) const {

@@ -42,6 +42,7 @@ __global__ void domain_consts_kernel(int log_n, uint32_t* out /* 6 elements */) 
 }
 
 struct DomainConsts { FT w, winv, g, ginv, ninv, zinv; };
+inline bool rem_check(uint32_t n, uint32_t m) { return m == 0 || n % m != 0 || ((n / m) & (n / m - 1)) != 0; }
 
 hipError_t get_consts(hipStream_t st, int log_n, DomainConsts* c) {
   uint32_t* d = nullptr;
@@ -83,7 +84,9 @@ hipError_t run(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t* tmp, i
   memcpy(&c, t.consts, sizeof c);
   FT scale = FT::one();
   int use_scale = 0;
-  if (inverse && !coset) {  // plain 1/n: constant multiply in the last pass
+  const bool raw = (inverse & 2) != 0;  // inverse root, no 1/n (a row transform inside a mixed-radix domain)
+  inverse &= 1;
+  if (inverse && !coset && !raw) {  // plain 1/n: constant multiply in the last pass
     scale = c.ninv;
     use_scale = 1;
   }
@@ -114,6 +117,84 @@ hipError_t run(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t* tmp, i
   }
   if (npasses) *npasses = P;
   return hipSuccess;
+}
+
+// ---- mixed-radix domain n = m * 2^a
+struct MixedConsts { FT wn, wn_inv, wm, wm_inv, ninv, zinv; };
+__global__ void mixed_consts_kernel(uint32_t n, uint32_t m, uint32_t* out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  typedef typename FT::Params P;
+  // e = (p - 1) / n: p - 1 = (p - 2) + 1 on 32-bit words, then long division
+  constexpr int NW = P::N32;
+  uint32_t pm1[NW], e[NW];
+  uint64_t carry = 1;
+  for (int i = 0; i < NW; i++) { uint64_t x = (uint64_t)P::modm2(i) + carry; pm1[i] = (uint32_t)x; carry = x >> 32; }
+  uint64_t rem = 0;
+  for (int i = NW - 1; i >= 0; i--) { uint64_t cur = (rem << 32) | pm1[i]; e[i] = (uint32_t)(cur / n); rem = cur % n; }
+  FT g = FT::generator(), w = FT::one();
+  bool started = false;
+  for (int i = NW * 32 - 1; i >= 0; i--) {
+    if (started) w = w.sqr();
+    if ((e[i >> 5] >> (i & 31)) & 1) { w = started ? w * g : g; started = true; }
+  }
+  FT wm = w.pow_u64(n / m);
+  FT zinv = (g.pow_u64(n) - FT::one()).inv();
+  w.store(out);
+  w.inv().store(out + EW);
+  wm.store(out + 2 * EW);
+  wm.inv().store(out + 3 * EW);
+  FT::from_u64(n).inv().store(out + 4 * EW);
+  zinv.store(out + 5 * EW);
+}
+hipError_t mixed_make_tables(hipStream_t st, uint32_t n, uint32_t m, FftTables* t) {
+  if (rem_check(n, m)) return hipErrorInvalidValue;
+  uint32_t* d = nullptr;
+  PCD_HIP_TRY(hipMalloc(&d, 6 * EW * 4));
+  hipLaunchKernelGGL(mixed_consts_kernel, dim3(1), dim3(64), 0, st, n, m, d);
+  MixedConsts c;
+  hipError_t e = hipMemcpyAsync(&c, d, 6 * EW * 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d);
+  PCD_HIP_TRY(e);
+  static_assert(sizeof(MixedConsts) <= sizeof(t->consts), "consts buffer too small");
+  memcpy(t->consts, &c, sizeof c);
+  const uint32_t N2 = n / m;
+  PCD_HIP_TRY(hipMalloc(&t->tw_fwd, (size_t)N2 * EW * 4));
+  PCD_HIP_TRY(hipMalloc(&t->tw_inv, (size_t)N2 * EW * 4));
+  PCD_HIP_TRY(hipMalloc(&t->coset, (size_t)n * EW * 4));
+  PCD_HIP_TRY(hipMalloc(&t->coset_inv_scaled, (size_t)n * EW * 4));
+  FT g = FT::generator();
+  DomainConsts dc;  // g^-1 via the radix-2 helper (log_n irrelevant for g)
+  PCD_HIP_TRY(get_consts(st, 1, &dc));
+  dim3 bd(64);
+  hipLaunchKernelGGL(fft_fill_powers<FT>, dim3(((N2 + 255) / 256 + 63) / 64), bd, 0, st, t->tw_fwd, N2, c.wn, FT::one());
+  hipLaunchKernelGGL(fft_fill_powers<FT>, dim3(((N2 + 255) / 256 + 63) / 64), bd, 0, st, t->tw_inv, N2, c.wn_inv, FT::one());
+  hipLaunchKernelGGL(fft_fill_powers<FT>, dim3(((n + 255) / 256 + 63) / 64), bd, 0, st, t->coset, n, g, FT::one());
+  hipLaunchKernelGGL(fft_fill_powers<FT>, dim3(((n + 255) / 256 + 63) / 64), bd, 0, st, t->coset_inv_scaled, n, dc.ginv, c.ninv);
+  PCD_HIP_TRY(hipGetLastError());
+  return hipStreamSynchronize(st);
+}
+// x (n elements) transformed in place; tmp: n elements; t2: radix-2 tables of the 2^a row domain
+hipError_t mixed_run(hipStream_t st, const FftTables& t, const FftTables& t2, uint32_t* x, uint32_t* tmp, uint32_t m, int a,
+                     int inverse, int coset) {
+  MixedConsts c;
+  memcpy(&c, t.consts, sizeof c);
+  const uint32_t N2 = 1u << a, n = N2 * m;
+  const uint32_t* pre = (coset && !inverse) ? t.coset : nullptr;
+  hipLaunchKernelGGL(fft_mixed_columns_kernel<FT>, dim3((N2 + 63) / 64), dim3(64), 0, st, x, tmp, inverse ? t.tw_inv : t.tw_fwd, N2, m,
+                     inverse ? c.wm_inv : c.wm, pre);
+  for (uint32_t k1 = 0; k1 < m; k1++)  // rows through the radix-2 passes; x serves as their ping-pong space
+    PCD_HIP_TRY(run(st, t2, tmp + (size_t)k1 * N2 * EW, x + (size_t)k1 * N2 * EW, a, inverse ? 3 : 0, 0, nullptr, nullptr));
+  const uint32_t* post = (coset && inverse) ? t.coset_inv_scaled : nullptr;
+  const int use_scale = (inverse && !coset) ? 1 : 0;
+  hipLaunchKernelGGL(fft_mixed_interleave_kernel<FT>, dim3((n + 255) / 256), dim3(256), 0, st, tmp, x, N2, m, post, use_scale, c.ninv);
+  return hipGetLastError();
+}
+hipError_t mixed_mul_sub_divz(hipStream_t st, const FftTables& t, uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t n) {
+  MixedConsts mc;
+  memcpy(&mc, t.consts, sizeof mc);
+  hipLaunchKernelGGL(fft_mul_sub_scale<FT>, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, n, mc.zinv);
+  return hipGetLastError();
 }
 
 hipError_t convert(hipStream_t st, const uint32_t* in, uint32_t* out, uint32_t n, int mode) {
@@ -163,7 +244,8 @@ hipError_t mul_sub_divz(hipStream_t st, const FftTables& t, uint32_t* a, const u
 #define PCD_CAT_(a, b) a##b
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const FieldEntry* PCD_CAT(pcd_field_entry_, PCD_FIELD_IDX)() {
-  static const FieldEntry e = {EW, FT::ABI_WORDS, FT::Params::TWO_ADICITY, make_tables, run, convert, spmv, mul_sub_divz};
+  static const FieldEntry e = {EW, FT::ABI_WORDS, FT::Params::TWO_ADICITY, make_tables, run, convert, spmv, mul_sub_divz,
+                               mixed_make_tables, mixed_run, mixed_mul_sub_divz};
   return &e;
 }
 

@@ -29,6 +29,31 @@ def test_fft_vs_oracle(co, gpu_ctx, fid, logs):
                 assert np.array_equal(gpu_ctx.fft(fid, x, inverse=inv, coset=coset), want), (fid, log_n, inv, coset)
 
 
+@pytest.mark.parametrize("fid,q", [(0, 7), (2, 5)])
+def test_mixed_radix_fft(co, gpu_ctx, fid, q):
+    """K2m: MixedRadixEvaluationDomain transforms (the help-proof domains beyond 2^17 / 2^15) vs the oracle."""
+    for m, a in ((q, 3), (q * q, 2), (q, 11), (q * q, 10), (q, 13)):
+        n = m << a
+        x = co.gen_field(fid, n, seed=n)
+        for inv in (False, True):
+            for coset in (False, True):
+                want = co.fft_general(fid, x, m, inverse=inv, coset=coset, nthreads=16)
+                assert np.array_equal(gpu_ctx.fft_general(fid, x, inverse=inv, coset=coset), want), (fid, m, a, inv, coset)
+    from pcd_amd import capi
+    with pytest.raises(capi.PcdHipError):
+        gpu_ctx.fft_general(fid, np.zeros((3 * 64, x.shape[1]), dtype=np.uint64))  # 3 * 2^6 is not a domain size
+
+
+@pytest.mark.parametrize("cid,nc", [(1, (1 << 17) + 1000), (3, (1 << 15) + 500)])
+def test_witness_map_mixed_radix_domain(co, gpu_ctx, cid, nc):
+    """help-proof witness map on a domain beyond the help field's 2-adicity (7 * 2^15 / 5 * 2^13 elements)."""
+    fr = co.CURVE_FR[cid]
+    r = co.synthetic_r1cs(fr, nc, 2, seed=nc)
+    want = co.witness_map(r, nthreads=32)
+    got = gpu_ctx.witness_map(fr, r)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
 def test_fft_size_limits(gpu_ctx):
     from pcd_amd import capi
     with pytest.raises(capi.PcdHipError):  # 2-adicity of F298A is 17: needs the mixed-radix domain

@@ -53,3 +53,21 @@ def test_group_order_and_pairing_bilinearity(co, cid):
                                                co.fp_op(fr, "from_canonical", k[1:2])))[0]
     ab_g1, _ = co.to_affine(cid, 1, co.scalar_mul(cid, 1, g1, ab))
     assert np.array_equal(co.pairing(cid, a_g1[0], b_g2[0]), co.pairing(cid, ab_g1[0], g2))
+
+
+@pytest.mark.parametrize("fid,q", [(0, 7), (2, 5)])
+def test_mixed_radix_domain_vs_bigint(co, fid, q):
+    """ark-poly MixedRadixEvaluationDomain (sizes 2^a q^b): C++ restatement == naive big-integer DFT."""
+    import random
+    from oracle import pyoracle as O
+    f = O.FIELDS[fid]
+    rnd = random.Random(fid)
+    for m, a in ((q, 3), (q * q, 2), (q, 0)):
+        xs = [rnd.randrange(f.p) for _ in range(m << a)]
+        X = O.pack_fp(f, xs)
+        for inv in (False, True):
+            for coset in (False, True):
+                want = O.dft_general(f, xs, inverse=inv, coset=coset)
+                assert O.unpack_fp(f, co.fft_general(fid, X, m, inverse=inv, coset=coset, nthreads=2)) == want
+    assert co.domain_size(fid, (1 << f.two_adicity) + 1) == O.best_mixed_domain_size(f, (1 << f.two_adicity) + 1, q)
+    assert co.domain_size(fid, 1000) == 1024
