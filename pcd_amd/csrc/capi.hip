@@ -203,6 +203,13 @@ void pcdhip_destroy(pcdhip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   ctx->msm_ws.release();
   ctx->aux_ws.release();
+  for (int k = 0; k < 5; k++) {
+    ctx->g16_ws[k].release();
+    if (ctx->g16_streams[k]) (void)hipStreamDestroy(ctx->g16_streams[k]);
+    if (ctx->g16_begin[k]) (void)hipEventDestroy(ctx->g16_begin[k]);
+    if (ctx->g16_end[k]) (void)hipEventDestroy(ctx->g16_end[k]);
+  }
+  if (ctx->g16_ready) (void)hipEventDestroy(ctx->g16_ready);
   for (auto& kv : ctx->fft_tables) {
     (void)hipFree(kv.second.tw_fwd); (void)hipFree(kv.second.tw_inv);
     (void)hipFree(kv.second.coset); (void)hipFree(kv.second.coset_inv_scaled);
@@ -332,7 +339,7 @@ void pcdhip_bases_free(pcdhip_ctx* ctx, pcdhip_bases* bases) {
   delete bases;
 }
 int pcdhip_msm_config(pcdhip_ctx* ctx, int window_bits, int chunk) {
-  if (!ctx || window_bits < 0 || window_bits > 20 || chunk < 0) return PCDHIP_E_ARG;
+  if (!ctx || window_bits < 0 || window_bits > 24 || chunk < 0) return PCDHIP_E_ARG;
   ctx->msm_c = window_bits;
   ctx->msm_chunk = (uint32_t)chunk;
   return PCDHIP_OK;
@@ -610,20 +617,24 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
   int rc = 0;
   // delta is appended to the a / b / l queries: r*delta, s*delta and -rs*delta then ride inside the MSMs as
   // one more (base, scalar) pair instead of being serial scalar multiplications in the assembly.
-  auto upload_plus = [&](int group, const uint64_t* q, const uint8_t* inf, size_t n, const uint64_t* extra, pcdhip_bases** out) -> int {
+  // Every a / b / l query gets three trailing slots matching the scalar tail [r, s, -rs] that follows the
+  // assignment: delta sits in the slot whose scalar the query needs, the other two slots hold the point at infinity.
+  auto upload_plus = [&](int group, const uint64_t* q, const uint8_t* inf, size_t n, const uint64_t* extra, int slot_idx,
+                         pcdhip_bases** out) -> int {
     const size_t pl = (size_t)pcdhip_point_limbs(cid, group);
-    std::vector<uint64_t> tmp((n + 1) * pl);
-    std::vector<uint8_t> tinf(n + 1, 0);
+    std::vector<uint64_t> tmp((n + 3) * pl, 0);
+    std::vector<uint8_t> tinf(n + 3, 1);
     if (n) memcpy(tmp.data(), q, n * pl * 8);
-    memcpy(tmp.data() + n * pl, extra, pl * 8);
-    if (inf) memcpy(tinf.data(), inf, n);
-    return pcdhip_bases_upload(ctx, cid, group, tmp.data(), tinf.data(), n + 1, out);
+    for (size_t i = 0; i < n; i++) tinf[i] = inf ? inf[i] : 0;
+    memcpy(tmp.data() + (n + slot_idx) * pl, extra, pl * 8);
+    tinf[n + slot_idx] = 0;
+    return pcdhip_bases_upload(ctx, cid, group, tmp.data(), tinf.data(), n + 3, out);
   };
-  rc = rc ? rc : upload_plus(1, h->a_query, h->a_inf, h->num_vars, h->delta_g1, &pk->a_query);
-  rc = rc ? rc : upload_plus(1, h->b_g1_query, h->b_g1_inf, h->num_vars, h->delta_g1, &pk->b_g1_query);
-  rc = rc ? rc : upload_plus(2, h->b_g2_query, h->b_g2_inf, h->num_vars, h->delta_g2, &pk->b_g2_query);
+  rc = rc ? rc : upload_plus(1, h->a_query, h->a_inf, h->num_vars, h->delta_g1, 0, &pk->a_query);       // r * delta
+  rc = rc ? rc : upload_plus(1, h->b_g1_query, h->b_g1_inf, h->num_vars, h->delta_g1, 1, &pk->b_g1_query);  // s * delta
+  rc = rc ? rc : upload_plus(2, h->b_g2_query, h->b_g2_inf, h->num_vars, h->delta_g2, 1, &pk->b_g2_query);
   rc = rc ? rc : pcdhip_bases_upload(ctx, cid, 1, h->h_query, h->h_inf, h->h_len, &pk->h_query);
-  rc = rc ? rc : upload_plus(1, h->l_query, h->l_inf, h->l_len, h->delta_g1, &pk->l_query);
+  rc = rc ? rc : upload_plus(1, h->l_query, h->l_inf, h->l_len, h->delta_g1, 2, &pk->l_query);           // -rs * delta
   if (!rc) {
     const size_t w1 = (size_t)pcdhip_point_limbs(cid, 1) * 8, w2 = (size_t)pcdhip_point_limbs(cid, 2) * 8;
     const CurveEntry& ce = curve_entry(cid);
@@ -692,7 +703,7 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   // z (C-ABI Montgomery) -> device image for the SpMV, and canonical words for the MSMs
   TRY(ctx->aux_ws.ensure(AUX_Z, m * fe.words * 4));
   TRY(ctx->aux_ws.ensure(AUX_SCAL, m * sb));
-  TRY(ctx->aux_ws.ensure(AUX_Z_CANON, (m + 4) * sb));  // + one slot after z for the delta scalar, + [r, s, -rs]
+  TRY(ctx->aux_ws.ensure(AUX_Z_CANON, (m + 4) * sb));  // assignment followed by the delta scalars [r, s, -rs]
   uint32_t* z_dev = (uint32_t*)ctx->aux_ws.buf[AUX_Z];
   uint32_t* z_abi = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
   uint32_t* z_can = (uint32_t*)ctx->aux_ws.buf[AUX_Z_CANON];
@@ -730,22 +741,34 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   TRY(hipMemcpyAsync(rs_dev, r_mont, sb, hipMemcpyHostToDevice, st));
   TRY(hipMemcpyAsync((char*)rs_dev + sb, s_mont, sb, hipMemcpyHostToDevice, st));
   const size_t hl = std::min<size_t>(pk->h_query->n, n);
-  MsmTimings* tm = nullptr;
-  uint32_t* slot = z_can + m * sw;      // scalar of the appended delta point
-  uint32_t* extra = slot + sw;          // canonical [r, s, -rs]
+  uint32_t* extra = z_can + m * sw;  // canonical [r, s, -rs] right after the assignment: the scalars of the delta slots
   TRY(ce.prepare_scalars(st, rs_dev, extra));
-  TRY(g1.msm(ctx->msm_ws, st, pk->h_query->view(0), h_can, (uint32_t)hl, msm_g1, ctx->msm_c, ctx->msm_chunk, tm));
-  TRY(hipEventRecord(ev[2], st));
-  TRY(hipMemcpyAsync(slot, extra + 2 * sw, sb, hipMemcpyDeviceToDevice, st));  // -rs
-  TRY(g1.msm(ctx->msm_ws, st, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni + 1), (uint32_t*)((char*)msm_g1 + j1), ctx->msm_c, ctx->msm_chunk, tm));
-  TRY(hipEventRecord(ev[3], st));
-  TRY(hipMemcpyAsync(slot, extra, sb, hipMemcpyDeviceToDevice, st));  // r
-  TRY(g1.msm(ctx->msm_ws, st, pk->a_query->view(1), z_can + sw, (uint32_t)m, (uint32_t*)((char*)msm_g1 + 2 * j1), ctx->msm_c, ctx->msm_chunk, tm));
-  TRY(hipEventRecord(ev[4], st));
-  TRY(hipMemcpyAsync(slot, extra + sw, sb, hipMemcpyDeviceToDevice, st));  // s
-  TRY(g1.msm(ctx->msm_ws, st, pk->b_g1_query->view(1), z_can + sw, (uint32_t)m, (uint32_t*)((char*)msm_g1 + 3 * j1), ctx->msm_c, ctx->msm_chunk, tm));
-  TRY(hipEventRecord(ev[5], st));
-  TRY(g2.msm(ctx->msm_ws, st, pk->b_g2_query->view(1), z_can + sw, (uint32_t)m, msm_g2, ctx->msm_c, ctx->msm_chunk, tm));
+  // five concurrent MSMs
+  if (!ctx->g16_ready) {
+    TRY(hipEventCreateWithFlags(&ctx->g16_ready, hipEventDisableTiming));
+    for (int k = 0; k < 5; k++) {
+      TRY(hipStreamCreateWithFlags(&ctx->g16_streams[k], hipStreamNonBlocking));
+      TRY(hipEventCreate(&ctx->g16_begin[k]));
+      TRY(hipEventCreate(&ctx->g16_end[k]));
+    }
+  }
+  TRY(hipEventRecord(ctx->g16_ready, st));
+  struct Job { const GroupEntry* ge; MsmBasesView bv; const uint32_t* sc; uint32_t n; uint32_t* out; };
+  const Job jobs[5] = {
+      {&g2, pk->b_g2_query->view(1), z_can + sw, (uint32_t)(m + 2), msm_g2},                       // heaviest first
+      {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, msm_g1},
+      {&g1, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni + 3), (uint32_t*)((char*)msm_g1 + j1)},
+      {&g1, pk->a_query->view(1), z_can + sw, (uint32_t)(m + 2), (uint32_t*)((char*)msm_g1 + 2 * j1)},
+      {&g1, pk->b_g1_query->view(1), z_can + sw, (uint32_t)(m + 2), (uint32_t*)((char*)msm_g1 + 3 * j1)},
+  };
+  for (int k = 0; k < 5; k++) {
+    hipStream_t sk = ctx->g16_streams[k];
+    TRY(hipStreamWaitEvent(sk, ctx->g16_ready, 0));
+    TRY(hipEventRecord(ctx->g16_begin[k], sk));
+    TRY(jobs[k].ge->msm(ctx->g16_ws[k], sk, jobs[k].bv, jobs[k].sc, jobs[k].n, jobs[k].out, ctx->msm_c, ctx->msm_chunk, nullptr));
+    TRY(hipEventRecord(ctx->g16_end[k], sk));
+    TRY(hipStreamWaitEvent(st, ctx->g16_end[k], 0));
+  }
   TRY(hipEventRecord(ev[6], st));
   // K5: assembly (writes the proof in the C-ABI image)
   TRY(ce.assemble(st, msm_g1, msm_g2, pk->singles, rs_dev, scratch, proof_dev));
@@ -761,7 +784,11 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
       inf_out[i] = (o == 0) ? 1 : 0;
     }
   }
-  for (int i = 0; i < 7; i++) (void)hipEventElapsedTime(&ctx->g16_ms[i], ev[i], ev[i + 1]);
+  // [witness_map, msm_h, msm_l, msm_a, msm_b_g1, msm_b_g2 (each on its own stream: they overlap), assembly, total]
+  (void)hipEventElapsedTime(&ctx->g16_ms[0], ev[0], ev[1]);
+  const int order[5] = {5, 1, 2, 3, 4};  // job k -> timing slot
+  for (int k = 0; k < 5; k++) (void)hipEventElapsedTime(&ctx->g16_ms[order[k]], ctx->g16_begin[k], ctx->g16_end[k]);
+  (void)hipEventElapsedTime(&ctx->g16_ms[6], ev[6], ev[7]);
   (void)hipEventElapsedTime(&ctx->g16_ms[7], ev[0], ev[7]);
   for (auto& e : ev) (void)hipEventDestroy(e);
   return PCDHIP_OK;

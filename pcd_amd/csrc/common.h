@@ -54,6 +54,11 @@ struct pcdhip_ctx {
   hipStream_t stream;
   pcd::MsmWorkspace msm_ws;
   pcd::MsmWorkspace aux_ws;  // fft ping-pong, witness-map vectors, groth16 scratch
+  // the five MSMs of a Groth16 proof run concurrently, each on its own stream with its own workspace: the
+  // latency-bound bucket-reduction tail of one overlaps the throughput-bound accumulation of the others
+  hipStream_t g16_streams[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  pcd::MsmWorkspace g16_ws[5];
+  hipEvent_t g16_ready = nullptr, g16_begin[5] = {nullptr}, g16_end[5] = {nullptr};
   std::map<uint64_t, pcd::FftTables> fft_tables;
   int msm_c = 0;
   uint32_t msm_chunk = 0;

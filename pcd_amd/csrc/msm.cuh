@@ -41,10 +41,14 @@ struct MsmPlan {
 inline int msm_pick_window(size_t n, int scalar_bits, int full_precompute) {
   double best = 1e300;
   int bc = 8;
-  for (int c = 6; c <= 18; c++) {
+  for (int c = 6; c <= 22; c++) {
     int W = (scalar_bits + c - 1) / c;
     int Wg = full_precompute ? 1 : W;
     double cost = (double)W * (double)n * 11.0 + (double)Wg * (double)(2u << c) * 16.0 * 1.3;
+    // a short top window concentrates n entries on 2^top buckets: their histogram / scatter atomics serialise
+    // (measured: ~35 ns per entry per hot bucket, i.e. ~1400 modmul-times)
+    int top = scalar_bits - (W - 1) * c;
+    cost += (double)n / (double)(1u << (top > 20 ? 20 : top)) * 1400.0;
     if (cost < best) { best = cost; bc = c; }
   }
   return bc;
@@ -155,12 +159,13 @@ PCD_DEV uint32_t msm_find_key(const uint32_t* __restrict__ off, uint32_t nkeys, 
 
 template <class G>
 __global__ void __launch_bounds__(64) msm_accumulate_kernel(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted_idx,
-                                                            const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t M,
+                                                            const uint32_t* __restrict__ off, uint32_t nkeys,
                                                             uint32_t chunk, uint32_t* __restrict__ buckets,
                                                             uint32_t* __restrict__ piece_first, uint32_t* __restrict__ piece_last) {
   typedef typename G::F F;
   typedef EC<G> E;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t M = off[nkeys];  // total sorted entries: read on the device, the host never waits for it
   uint64_t start64 = (uint64_t)t * chunk;
   if (start64 >= M) return;
   uint32_t start = (uint32_t)start64, end = (uint32_t)min((uint64_t)M, start64 + chunk);
@@ -214,31 +219,36 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
   acc.store(buckets + (size_t)key * Jac<F>::WORDS);
 }
 
-// One wave per big bucket: strided serial sums, then a 6-level tree through global scratch.
+// One wave per big bucket (grid-stride over the device-side list): strided serial sums, then a 6-level tree
+// through global scratch.
 template <class G>
-__global__ void __launch_bounds__(64) msm_big_bucket_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ piece_first,
-                                                            const uint32_t* __restrict__ piece_last, uint32_t* __restrict__ buckets,
-                                                            uint32_t* __restrict__ scratch /* gridDim.x * 64 points */) {
+__global__ void __launch_bounds__(64) msm_big_bucket_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count,
+                                                            const uint32_t* __restrict__ piece_first, const uint32_t* __restrict__ piece_last,
+                                                            uint32_t* __restrict__ buckets, uint32_t* __restrict__ scratch /* gridDim.x * 64 points */) {
   typedef typename G::F F;
   typedef EC<G> E;
-  uint32_t key = big_list[3 * blockIdx.x], t0 = big_list[3 * blockIdx.x + 1], t1 = big_list[3 * blockIdx.x + 2];
+  const uint32_t nbig = *big_count;
   uint32_t* my = scratch + (size_t)blockIdx.x * 64 * Jac<F>::WORDS;
-  Jac<F> acc = Jac<F>::infinity();
-  for (uint32_t u = t0 + threadIdx.x; u <= t1; u += 64) {
-    const uint32_t* src = (u == t1) ? piece_first : piece_last;
-    acc = E::add(acc, Jac<F>::load(src + (size_t)u * Jac<F>::WORDS));
-  }
-  acc.store(my + (size_t)threadIdx.x * Jac<F>::WORDS);
-  __syncthreads();
-  for (int s = 32; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-      Jac<F> o = Jac<F>::load(my + (size_t)(threadIdx.x + s) * Jac<F>::WORDS);
-      acc = E::add(acc, o);
-      acc.store(my + (size_t)threadIdx.x * Jac<F>::WORDS);
+  for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+    uint32_t key = big_list[3 * b], t0 = big_list[3 * b + 1], t1 = big_list[3 * b + 2];
+    Jac<F> acc = Jac<F>::infinity();
+    for (uint32_t u = t0 + threadIdx.x; u <= t1; u += 64) {
+      const uint32_t* src = (u == t1) ? piece_first : piece_last;
+      acc = E::add(acc, Jac<F>::load(src + (size_t)u * Jac<F>::WORDS));
     }
+    acc.store(my + (size_t)threadIdx.x * Jac<F>::WORDS);
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) {
+        Jac<F> o = Jac<F>::load(my + (size_t)(threadIdx.x + s) * Jac<F>::WORDS);
+        acc = E::add(acc, o);
+        acc.store(my + (size_t)threadIdx.x * Jac<F>::WORDS);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) acc.store(buckets + (size_t)key * Jac<F>::WORDS);
     __syncthreads();
   }
-  if (threadIdx.x == 0) acc.store(buckets + (size_t)key * Jac<F>::WORDS);
 }
 
 // ------------------------------------------------------------------------------------------------ tail: sum_d d * B_d
@@ -421,25 +431,18 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   // 2. scan
   hipLaunchKernelGGL(scan_block_sums, dim3(scan_blocks), dim3(1024), 0, st, cnt, pl.nkeys, scan_per_block, bsum);
   hipLaunchKernelGGL(scan_apply, dim3(scan_blocks), dim3(1024), 0, st, cnt, pl.nkeys, scan_per_block, bsum, scan_blocks, off);
-  uint32_t M = 0;
-  PCD_HIP_TRY(hipMemcpyAsync(&M, off + pl.nkeys, 4, hipMemcpyDeviceToHost, st));
-  PCD_HIP_TRY(hipStreamSynchronize(st));  // M sizes the accumulate grid
   PCD_HIP_TRY(mark(2));
-  if (M == 0) {
-    Jac<F> inf = Jac<F>::infinity();
-    PCD_HIP_TRY(hipMemcpyAsync(out_dev, &inf, PB, hipMemcpyHostToDevice, st));
-    if (tm) { for (auto& e : ev) (void)hipEventDestroy(e); }
-    return hipStreamSynchronize(st);
-  }
   // 3. scatter (cursor = cnt reset to zero)
   PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)pl.nkeys * 4, st));
   hipLaunchKernelGGL((msm_digits_kernel<NS, true>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, cnt, off, sorted);
   PCD_HIP_TRY(mark(3));
-  // 4. accumulate
-  const uint32_t nchunks = (uint32_t)(((uint64_t)M + pl.chunk - 1) / pl.chunk);
+  // 4. accumulate.  Nothing below waits for the host: grids are sized for the largest possible list (n W entries;
+  //    the actual count M = off[nkeys] is read on the device) so the whole MSM is one asynchronous chain of launches.
+  const uint32_t nchunks = (uint32_t)((maxM + pl.chunk - 1) / pl.chunk);
   PCD_HIP_TRY(ws.ensure(WS_PFIRST, (size_t)nchunks * PB));
   PCD_HIP_TRY(ws.ensure(WS_PLAST, (size_t)nchunks * PB));
-  const uint32_t big_cap = 1u << 16;
+  const uint32_t big_limit = 8;
+  const uint32_t big_cap = nchunks / big_limit + 2;  // a big bucket spans more than big_limit chunks
   PCD_HIP_TRY(ws.ensure(WS_BIG, (size_t)(3 * big_cap + 4) * 4));
   uint32_t* pfirst = (uint32_t*)ws.buf[WS_PFIRST];
   uint32_t* plast = (uint32_t*)ws.buf[WS_PLAST];
@@ -447,20 +450,17 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   uint32_t* big_count = big + 3 * big_cap;
   PCD_HIP_TRY(hipMemsetAsync(buckets, 0, (size_t)pl.nkeys * PB, st));  // Z = 0: identity
   PCD_HIP_TRY(hipMemsetAsync(big_count, 0, 4, st));
-  hipLaunchKernelGGL((msm_accumulate_kernel<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, bases_dev, sorted, off, pl.nkeys, M, pl.chunk,
-                     buckets, pfirst, plast);
+  hipLaunchKernelGGL((msm_accumulate_kernel<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, bases_dev, sorted, off, pl.nkeys, pl.chunk, buckets,
+                     pfirst, plast);
   PCD_HIP_TRY(mark(4));
   // 5. pieces
-  const uint32_t big_limit = 8;
   hipLaunchKernelGGL((msm_fixup_kernel<G>), dim3((pl.nkeys + 63) / 64), dim3(64), 0, st, off, pl.nkeys, pl.chunk, pfirst, plast, buckets,
                      big_limit, big_count, big, big_cap);
-  uint32_t nbig = 0;
-  PCD_HIP_TRY(hipMemcpyAsync(&nbig, big_count, 4, hipMemcpyDeviceToHost, st));
-  PCD_HIP_TRY(hipStreamSynchronize(st));
-  if (nbig > big_cap) return hipErrorOutOfMemory;
-  if (nbig) {
-    PCD_HIP_TRY(ws.ensure(WS_BIGSCR, (size_t)nbig * 64 * PB));
-    hipLaunchKernelGGL((msm_big_bucket_kernel<G>), dim3(nbig), dim3(64), 0, st, big, pfirst, plast, buckets, (uint32_t*)ws.buf[WS_BIGSCR]);
+  {
+    const uint32_t big_grid = std::min<uint32_t>(big_cap, 2048);
+    PCD_HIP_TRY(ws.ensure(WS_BIGSCR, (size_t)big_grid * 64 * PB));
+    hipLaunchKernelGGL((msm_big_bucket_kernel<G>), dim3(big_grid), dim3(64), 0, st, big, big_count, pfirst, plast, buckets,
+                       (uint32_t*)ws.buf[WS_BIGSCR]);
   }
   PCD_HIP_TRY(mark(5));
   // 6. tail levels
