@@ -55,8 +55,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE == {args.gpus} (launch with torch.distributed.run)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PCD_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank dry run of the RCCL path
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     # ---- synthetic inputs (oracle helpers are test infrastructure: used here only to MAKE inputs and, below,
@@ -75,14 +79,14 @@ def main():
     ctx.msm_profile(True)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.sync()
 
     def step():
         part = ctx.msm(bases, sbuf)
-        if world > 1:
+        if use_dist:
             from pcd_amd.dist import all_gather_points
             part = ctx.points_sum(CURVE, GROUP, all_gather_points(part, device))
         return part
@@ -99,7 +103,7 @@ def main():
         tot_ms.append(tm["total"])
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -162,7 +166,7 @@ def main():
         if step_info:
             out["pcd_step"] = step_info
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
