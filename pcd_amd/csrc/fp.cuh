@@ -184,6 +184,57 @@ struct Fp {
   PCD_HD Fp operator*(const Fp& b) const { return mul(*this, b); }
   PCD_HD Fp sqr() const { return sqr_(*this); }
 
+  // Fused sums of products (a0 b0 + a1 b1 [+ a2 b2]) / R' with ONE Montgomery reduction: the building block of the
+  // Fq2 / Fq3 products (schoolbook with lazy reduction: no Karatsuba additions, one reduction per output coefficient).
+  // Column sums stay below (TERMS + 1) N 2^56 < 2^63.  TERMS = 3 can reach 2.5p for the 753-bit fields (R'/p < 16),
+  // so it ends with one normalising pass.
+  // (operands by reference: the callers hold them in memory anyway, and large by-value argument lists
+  // miscompiled for the 753-bit fields on gfx950 / ROCm 7.2)
+  template <int TERMS>
+  __host__ __device__ __noinline__ static void dot(Fp& out, const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, const Fp& a2,
+                                                   const Fp& b2) {
+    uint32_t m[N];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        acc += (uint64_t)a0.v[i] * b0.v[k - i];
+        acc += (uint64_t)a1.v[i] * b1.v[k - i];
+        if (TERMS == 3) acc += (uint64_t)a2.v[i] * b2.v[k - i];
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::mod(k - i);
+      m[k] = ((uint32_t)acc * P::INV) & MASK;
+      acc += (uint64_t)m[k] * P::mod(0);
+      acc >>= 28;
+    }
+    int32_t r[N];
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) {
+        acc += (uint64_t)a0.v[i] * b0.v[k - i];
+        acc += (uint64_t)a1.v[i] * b1.v[k - i];
+        if (TERMS == 3) acc += (uint64_t)a2.v[i] * b2.v[k - i];
+      }
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::mod(k - i);
+      r[k - N] = (int32_t)((uint32_t)acc & MASK);
+      acc >>= 28;
+    }
+    r[N - 1] = (int32_t)(uint32_t)acc;
+    if (TERMS == 3) { out = norm_reduce<false>(r); return; }  // value < 4p -> [0, 2p)
+#pragma unroll
+    for (int i = 0; i < N; i++) out.v[i] = (uint32_t)r[i];  // TERMS == 2: < 2p already (8 p^2 / R' + p)
+  }
+  PCD_HD static Fp dot2(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1) { Fp o; dot<2>(o, a0, b0, a1, b1, a0, a0); return o; }
+  PCD_HD static Fp dot3(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, const Fp& a2, const Fp& b2) {
+    Fp o;
+    dot<3>(o, a0, b0, a1, b1, a2, b2);
+    return o;
+  }
+
   // multiplication by a small non-negative integer (curve / tower constants, k < 2^8)
   PCD_HD Fp mul_small(unsigned k) const {
     if (k == 0) return zero();
@@ -311,17 +362,20 @@ struct Fp2 {
   PCD_HD Fp2 dbl() const { return {c0.dbl(), c1.dbl()}; }
   // (not inlined, like Fp::mul: bounds the code size of the G2 point kernels; operands by reference --
   // large by-value aggregates passed on the stack miscompiled for Fp3 on gfx950 / ROCm 7.2)
+  // schoolbook with lazy reduction: (a0 b0 + nr a1 b1) + (a0 b1 + a1 b0) u, one Montgomery reduction per coefficient
   __host__ __device__ __noinline__ static void mul(Fp2& o, const Fp2& a, const Fp2& b) {
-    F v0 = a.c0 * b.c0, v1 = a.c1 * b.c1;
-    F s = (a.c0 + a.c1) * (b.c0 + b.c1);
-    o.c0 = v0 + v1.mul_small(NR);
-    o.c1 = s - v0 - v1;
+    F na1 = a.c1.mul_small(NR);
+    F r0 = F::dot2(a.c0, b.c0, na1, b.c1);
+    F r1 = F::dot2(a.c0, b.c1, a.c1, b.c0);
+    o.c0 = r0;
+    o.c1 = r1;
   }
-  __host__ __device__ __noinline__ static void sqr_(Fp2& o, const Fp2& a) {  // complex squaring: 2 base multiplications
-    F ab = a.c0 * a.c1;
-    F t = (a.c0 + a.c1) * (a.c0 + a.c1.mul_small(NR));
-    o.c0 = t - ab - ab.mul_small(NR);
-    o.c1 = ab.dbl();
+  __host__ __device__ __noinline__ static void sqr_(Fp2& o, const Fp2& a) {
+    F na1 = a.c1.mul_small(NR);
+    F r0 = F::dot2(a.c0, a.c0, na1, a.c1);
+    F r1 = (a.c0 * a.c1).dbl();
+    o.c0 = r0;
+    o.c1 = r1;
   }
   PCD_HD Fp2 operator*(const Fp2& b) const { Fp2 o; mul(o, *this, b); return o; }
   PCD_HD Fp2 sqr() const { Fp2 o; sqr_(o, *this); return o; }
@@ -356,26 +410,26 @@ struct Fp3 {
   PCD_HD Fp3 operator-(const Fp3& b) const { return {c0 - b.c0, c1 - b.c1, c2 - b.c2}; }
   PCD_HD Fp3 neg() const { return {c0.neg(), c1.neg(), c2.neg()}; }
   PCD_HD Fp3 dbl() const { return {c0.dbl(), c1.dbl(), c2.dbl()}; }
+  // schoolbook with lazy reduction, one Montgomery reduction per coefficient:
+  //   c0 = a0 b0 + nr (a1 b2 + a2 b1),  c1 = a0 b1 + a1 b0 + nr a2 b2,  c2 = a0 b2 + a1 b1 + a2 b0
   __host__ __device__ __noinline__ static void mul(Fp3& o, const Fp3& a, const Fp3& b) {
-    F ad = a.c0 * b.c0, be = a.c1 * b.c1, cf = a.c2 * b.c2;
-    F x = (a.c1 + a.c2) * (b.c1 + b.c2) - be - cf;
-    F y = (a.c0 + a.c1) * (b.c0 + b.c1) - ad - be;
-    F z = (a.c0 + a.c2) * (b.c0 + b.c2) - ad + be - cf;
-    o.c0 = ad + x.mul_small(NR);
-    o.c1 = y + cf.mul_small(NR);
-    o.c2 = z;
+    F na1 = a.c1.mul_small(NR), na2 = a.c2.mul_small(NR);
+    F r0 = F::dot3(a.c0, b.c0, na1, b.c2, na2, b.c1);
+    F r1 = F::dot3(a.c0, b.c1, a.c1, b.c0, na2, b.c2);
+    F r2 = F::dot3(a.c0, b.c2, a.c1, b.c1, a.c2, b.c0);
+    o.c0 = r0;
+    o.c1 = r1;
+    o.c2 = r2;
   }
-  __host__ __device__ __noinline__ static void sqr_(Fp3& o, const Fp3& a) {  // CH-SQR2: 2 mul + 3 sqr in the base field
-    F s0 = a.c0.sqr();
-    F ab = a.c0 * a.c1;
-    F s1 = ab.dbl();
-    F s2 = (a.c0 - a.c1 + a.c2).sqr();
-    F bc = a.c1 * a.c2;
-    F s3 = bc.dbl();
-    F s4 = a.c2.sqr();
-    o.c0 = s0 + s3.mul_small(NR);
-    o.c1 = s1 + s4.mul_small(NR);
-    o.c2 = s1 + s2 + s3 - s0 - s4;
+  //   c0 = a0^2 + 2 nr a1 a2,  c1 = 2 a0 a1 + nr a2^2,  c2 = a1^2 + 2 a0 a2
+  __host__ __device__ __noinline__ static void sqr_(Fp3& o, const Fp3& a) {
+    F d0 = a.c0.dbl(), na2 = a.c2.mul_small(NR), dna1 = a.c1.mul_small(2 * NR);
+    F r0 = F::dot2(a.c0, a.c0, dna1, a.c2);
+    F r1 = F::dot2(d0, a.c1, na2, a.c2);
+    F r2 = F::dot2(a.c1, a.c1, d0, a.c2);
+    o.c0 = r0;
+    o.c1 = r1;
+    o.c2 = r2;
   }
   PCD_HD Fp3 operator*(const Fp3& b) const { Fp3 o; mul(o, *this, b); return o; }
   PCD_HD Fp3 sqr() const { Fp3 o; sqr_(o, *this); return o; }
