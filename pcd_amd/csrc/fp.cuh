@@ -60,6 +60,8 @@ struct Fp {
   static constexpr int WORDS = N;           // u32 words per element in device memory
   static constexpr int ABI_WORDS = P::N32;  // u32 words per element at the C-ABI
   static constexpr uint32_t MASK = 0x0FFFFFFFu;
+  // 298-bit fields: the product (242 mads) is inlined into its callers; 753-bit: one non-inlined copy (1458 mads)
+  static constexpr bool INLINE_ARITH = (N <= 11);
   uint32_t v[N];
 
   PCD_HD static Fp zero() { Fp r; for (int i = 0; i < N; i++) r.v[i] = 0; return r; }
@@ -123,7 +125,11 @@ struct Fp {
 
   // Montgomery product (product scanning, reduction interleaved): inputs and output in [0, 2p).
   // NOT inlined: one fully unrolled copy per field per code object (2 N^2 v_mad_u64_u32 + ~6 N others).
-  __host__ __device__ __noinline__ static Fp mul(Fp a, Fp b) {
+  __host__ __device__ __noinline__ static Fp mul_call(Fp a, Fp b) { return mul_impl(a, b); }
+  PCD_HD static Fp mul(const Fp& a, const Fp& b) {
+    if constexpr (INLINE_ARITH) return mul_impl(a, b); else return mul_call(a, b);
+  }
+  PCD_HD static Fp mul_impl(const Fp& a, const Fp& b) {
     uint32_t m[N];
     uint64_t acc = 0;
 #pragma unroll
@@ -151,7 +157,11 @@ struct Fp {
   }
   // Montgomery square: the a_i a_j (i < j) products are taken once with a doubled operand (limbs < 2^29, column
   // sums still < 2^62): N(N+1)/2 + N^2 mads instead of 2 N^2.
-  __host__ __device__ __noinline__ static Fp sqr_(Fp a) {
+  __host__ __device__ __noinline__ static Fp sqr_call(Fp a) { return sqr_impl(a); }
+  PCD_HD static Fp sqr_(const Fp& a) {
+    if constexpr (INLINE_ARITH) return sqr_impl(a); else return sqr_call(a);
+  }
+  PCD_HD static Fp sqr_impl(const Fp& a) {
     uint32_t m[N], a2[N];
 #pragma unroll
     for (int i = 0; i < N; i++) a2[i] = a.v[i] << 1;
@@ -191,8 +201,16 @@ struct Fp {
   // (operands by reference: the callers hold them in memory anyway, and large by-value argument lists
   // miscompiled for the 753-bit fields on gfx950 / ROCm 7.2)
   template <int TERMS>
-  __host__ __device__ __noinline__ static void dot(Fp& out, const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, const Fp& a2,
-                                                   const Fp& b2) {
+  __host__ __device__ __noinline__ static void dot_call(Fp& out, const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, const Fp& a2,
+                                                        const Fp& b2) {
+    dot_impl<TERMS>(out, a0, b0, a1, b1, a2, b2);
+  }
+  template <int TERMS>
+  PCD_HD static void dot(Fp& out, const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, const Fp& a2, const Fp& b2) {
+    if constexpr (INLINE_ARITH) dot_impl<TERMS>(out, a0, b0, a1, b1, a2, b2); else dot_call<TERMS>(out, a0, b0, a1, b1, a2, b2);
+  }
+  template <int TERMS>
+  PCD_HD static void dot_impl(Fp& out, const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, const Fp& a2, const Fp& b2) {
     uint32_t m[N];
     uint64_t acc = 0;
 #pragma unroll
@@ -363,14 +381,18 @@ struct Fp2 {
   // (not inlined, like Fp::mul: bounds the code size of the G2 point kernels; operands by reference --
   // large by-value aggregates passed on the stack miscompiled for Fp3 on gfx950 / ROCm 7.2)
   // schoolbook with lazy reduction: (a0 b0 + nr a1 b1) + (a0 b1 + a1 b0) u, one Montgomery reduction per coefficient
-  __host__ __device__ __noinline__ static void mul(Fp2& o, const Fp2& a, const Fp2& b) {
+  __host__ __device__ __noinline__ static void mul_call(Fp2& o, const Fp2& a, const Fp2& b) { mul_impl(o, a, b); }
+  __host__ __device__ __noinline__ static void sqr_call(Fp2& o, const Fp2& a) { sqr_impl(o, a); }
+  PCD_HD static void mul(Fp2& o, const Fp2& a, const Fp2& b) { if constexpr (F::INLINE_ARITH) mul_impl(o, a, b); else mul_call(o, a, b); }
+  PCD_HD static void sqr_(Fp2& o, const Fp2& a) { if constexpr (F::INLINE_ARITH) sqr_impl(o, a); else sqr_call(o, a); }
+  PCD_HD static void mul_impl(Fp2& o, const Fp2& a, const Fp2& b) {
     F na1 = a.c1.mul_small(NR);
     F r0 = F::dot2(a.c0, b.c0, na1, b.c1);
     F r1 = F::dot2(a.c0, b.c1, a.c1, b.c0);
     o.c0 = r0;
     o.c1 = r1;
   }
-  __host__ __device__ __noinline__ static void sqr_(Fp2& o, const Fp2& a) {
+  PCD_HD static void sqr_impl(Fp2& o, const Fp2& a) {
     F na1 = a.c1.mul_small(NR);
     F r0 = F::dot2(a.c0, a.c0, na1, a.c1);
     F r1 = (a.c0 * a.c1).dbl();

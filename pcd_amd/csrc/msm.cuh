@@ -199,7 +199,8 @@ template <class G>
 __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t chunk,
                                                        const uint32_t* __restrict__ piece_first, const uint32_t* __restrict__ piece_last,
                                                        uint32_t* __restrict__ buckets, uint32_t big_limit, uint32_t* __restrict__ big_count,
-                                                       uint32_t* __restrict__ big_list /* (key, t0, t1) */, uint32_t big_cap) {
+                                                       uint32_t* __restrict__ big_list /* (key, first segment, #segments) */, uint32_t big_cap,
+                                                       uint32_t* __restrict__ seg_list /* (t_lo, t_hi, t_last) */, uint32_t seg_len) {
   typedef typename G::F F;
   typedef EC<G> E;
   uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
@@ -208,9 +209,15 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
   if (hi == lo) return;
   uint32_t t0 = lo / chunk, t1 = (hi - 1) / chunk;
   if (t1 == t0) return;  // the whole run lies inside one chunk: msm_accumulate wrote the bucket itself
-  if (t1 - t0 + 1 > big_limit) {
-    uint32_t slot = atomicAdd(big_count, 1u);
-    if (slot < big_cap) { big_list[3 * slot] = key; big_list[3 * slot + 1] = t0; big_list[3 * slot + 2] = t1; }
+  if (t1 - t0 + 1 > big_limit) {  // big bucket: its pieces are cut into segments of seg_len, one wave each
+    uint32_t nseg = (t1 - t0 + seg_len) / seg_len;
+    uint32_t slot = atomicAdd(&big_count[0], 1u);
+    uint32_t s0 = atomicAdd(&big_count[1], nseg);
+    if (slot < big_cap) { big_list[3 * slot] = key; big_list[3 * slot + 1] = s0; big_list[3 * slot + 2] = nseg; }
+    for (uint32_t i = 0; i < nseg; i++) {
+      uint32_t lo = t0 + i * seg_len, hi = min(t1, lo + seg_len - 1);
+      seg_list[3 * (s0 + i)] = lo; seg_list[3 * (s0 + i) + 1] = hi; seg_list[3 * (s0 + i) + 2] = t1;
+    }
     return;
   }
   Jac<F> acc = Jac<F>::load(piece_last + (size_t)t0 * Jac<F>::WORDS);
@@ -219,35 +226,57 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
   acc.store(buckets + (size_t)key * Jac<F>::WORDS);
 }
 
-// One wave per big bucket (grid-stride over the device-side list): strided serial sums, then a 6-level tree
-// through global scratch.
+// Big buckets, two levels (all counts live on the device; grid-stride loops):
+//   A: one wave per segment of <= seg_len pieces -> partial[segment]      B: one wave per big bucket sums its partials.
+// A wave sums strided pieces per lane, then a 6-level tree through global scratch.
 template <class G>
-__global__ void __launch_bounds__(64) msm_big_bucket_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count,
-                                                            const uint32_t* __restrict__ piece_first, const uint32_t* __restrict__ piece_last,
-                                                            uint32_t* __restrict__ buckets, uint32_t* __restrict__ scratch /* gridDim.x * 64 points */) {
+PCD_DEV void msm_wave_tree(Jac<typename G::F> acc, uint32_t* my /* 64 points of scratch */, uint32_t* dst) {
   typedef typename G::F F;
   typedef EC<G> E;
-  const uint32_t nbig = *big_count;
+  acc.store(my + (size_t)threadIdx.x * Jac<F>::WORDS);
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      Jac<F> o = Jac<F>::load(my + (size_t)(threadIdx.x + s) * Jac<F>::WORDS);
+      acc = E::add(acc, o);
+      acc.store(my + (size_t)threadIdx.x * Jac<F>::WORDS);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) acc.store(dst);
+  __syncthreads();
+}
+template <class G>
+__global__ void __launch_bounds__(64) msm_big_segments_kernel(const uint32_t* __restrict__ seg_list, const uint32_t* __restrict__ big_count,
+                                                              const uint32_t* __restrict__ piece_first, const uint32_t* __restrict__ piece_last,
+                                                              uint32_t* __restrict__ partial, uint32_t* __restrict__ scratch) {
+  typedef typename G::F F;
+  typedef EC<G> E;
+  const uint32_t nseg = big_count[1];
   uint32_t* my = scratch + (size_t)blockIdx.x * 64 * Jac<F>::WORDS;
-  for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
-    uint32_t key = big_list[3 * b], t0 = big_list[3 * b + 1], t1 = big_list[3 * b + 2];
+  for (uint32_t sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
+    uint32_t lo = seg_list[3 * sg], hi = seg_list[3 * sg + 1], tlast = seg_list[3 * sg + 2];
     Jac<F> acc = Jac<F>::infinity();
-    for (uint32_t u = t0 + threadIdx.x; u <= t1; u += 64) {
-      const uint32_t* src = (u == t1) ? piece_first : piece_last;
+    for (uint32_t u = lo + threadIdx.x; u <= hi; u += 64) {
+      const uint32_t* src = (u == tlast) ? piece_first : piece_last;
       acc = E::add(acc, Jac<F>::load(src + (size_t)u * Jac<F>::WORDS));
     }
-    acc.store(my + (size_t)threadIdx.x * Jac<F>::WORDS);
-    __syncthreads();
-    for (int s = 32; s > 0; s >>= 1) {
-      if ((int)threadIdx.x < s) {
-        Jac<F> o = Jac<F>::load(my + (size_t)(threadIdx.x + s) * Jac<F>::WORDS);
-        acc = E::add(acc, o);
-        acc.store(my + (size_t)threadIdx.x * Jac<F>::WORDS);
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) acc.store(buckets + (size_t)key * Jac<F>::WORDS);
-    __syncthreads();
+    msm_wave_tree<G>(acc, my, partial + (size_t)sg * Jac<F>::WORDS);
+  }
+}
+template <class G>
+__global__ void __launch_bounds__(64) msm_big_bucket_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count,
+                                                            const uint32_t* __restrict__ partial, uint32_t* __restrict__ buckets,
+                                                            uint32_t* __restrict__ scratch) {
+  typedef typename G::F F;
+  typedef EC<G> E;
+  const uint32_t nbig = big_count[0];
+  uint32_t* my = scratch + (size_t)blockIdx.x * 64 * Jac<F>::WORDS;
+  for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+    uint32_t key = big_list[3 * b], s0 = big_list[3 * b + 1], ns = big_list[3 * b + 2];
+    Jac<F> acc = Jac<F>::infinity();
+    for (uint32_t u = threadIdx.x; u < ns; u += 64) acc = E::add(acc, Jac<F>::load(partial + (size_t)(s0 + u) * Jac<F>::WORDS));
+    msm_wave_tree<G>(acc, my, buckets + (size_t)key * Jac<F>::WORDS);
   }
 }
 
@@ -353,8 +382,8 @@ hipError_t msm_precompute(hipStream_t st, uint32_t* pts, uint32_t n, int groups,
 // ------------------------------------------------------------------------------------------------ host driver
 struct MsmWorkspace {
   // device buffers, grown on demand and reused across calls (no allocation on the hot path once warm)
-  void* buf[16] = {nullptr};
-  size_t cap[16] = {0};
+  void* buf[20] = {nullptr};
+  size_t cap[20] = {0};
   hipError_t ensure(int slot, size_t bytes) {
     if (cap[slot] >= bytes) return hipSuccess;
     if (buf[slot]) { hipError_t e = hipFree(buf[slot]); if (e != hipSuccess) return e; buf[slot] = nullptr; cap[slot] = 0; }
@@ -364,14 +393,15 @@ struct MsmWorkspace {
     cap[slot] = want;
     return hipSuccess;
   }
-  void release() { for (int i = 0; i < 16; i++) if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; } }
+  void release() { for (int i = 0; i < 20; i++) if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; } }
 };
 
 struct MsmTimings {  // milliseconds, filled when events are requested
   float digits = 0, scan = 0, scatter = 0, accumulate = 0, fixup = 0, tail = 0, horner = 0, total = 0;
 };
 
-enum { WS_CNT = 0, WS_OFF, WS_BSUM, WS_SORTED, WS_BUCKETS, WS_PFIRST, WS_PLAST, WS_BIG, WS_BIGSCR, WS_A0, WS_A1, WS_C0, WS_C1, WS_OUT, WS_SCAL };
+enum { WS_CNT = 0, WS_OFF, WS_BSUM, WS_SORTED, WS_BUCKETS, WS_PFIRST, WS_PLAST, WS_BIG, WS_BIGSCR, WS_A0, WS_A1, WS_C0, WS_C1, WS_OUT, WS_SCAL,
+       WS_BIGPART };
 
 #define PCD_HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -441,26 +471,32 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   const uint32_t nchunks = (uint32_t)((maxM + pl.chunk - 1) / pl.chunk);
   PCD_HIP_TRY(ws.ensure(WS_PFIRST, (size_t)nchunks * PB));
   PCD_HIP_TRY(ws.ensure(WS_PLAST, (size_t)nchunks * PB));
-  const uint32_t big_limit = 8;
-  const uint32_t big_cap = nchunks / big_limit + 2;  // a big bucket spans more than big_limit chunks
-  PCD_HIP_TRY(ws.ensure(WS_BIG, (size_t)(3 * big_cap + 4) * 4));
+  const uint32_t big_limit = 8, seg_len = 256;
+  const uint32_t big_cap = nchunks / big_limit + 2;   // a big bucket spans more than big_limit chunks
+  const uint32_t seg_cap = nchunks / seg_len + big_cap + 2;
+  PCD_HIP_TRY(ws.ensure(WS_BIG, (size_t)(3 * big_cap + 3 * seg_cap + 8) * 4));
+  PCD_HIP_TRY(ws.ensure(WS_BIGPART, (size_t)seg_cap * PB));
   uint32_t* pfirst = (uint32_t*)ws.buf[WS_PFIRST];
   uint32_t* plast = (uint32_t*)ws.buf[WS_PLAST];
   uint32_t* big = (uint32_t*)ws.buf[WS_BIG];
-  uint32_t* big_count = big + 3 * big_cap;
+  uint32_t* seg_list = big + 3 * big_cap;
+  uint32_t* big_count = seg_list + 3 * seg_cap;  // [#big buckets, #segments]
+  uint32_t* big_partial = (uint32_t*)ws.buf[WS_BIGPART];
   PCD_HIP_TRY(hipMemsetAsync(buckets, 0, (size_t)pl.nkeys * PB, st));  // Z = 0: identity
-  PCD_HIP_TRY(hipMemsetAsync(big_count, 0, 4, st));
+  PCD_HIP_TRY(hipMemsetAsync(big_count, 0, 8, st));
   hipLaunchKernelGGL((msm_accumulate_kernel<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, bases_dev, sorted, off, pl.nkeys, pl.chunk, buckets,
                      pfirst, plast);
   PCD_HIP_TRY(mark(4));
   // 5. pieces
   hipLaunchKernelGGL((msm_fixup_kernel<G>), dim3((pl.nkeys + 63) / 64), dim3(64), 0, st, off, pl.nkeys, pl.chunk, pfirst, plast, buckets,
-                     big_limit, big_count, big, big_cap);
+                     big_limit, big_count, big, big_cap, seg_list, seg_len);
   {
-    const uint32_t big_grid = std::min<uint32_t>(big_cap, 2048);
+    const uint32_t big_grid = std::min<uint32_t>(seg_cap, 2048);
     PCD_HIP_TRY(ws.ensure(WS_BIGSCR, (size_t)big_grid * 64 * PB));
-    hipLaunchKernelGGL((msm_big_bucket_kernel<G>), dim3(big_grid), dim3(64), 0, st, big, big_count, pfirst, plast, buckets,
+    hipLaunchKernelGGL((msm_big_segments_kernel<G>), dim3(big_grid), dim3(64), 0, st, seg_list, big_count, pfirst, plast, big_partial,
                        (uint32_t*)ws.buf[WS_BIGSCR]);
+    hipLaunchKernelGGL((msm_big_bucket_kernel<G>), dim3(std::min<uint32_t>(big_cap, 2048)), dim3(64), 0, st, big, big_count, big_partial,
+                       buckets, (uint32_t*)ws.buf[WS_BIGSCR]);
   }
   PCD_HIP_TRY(mark(5));
   // 6. tail levels

@@ -20,7 +20,7 @@ def hc():
     srcs = [os.path.join(HC, "hostcheck.hip")] + [os.path.join(ROOT, "pcd_amd", "csrc", f) for f in
                                                   ("fp.cuh", "ec.cuh", "pairing.cuh", "params_gen.h", "params28_gen.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared",
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared",
                                os.path.join(HC, "hostcheck.hip"), "-o", so], stderr=subprocess.DEVNULL)
     return C.CDLL(so)
 
