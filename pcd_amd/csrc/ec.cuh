@@ -41,25 +41,26 @@ struct Aff {
 
 // ------------------------------------------------------------------------------------------------ group configs
 // G: coordinate field F, scalar-field parameters FR, and multiplication by the curve coefficient a.
-template <class FQ, class FRP, unsigned A, int CURVE>
+// INL selects the inlined / compact variant of the field arithmetic (fp.cuh); the memory image is the same.
+template <class FQ, class FRP, unsigned A, int CURVE, bool INL = (FQ::N <= 11)>
 struct G1Cfg {
-  typedef Fp<FQ> F;
+  typedef Fp<FQ, INL> F;
   typedef FRP FR;
   static constexpr int CURVE_ID = CURVE;
   static constexpr int GROUP = 1;
   PCD_HD static F mul_by_a(const F& x) { return x.mul_small(A); }
 };
-template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE, bool INL = (FQ::N <= 11)>
 struct G2Cfg2 {  // twist over Fq2: a' = (a*nr, 0)
-  typedef Fp2<Fp<FQ>, NR> F;
+  typedef Fp2<Fp<FQ, INL>, NR> F;
   typedef FRP FR;
   static constexpr int CURVE_ID = CURVE;
   static constexpr int GROUP = 2;
   PCD_HD static F mul_by_a(const F& x) { return x.mul_small(A * NR); }
 };
-template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE, bool INL = (FQ::N <= 11)>
 struct G2Cfg3 {  // twist over Fq3: a' = (0, 0, a) = a u^2;  x u^2 = (nr c1, nr c2, c0)
-  typedef Fp3<Fp<FQ>, NR> F;
+  typedef Fp3<Fp<FQ, INL>, NR> F;
   typedef FRP FR;
   static constexpr int CURVE_ID = CURVE;
   static constexpr int GROUP = 2;
@@ -74,6 +75,11 @@ typedef G2Cfg2<F298A, F298B, PCD_MNT4_298_A_SMALL, PCD_MNT4_298_NR_SMALL, 0> G2_
 typedef G2Cfg3<F298B, F298A, PCD_MNT6_298_A_SMALL, PCD_MNT6_298_NR_SMALL, 1> G2_MNT6_298;
 typedef G2Cfg2<F753A, F753B, PCD_MNT4_753_A_SMALL, PCD_MNT4_753_NR_SMALL, 2> G2_MNT4_753;
 typedef G2Cfg3<F753B, F753A, PCD_MNT6_753_A_SMALL, PCD_MNT6_753_NR_SMALL, 3> G2_MNT6_753;
+// compact variants (non-inlined field arithmetic) for the latency-bound single-lane kernels
+typedef G1Cfg<F298A, F298B, PCD_MNT4_298_A_SMALL, 0, false> G1_MNT4_298_C;
+typedef G1Cfg<F298B, F298A, PCD_MNT6_298_A_SMALL, 1, false> G1_MNT6_298_C;
+typedef G2Cfg2<F298A, F298B, PCD_MNT4_298_A_SMALL, PCD_MNT4_298_NR_SMALL, 0, false> G2_MNT4_298_C;
+typedef G2Cfg3<F298B, F298A, PCD_MNT6_298_A_SMALL, PCD_MNT6_298_NR_SMALL, 1, false> G2_MNT6_298_C;
 
 // ------------------------------------------------------------------------------------------------ group law
 template <class G>

@@ -51,17 +51,19 @@ PCD_DEF_FIELD(F298B, PCD_F298B, PCD28_F298B)
 PCD_DEF_FIELD(F753A, PCD_F753A, PCD28_F753A)
 PCD_DEF_FIELD(F753B, PCD_F753B, PCD28_F753B)
 
-template <class P>
+// INL: inline the product / square into every caller (throughput kernels of the 298-bit fields) or keep ONE
+// non-inlined copy per code object (753-bit fields; and the latency-bound single-lane kernels -- proof assembly,
+// pairing -- whose loop bodies must fit the instruction cache).
+template <class P, bool INL = (P::N <= 11)>
 struct Fp {
   typedef P Params;
-  typedef Fp<P> Base;
+  typedef Fp<P, INL> Base;
   static constexpr int N = P::N;
   static constexpr int DEG = 1;
   static constexpr int WORDS = N;           // u32 words per element in device memory
   static constexpr int ABI_WORDS = P::N32;  // u32 words per element at the C-ABI
   static constexpr uint32_t MASK = 0x0FFFFFFFu;
-  // 298-bit fields: the product (242 mads) is inlined into its callers; 753-bit: one non-inlined copy (1458 mads)
-  static constexpr bool INLINE_ARITH = (N <= 11);
+  static constexpr bool INLINE_ARITH = INL;
   uint32_t v[N];
 
   PCD_HD static Fp zero() { Fp r; for (int i = 0; i < N; i++) r.v[i] = 0; return r; }

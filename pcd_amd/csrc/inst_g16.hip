@@ -7,10 +7,12 @@
 
 namespace pcd {
 
+// (the 298-bit curves use the compact field variant here: these kernels are single-lane and latency-bound, and a
+//  double-and-add loop body with inlined 242-mad products does not fit the instruction cache)
 #if PCD_CURVE_IDX == 0
-typedef G1_MNT4_298 GA; typedef G2_MNT4_298 GB;
+typedef G1_MNT4_298_C GA; typedef G2_MNT4_298_C GB;
 #elif PCD_CURVE_IDX == 1
-typedef G1_MNT6_298 GA; typedef G2_MNT6_298 GB;
+typedef G1_MNT6_298_C GA; typedef G2_MNT6_298_C GB;
 #elif PCD_CURVE_IDX == 2
 typedef G1_MNT4_753 GA; typedef G2_MNT4_753 GB;
 #elif PCD_CURVE_IDX == 3
@@ -23,7 +25,7 @@ namespace {
 
 typedef typename GA::F F1;
 typedef typename GB::F F2;
-typedef Fp<typename GA::FR> FR;
+typedef Fp<typename GA::FR, false> FR;
 // device-internal word counts, and the C-ABI ones (suffix A)
 constexpr int J1 = Jac<F1>::WORDS, J2 = Jac<F2>::WORDS, A1 = Aff<F1>::WORDS, A2 = Aff<F2>::WORDS;
 constexpr int A1A = Aff<F1>::ABI_WORDS, A2A = Aff<F2>::ABI_WORDS, SWA = FR::ABI_WORDS;

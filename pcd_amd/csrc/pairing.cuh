@@ -205,8 +205,8 @@ struct Pairing {
     PCD_HD static uint32_t loop(int i) { constexpr uint32_t m[PFX##_ATE_LOOP_NLIMBS] = PFX##_ATE_LOOP; return m[i]; } \
     PCD_HD static uint32_t w0(int i) { constexpr uint32_t m[PFX##_W0_NLIMBS] = PFX##_W0; return m[i]; }          \
   };
-PCD_DEF_PAIRING(PC_MNT4_298, G1_MNT4_298, G2_MNT4_298, PCD_MNT4_298)
-PCD_DEF_PAIRING(PC_MNT6_298, G1_MNT6_298, G2_MNT6_298, PCD_MNT6_298)
+PCD_DEF_PAIRING(PC_MNT4_298, G1_MNT4_298_C, G2_MNT4_298_C, PCD_MNT4_298)  // compact field variant: single-lane kernels
+PCD_DEF_PAIRING(PC_MNT6_298, G1_MNT6_298_C, G2_MNT6_298_C, PCD_MNT6_298)
 PCD_DEF_PAIRING(PC_MNT4_753, G1_MNT4_753, G2_MNT4_753, PCD_MNT4_753)
 PCD_DEF_PAIRING(PC_MNT6_753, G1_MNT6_753, G2_MNT6_753, PCD_MNT6_753)
 
