@@ -45,7 +45,7 @@ EXPORTS = [
     "pcdhip_field_limbs", "pcdhip_curve_base_field", "pcdhip_curve_scalar_field", "pcdhip_point_limbs",
     "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
     "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config",
-    "pcdhip_set_precompute", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_to_affine",
+    "pcdhip_set_precompute", "pcdhip_msm_set_sort", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
     "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings",
     "pcdhip_multi_pairing", "pcdhip_groth16_verify", "pcdhip_timer_start", "pcdhip_timer_stop",
@@ -148,6 +148,10 @@ class Context:
     def set_precompute(self, mode):
         """-1 full (default), 0 none, k >= 2 copies; applies to bases uploaded afterwards."""
         self._check(lib().pcdhip_set_precompute(self._ctx, int(mode)))
+
+    def msm_set_sort(self, mode):
+        """0: two-pass counting sort (default); 1: single-pass binning with on-device fallback."""
+        self._check(lib().pcdhip_msm_set_sort(self._ctx, int(mode)))
 
     def msm_profile(self, on=True):
         self._check(lib().pcdhip_msm_profile(self._ctx, int(on)))

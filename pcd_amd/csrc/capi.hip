@@ -344,6 +344,11 @@ int pcdhip_msm_config(pcdhip_ctx* ctx, int window_bits, int chunk) {
   ctx->msm_chunk = (uint32_t)chunk;
   return PCDHIP_OK;
 }
+int pcdhip_msm_set_sort(pcdhip_ctx* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 1) return PCDHIP_E_ARG;
+  ctx->msm_sort = mode;
+  return PCDHIP_OK;
+}
 int pcdhip_msm_profile(pcdhip_ctx* ctx, int on) {
   if (!ctx) return PCDHIP_E_ARG;
   ctx->msm_profile = on != 0;
@@ -365,7 +370,7 @@ static int msm_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset,
   uint32_t* out_dev = (uint32_t*)ctx->msm_ws.buf[WS_OUT];
   uint32_t* out_abi = out_dev + jac_b / 4;
   TRY(ge.msm(ctx->msm_ws, ctx->stream, bases->view(offset), scalars_dev, (uint32_t)n, out_dev, ctx->msm_c, ctx->msm_chunk,
-             ctx->msm_profile ? &ctx->msm_tm : nullptr));
+             ctx->msm_sort, ctx->msm_profile ? &ctx->msm_tm : nullptr));
   TRY(ge.jac_out(ctx->stream, out_dev, 1, out_abi));
   TRY(hipMemcpyAsync(out_xyz, out_abi, jac_abi_b, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
@@ -765,7 +770,7 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
     hipStream_t sk = ctx->g16_streams[k];
     TRY(hipStreamWaitEvent(sk, ctx->g16_ready, 0));
     TRY(hipEventRecord(ctx->g16_begin[k], sk));
-    TRY(jobs[k].ge->msm(ctx->g16_ws[k], sk, jobs[k].bv, jobs[k].sc, jobs[k].n, jobs[k].out, ctx->msm_c, ctx->msm_chunk, nullptr));
+    TRY(jobs[k].ge->msm(ctx->g16_ws[k], sk, jobs[k].bv, jobs[k].sc, jobs[k].n, jobs[k].out, ctx->msm_c, ctx->msm_chunk, ctx->msm_sort, nullptr));
     TRY(hipEventRecord(ctx->g16_end[k], sk));
     TRY(hipStreamWaitEvent(st, ctx->g16_end[k], 0));
   }

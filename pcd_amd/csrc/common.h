@@ -62,6 +62,7 @@ struct pcdhip_ctx {
   std::map<uint64_t, pcd::FftTables> fft_tables;
   int msm_c = 0;
   uint32_t msm_chunk = 0;
+  int msm_sort = 0;     // 0 two-pass counting sort, 1 single-pass binning
   int precompute = -1;  // bases uploaded through this context: -1 full (one bucket window), 0 none, k > 1 groups
   bool msm_profile = false;
   pcd::MsmTimings msm_tm;
@@ -76,7 +77,7 @@ namespace pcd {
 
 // ---- per-group entries (inst_group.hip, one object per group) ------------------------------------
 typedef hipError_t (*MsmFn)(MsmWorkspace&, hipStream_t, const MsmBasesView& bases, const uint32_t* scalars, uint32_t n,
-                            uint32_t* out_dev, int c, uint32_t chunk, MsmTimings* tm);
+                            uint32_t* out_dev, int c, uint32_t chunk, int sort_mode, MsmTimings* tm);
 typedef hipError_t (*PrecomputeFn)(hipStream_t, uint32_t* pts, uint32_t n, int groups, int shift);
 typedef hipError_t (*PointsSumFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* out_dev);
 typedef hipError_t (*ToAffineFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* aff_dev);

@@ -84,6 +84,29 @@ def test_edge_cases(co, gpu_ctx, cid, grp):
     check(co, gpu_ctx, cid, grp, pts, sc, inf=inf, modes=(-1, 0))
 
 
+@pytest.mark.parametrize("cid,grp,n", [(0, 1, 20000), (1, 2, 700)])
+def test_sort_strategies_and_slot_overflow(co, gpu_ctx, cid, grp, n):
+    """single-pass binning (default), its on-device fallback when a bucket overflows its slots (many equal
+    scalars), and the forced two-pass counting sort must all give the oracle's value."""
+    fr = co.CURVE_FR[cid]
+    pts = co.gen_points(cid, grp, n, seed=61)
+    for variant in ("uniform", "witness", "heavy"):
+        sc = co.gen_scalars(fr, n, seed=62, dist=1 if variant == "witness" else 0)
+        if variant == "heavy":
+            sc[: n // 2] = sc[0]          # n/2 equal scalars: every window has one bucket far above its slot capacity
+        want = co.to_affine(cid, grp, co.msm(cid, grp, pts, sc, nthreads=8))
+        for sort_mode in (0, 1):
+            gpu_ctx.msm_set_sort(sort_mode)
+            for pre in (-1, 0):
+                gpu_ctx.set_precompute(pre)
+                b = gpu_ctx.bases_upload(cid, grp, pts)
+                got = co.to_affine(cid, grp, gpu_ctx.msm(b, sc))
+                b.free()
+                assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1]), (variant, sort_mode, pre)
+    gpu_ctx.msm_set_sort(0)
+    gpu_ctx.set_precompute(-1)
+
+
 def test_points_sum_and_device_scalars(co, gpu_ctx):
     cid, grp, n = 0, 1, 3000
     fr = co.CURVE_FR[cid]
@@ -120,3 +143,34 @@ def test_full_size_2_20(co, gpu_ctx, dist):
     lhs = co.jac_add(cid, grp, got, gpu_ctx.msm(b, sc2))
     assert np.array_equal(co.to_affine(cid, grp, lhs)[0], co.to_affine(cid, grp, gpu_ctx.msm(b, ssum))[0])
     b.free()
+
+
+def test_c_abi_error_behaviour(co, gpu_ctx):
+    """Every entry point returns a negative PCDHIP_E_* code on bad input (nothing aborts or throws across the ABI)."""
+    import ctypes as C
+    from pcd_amd import capi
+    lib = capi.lib()
+    ctx = gpu_ctx._ctx
+    h = C.c_void_p()
+    one = np.zeros((1, 10), dtype=np.uint64)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.pcdhip_bases_upload(ctx, 9, 1, P(one), None, C.c_size_t(1), C.byref(h)) == -1          # bad curve id
+    assert lib.pcdhip_bases_upload(ctx, 0, 3, P(one), None, C.c_size_t(1), C.byref(h)) == -1          # bad group id
+    assert lib.pcdhip_bases_upload(ctx, 0, 1, None, None, C.c_size_t(1), C.byref(h)) == -1            # null points
+    assert lib.pcdhip_init(99, C.byref(h)) == -1                                                        # no such device
+    pts = co.gen_points(0, 1, 8, seed=1)
+    b = gpu_ctx.bases_upload(0, 1, pts)
+    sc = co.gen_scalars(1, 8, seed=2)
+    out = np.zeros(15, dtype=np.uint64)
+    assert lib.pcdhip_msm(ctx, b._h, C.c_size_t(4), P(sc), C.c_size_t(8), P(out)) == -1                # range beyond the handle
+    assert lib.pcdhip_msm(ctx, b._h, C.c_size_t(0), None, C.c_size_t(8), P(out)) == -1                  # null scalars
+    wrong = gpu_ctx.buf_upload(0, sc)                                                                   # scalars of the wrong field
+    assert lib.pcdhip_msm_dev(ctx, b._h, C.c_size_t(0), wrong._h, C.c_size_t(0), C.c_size_t(8), P(out)) == -1
+    assert lib.pcdhip_fft(ctx, 0, P(np.zeros((4, 5), dtype=np.uint64)), 31, 0, 0) == -1
+    assert lib.pcdhip_fft(ctx, 0, P(np.zeros((4, 5), dtype=np.uint64)), 18, 0, 0) == -2                # above the 2-adicity
+    assert lib.pcdhip_fft_general(ctx, 1, P(np.zeros((7 * 8, 5), dtype=np.uint64)), C.c_size_t(56), 0, 0) == -2  # no 7-subgroup support on the main field
+    assert lib.pcdhip_set_precompute(ctx, 1) == -1 and lib.pcdhip_msm_config(ctx, 99, 0) == -1
+    # n = 0 is legal everywhere: the identity
+    xy, inf = gpu_ctx.to_affine(0, 1, gpu_ctx.msm(b, sc[:0], n=0))
+    assert inf[0] == 1
+    b.free(); wrong.free()
