@@ -91,9 +91,10 @@ int pcdhip_msm_dev(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, co
 int pcdhip_set_precompute(pcdhip_ctx* ctx, int mode);
 /* Tuning / introspection: window bits (0 = automatic), sorted entries per lane (0 = default). */
 int pcdhip_msm_config(pcdhip_ctx* ctx, int window_bits, int chunk);
-/* Sorting strategy of the (bucket, base) entries: 0 (default) two-pass counting sort (histogram, scan, scatter);
- * 1 single-pass binning into per-bucket slots with an on-device fallback to the compact list when a bucket
- * overflows (faster for bit-heavy witnesses, slower for uniform scalars). */
+/* Sorting strategy of the (bucket, base) entries: 0 (default) MSD partition through LDS (per-workgroup bin
+ * histograms, one global atomic per workgroup and bin, per-bin LDS counting sort); 1 single-pass binning into
+ * per-bucket slots with an on-device fallback when a bucket overflows; 2 two-pass counting sort with one global
+ * atomic per entry (also what small inputs use). */
 int pcdhip_msm_set_sort(pcdhip_ctx* ctx, int mode);
 /* Per-stage device time of the last MSM (HIP events on the context's stream), milliseconds:
  * [digits, scan, scatter, accumulate, fixup, tail, horner, total]; enable with on != 0. */

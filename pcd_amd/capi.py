@@ -150,7 +150,7 @@ class Context:
         self._check(lib().pcdhip_set_precompute(self._ctx, int(mode)))
 
     def msm_set_sort(self, mode):
-        """0: two-pass counting sort (default); 1: single-pass binning with on-device fallback."""
+        """0: LDS partition sort (default); 1: single-pass binning with on-device fallback; 2: two-pass counting sort."""
         self._check(lib().pcdhip_msm_set_sort(self._ctx, int(mode)))
 
     def msm_profile(self, on=True):

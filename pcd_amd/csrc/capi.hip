@@ -345,7 +345,7 @@ int pcdhip_msm_config(pcdhip_ctx* ctx, int window_bits, int chunk) {
   return PCDHIP_OK;
 }
 int pcdhip_msm_set_sort(pcdhip_ctx* ctx, int mode) {
-  if (!ctx || mode < 0 || mode > 1) return PCDHIP_E_ARG;
+  if (!ctx || mode < 0 || mode > 2) return PCDHIP_E_ARG;
   ctx->msm_sort = mode;
   return PCDHIP_OK;
 }

@@ -62,7 +62,7 @@ struct pcdhip_ctx {
   std::map<uint64_t, pcd::FftTables> fft_tables;
   int msm_c = 0;
   uint32_t msm_chunk = 0;
-  int msm_sort = 0;     // 0 two-pass counting sort, 1 single-pass binning
+  int msm_sort = 0;     // 0 LDS partition sort, 1 single-pass binning, 2 two-pass counting sort
   int precompute = -1;  // bases uploaded through this context: -1 full (one bucket window), 0 none, k > 1 groups
   bool msm_profile = false;
   pcd::MsmTimings msm_tm;

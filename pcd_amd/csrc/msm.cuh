@@ -130,6 +130,156 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------ partition sort
+// Default sort of the (bucket, base) entries: an MSD partition through LDS instead of one global atomic per entry.
+//   bins of 2^BIN_SHIFT consecutive keys;
+//   pass 0  msm_coarse_kernel<false>: per-workgroup LDS histogram over the bins of a tile of scalars, one global atomic
+//           per (workgroup, non-empty bin);  scalars equal to one go, wave-aggregated, to the pseudo bucket's list
+//   scan    bin bases
+//   pass 1  msm_coarse_kernel<true>: the same LDS histogram, one global atomic per (workgroup, bin) to reserve a run in
+//           the bin, then the entries (key, base index) are written into that run through LDS cursors
+//   pass 2  msm_bin_sort_kernel: one workgroup per bin: LDS counting sort of its entries by the low key bits; writes
+//           the final base-index list and the per-key offsets (bins are in key order, so no global scan is needed)
+// Global atomics drop from n W to ~2 n W / TILE_ENTRIES_PER_BIN; everything else is LDS atomics and streaming.
+constexpr int MSM_BIN_SHIFT = 9;          // 512 keys per bin
+constexpr int MSM_TILE = 2048;            // scalars per workgroup in passes 0 / 1
+constexpr uint32_t MSM_MAX_BINS = 8192;   // LDS histogram of a workgroup: 32 KiB
+
+template <int NS, bool WRITE>
+__global__ void __launch_bounds__(256) msm_coarse_kernel(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, int Wg,
+                                                         uint32_t n_total, uint32_t base_offset, uint32_t nbins,
+                                                         uint32_t* __restrict__ gbin /* WRITE: cursors (start at the bin bases) */,
+                                                         uint64_t* __restrict__ entries, uint32_t* __restrict__ ones_count,
+                                                         uint32_t* __restrict__ ones_idx) {
+  extern __shared__ uint32_t lbin[];  // nbins counters, then (WRITE) reused as cursors
+  for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) lbin[b] = 0;
+  __syncthreads();
+  const uint32_t tile0 = blockIdx.x * MSM_TILE;
+  // sweep A: histogram of this tile
+  for (uint32_t k = threadIdx.x; k < MSM_TILE; k += blockDim.x) {
+    uint32_t i = tile0 + k;
+    bool live = i < n;
+    uint32_t s[NS];
+    bool is_one = false;
+    if (live) {
+      uint32_t hi = 0;
+#pragma unroll
+      for (int q = 0; q < NS; q++) { s[q] = scalars[(size_t)i * NS + q]; if (q) hi |= s[q]; }
+      is_one = (hi == 0 && s[0] == 1);
+    }
+    if (!WRITE) {  // the ones are listed once, in pass 0
+      unsigned long long m = __ballot(live && is_one);
+      if (m) {
+        int lane = threadIdx.x & 63;
+        int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(ones_count, (uint32_t)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (live && is_one) ones_idx[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = base_offset + i;
+      }
+    }
+    if (!live || is_one) continue;
+    int j = 0;
+    for (int w = 0; w < W; w++) {
+      uint32_t d = msm_digit<NS>(s, w, c);
+      if (d != 0) atomicAdd(&lbin[((((uint32_t)j << c) | d)) >> MSM_BIN_SHIFT], 1u);
+      if (++j == Wg) j = 0;
+    }
+  }
+  __syncthreads();
+  // one global atomic per non-empty bin: total count (pass 0) or run reservation (pass 1)
+  for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) {
+    uint32_t cnt = lbin[b];
+    if (cnt) {
+      uint32_t base = atomicAdd(&gbin[b], cnt);
+      if (WRITE) lbin[b] = base;  // becomes this workgroup's cursor inside the bin
+    }
+  }
+  if (!WRITE) return;
+  __syncthreads();
+  // sweep B: write the entries
+  for (uint32_t k = threadIdx.x; k < MSM_TILE; k += blockDim.x) {
+    uint32_t i = tile0 + k;
+    if (i >= n) continue;
+    uint32_t s[NS];
+    uint32_t hi = 0;
+#pragma unroll
+    for (int q = 0; q < NS; q++) { s[q] = scalars[(size_t)i * NS + q]; if (q) hi |= s[q]; }
+    if (hi == 0 && s[0] <= 1) continue;  // zero or one
+    int g = 0, j = 0;
+    for (int w = 0; w < W; w++) {
+      uint32_t d = msm_digit<NS>(s, w, c);
+      if (d != 0) {
+        uint32_t key = ((uint32_t)j << c) | d;
+        uint32_t pos = atomicAdd(&lbin[key >> MSM_BIN_SHIFT], 1u);
+        entries[pos] = ((uint64_t)key << 32) | (uint64_t)((uint32_t)g * n_total + base_offset + i);
+      }
+      if (++j == Wg) { j = 0; g++; }
+    }
+  }
+}
+
+// bin_base: exclusive scan of the bin counts (nbins + 1 values) + the list offsets of the pseudo bucket
+static __global__ void __launch_bounds__(1024) msm_bin_scan_kernel(const uint32_t* __restrict__ bin_cnt, uint32_t nbins,
+                                                                   uint32_t* __restrict__ bin_base, uint32_t* __restrict__ cursor,
+                                                                   const uint32_t* __restrict__ ones_count, uint32_t* __restrict__ off,
+                                                                   uint32_t nkeys) {
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (nbins + 1023) / 1024;
+  const uint32_t lo = threadIdx.x * per, hi = min(nbins, lo + per);
+  uint32_t acc = 0;
+  for (uint32_t b = lo; b < hi; b++) acc += bin_cnt[b];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 1; s < 1024; s <<= 1) {
+    uint32_t t = ((int)threadIdx.x >= s) ? part[threadIdx.x - s] : 0;
+    __syncthreads();
+    part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - acc;
+  for (uint32_t b = lo; b < hi; b++) { bin_base[b] = run; cursor[b] = run; run += bin_cnt[b]; }
+  if (threadIdx.x == 1023) {
+    uint32_t M = part[1023];
+    bin_base[nbins] = M;
+    off[nkeys] = M;                    // pseudo bucket (scalars equal to one) follows the real entries
+    off[nkeys + 1] = M + *ones_count;
+  }
+}
+
+// one workgroup per bin: counting sort of its entries by the low MSM_BIN_SHIFT key bits
+static __global__ void __launch_bounds__(256) msm_bin_sort_kernel(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ bin_base,
+                                                                  uint32_t* __restrict__ sorted_idx, uint32_t* __restrict__ off) {
+  constexpr uint32_t KB = 1u << MSM_BIN_SHIFT;
+  __shared__ uint32_t hist[KB];
+  __shared__ uint32_t wsum[4];
+  const uint32_t b = blockIdx.x, lo = bin_base[b], hi = bin_base[b + 1];
+  for (uint32_t k = threadIdx.x; k < KB; k += blockDim.x) hist[k] = 0;
+  __syncthreads();
+  for (uint32_t p = lo + threadIdx.x; p < hi; p += blockDim.x) atomicAdd(&hist[(uint32_t)(entries[p] >> 32) & (KB - 1)], 1u);
+  __syncthreads();
+  // exclusive scan of the 512 counters: two per lane, wave scan, then the four wave totals
+  const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  uint32_t c0 = hist[2 * t], c1 = hist[2 * t + 1];
+  uint32_t incl = c0 + c1;
+  for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += o; }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t q = 0; q < wv; q++) before += wsum[q];
+  uint32_t ex = lo + before + incl - (c0 + c1);
+  hist[2 * t] = ex;
+  hist[2 * t + 1] = ex + c0;
+  off[(size_t)b * KB + 2 * t] = ex;
+  off[(size_t)b * KB + 2 * t + 1] = ex + c0;
+  __syncthreads();
+  for (uint32_t p = lo + threadIdx.x; p < hi; p += blockDim.x) {
+    uint64_t e = entries[p];
+    uint32_t pos = atomicAdd(&hist[(uint32_t)(e >> 32) & (KB - 1)], 1u);
+    sorted_idx[pos] = (uint32_t)e;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ scan (exclusive, u32)
 static __global__ void __launch_bounds__(1024) scan_block_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t per_block,
                                                          uint32_t* __restrict__ block_sums) {
@@ -462,7 +612,7 @@ struct MsmTimings {  // milliseconds, filled when events are requested
 };
 
 enum { WS_CNT = 0, WS_OFF, WS_BSUM, WS_SORTED, WS_BUCKETS, WS_PFIRST, WS_PLAST, WS_BIG, WS_BIGSCR, WS_A0, WS_A1, WS_C0, WS_C1, WS_OUT, WS_SCAL,
-       WS_BIGPART, WS_ONES, WS_SLOTS, WS_CUR };
+       WS_BIGPART, WS_ONES, WS_SLOTS, WS_CUR, WS_ENTRIES };
 
 #define PCD_HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -528,6 +678,9 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   uint32_t cap = (uint32_t)(mu + 6.0 * sqrt(mu) + 8.0);
   cap = (cap + 7u) & ~7u;
   const bool use_slots = single_pass && (double)pl.nkeys * cap * 4.0 <= 1.5e9;
+  // default: MSD partition through LDS (needs whole bins of 2^MSM_BIN_SHIFT keys and an LDS histogram per workgroup)
+  const uint32_t nbins = pl.nkeys >> MSM_BIN_SHIFT;
+  const bool use_partition = sort_mode == 0 && pl.c >= MSM_BIN_SHIFT && nbins >= 1 && nbins <= MSM_MAX_BINS && n >= 4096;
   uint32_t* slots = nullptr;
   if (use_slots) { PCD_HIP_TRY(ws.ensure(WS_SLOTS, (size_t)pl.nkeys * cap * 4)); slots = (uint32_t*)ws.buf[WS_SLOTS]; }
 
@@ -553,6 +706,26 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
                        off, sorted, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, flag, 1);
     PCD_HIP_TRY(mark(3));
     src = {sorted, slots, ones_idx, flag, cap, ones_key};
+  } else if (use_partition) {
+    // 1. coarse histogram  2. bin bases  3. partition + per-bin counting sort (see "partition sort" above)
+    const uint32_t tiles = (n + MSM_TILE - 1) / MSM_TILE;
+    PCD_HIP_TRY(ws.ensure(WS_ENTRIES, (size_t)maxM * 8));
+    PCD_HIP_TRY(ws.ensure(WS_CUR, ((size_t)2 * nbins + 8) * 4));
+    uint64_t* entries = (uint64_t*)ws.buf[WS_ENTRIES];
+    uint32_t* bin_base = (uint32_t*)ws.buf[WS_CUR];
+    uint32_t* cursor = bin_base + nbins + 2;
+    uint32_t* ones_count = flag;  // (the binning flag word is unused on this path)
+    PCD_HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
+    hipLaunchKernelGGL((msm_coarse_kernel<NS, false>), dim3(tiles), dim3(256), (size_t)nbins * 4, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total,
+                       bv.offset, nbins, cnt, (uint64_t*)nullptr, ones_count, ones_idx);
+    PCD_HIP_TRY(mark(1));
+    hipLaunchKernelGGL(msm_bin_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, nbins, bin_base, cursor, ones_count, off, pl.nkeys);
+    PCD_HIP_TRY(mark(2));
+    hipLaunchKernelGGL((msm_coarse_kernel<NS, true>), dim3(tiles), dim3(256), (size_t)nbins * 4, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total,
+                       bv.offset, nbins, cursor, entries, ones_count, ones_idx);
+    hipLaunchKernelGGL(msm_bin_sort_kernel, dim3(nbins), dim3(256), 0, st, entries, bin_base, sorted, off);
+    PCD_HIP_TRY(mark(3));
+    src = {sorted, nullptr, ones_idx, nullptr, 0u, ones_key};
   } else {
     // 1. histogram  2. scan  3. scatter (cursor = cnt reset to zero)
     hipLaunchKernelGGL((msm_digits_kernel<NS, MODE_HIST>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, pl.nkeys, cnt,

@@ -86,8 +86,8 @@ def test_edge_cases(co, gpu_ctx, cid, grp):
 
 @pytest.mark.parametrize("cid,grp,n", [(0, 1, 20000), (1, 2, 700)])
 def test_sort_strategies_and_slot_overflow(co, gpu_ctx, cid, grp, n):
-    """single-pass binning (default), its on-device fallback when a bucket overflows its slots (many equal
-    scalars), and the forced two-pass counting sort must all give the oracle's value."""
+    """the LDS partition sort (default), the single-pass binning and its on-device fallback when a bucket overflows
+    its slots (many equal scalars), and the two-pass counting sort must all give the oracle's value."""
     fr = co.CURVE_FR[cid]
     pts = co.gen_points(cid, grp, n, seed=61)
     for variant in ("uniform", "witness", "heavy"):
@@ -95,7 +95,7 @@ def test_sort_strategies_and_slot_overflow(co, gpu_ctx, cid, grp, n):
         if variant == "heavy":
             sc[: n // 2] = sc[0]          # n/2 equal scalars: every window has one bucket far above its slot capacity
         want = co.to_affine(cid, grp, co.msm(cid, grp, pts, sc, nthreads=8))
-        for sort_mode in (0, 1):
+        for sort_mode in (0, 1, 2):
             gpu_ctx.msm_set_sort(sort_mode)
             for pre in (-1, 0):
                 gpu_ctx.set_precompute(pre)
