@@ -14,8 +14,8 @@ pts = co.gen_points(cid, grp, n, seed=1)
 sc = co.gen_scalars(fr, n, seed=2, dist=0)
 sb = ctx.buf_upload(fr, sc)
 want = co.to_affine(cid, grp, co.msm(cid, grp, pts, sc, nthreads=32))[0]
-for c in (18, 19, 20):
-    for chunk in (32,):
+for c in (18, 19, 20, 21):
+    for chunk in (24, 32, 48):
         ctx.msm_config(c, chunk)
         ctx.set_precompute(-1)
         b = ctx.bases_upload(cid, grp, pts)
