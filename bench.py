@@ -194,7 +194,7 @@ def synthetic_keys(co, curve, r, seed):
 def pcd_step(ctx, co):
     """Prover arithmetic of one PCD step: main proof (MNT4-298, domain 2^20) + help proof (MNT6-298, domain
     2^16: its scalar field has 2-adicity 17), witness-like assignment; keys resident; bit-exact vs the oracle."""
-    info = {"unit": "ms", "what": "witness map + 4 G1 MSM + 1 G2 MSM + assembly, per proof; R1CS synthesis (Rust host) excluded"}
+    info = {"unit": "ms", "what": "witness map + the proof's MSMs (h, l, A, s*A, r*B1 on G1; B on G2: every scalar multiplication of create_proof rides inside an MSM) + assembly, per proof; R1CS synthesis (Rust host) excluded"}
     total_gpu, total_cpu = 0.0, 0.0
     for name, curve, log_n in (("main_mnt4_298", 0, 20), ("help_mnt6_298", 1, 16)):
         fr = co.CURVE_FR[curve]

@@ -203,7 +203,7 @@ void pcdhip_destroy(pcdhip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   ctx->msm_ws.release();
   ctx->aux_ws.release();
-  for (int k = 0; k < 5; k++) {
+  for (int k = 0; k < 6; k++) {
     ctx->g16_ws[k].release();
     if (ctx->g16_streams[k]) (void)hipStreamDestroy(ctx->g16_streams[k]);
     if (ctx->g16_begin[k]) (void)hipEventDestroy(ctx->g16_begin[k]);
@@ -622,42 +622,26 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
   int rc = 0;
   // delta is appended to the a / b / l queries: r*delta, s*delta and -rs*delta then ride inside the MSMs as
   // one more (base, scalar) pair instead of being serial scalar multiplications in the assembly.
-  // Every a / b / l query gets three trailing slots matching the scalar tail [r, s, -rs] that follows the
-  // assignment: delta sits in the slot whose scalar the query needs, the other two slots hold the point at infinity.
-  auto upload_plus = [&](int group, const uint64_t* q, const uint8_t* inf, size_t n, const uint64_t* extra, int slot_idx,
-                         pcdhip_bases** out) -> int {
+  // Every a / b / l query gets four trailing slots matching the scalar tail [r, s, -rs, 1] that follows the
+  // assignment: delta sits in the slot whose scalar the query needs, the vk point (alpha / beta) in the last one,
+  // the remaining slots hold the point at infinity.  See inst_g16.hip.
+  auto upload_plus = [&](int group, const uint64_t* q, const uint8_t* inf, size_t n, const uint64_t* delta, int delta_slot,
+                         const uint64_t* vk_point, pcdhip_bases** out) -> int {
     const size_t pl = (size_t)pcdhip_point_limbs(cid, group);
-    std::vector<uint64_t> tmp((n + 3) * pl, 0);
-    std::vector<uint8_t> tinf(n + 3, 1);
+    std::vector<uint64_t> tmp((n + 4) * pl, 0);
+    std::vector<uint8_t> tinf(n + 4, 1);
     if (n) memcpy(tmp.data(), q, n * pl * 8);
     for (size_t i = 0; i < n; i++) tinf[i] = inf ? inf[i] : 0;
-    memcpy(tmp.data() + (n + slot_idx) * pl, extra, pl * 8);
-    tinf[n + slot_idx] = 0;
-    return pcdhip_bases_upload(ctx, cid, group, tmp.data(), tinf.data(), n + 3, out);
+    memcpy(tmp.data() + (n + delta_slot) * pl, delta, pl * 8);
+    tinf[n + delta_slot] = 0;
+    if (vk_point) { memcpy(tmp.data() + (n + 3) * pl, vk_point, pl * 8); tinf[n + 3] = 0; }
+    return pcdhip_bases_upload(ctx, cid, group, tmp.data(), tinf.data(), n + 4, out);
   };
-  rc = rc ? rc : upload_plus(1, h->a_query, h->a_inf, h->num_vars, h->delta_g1, 0, &pk->a_query);       // r * delta
-  rc = rc ? rc : upload_plus(1, h->b_g1_query, h->b_g1_inf, h->num_vars, h->delta_g1, 1, &pk->b_g1_query);  // s * delta
-  rc = rc ? rc : upload_plus(2, h->b_g2_query, h->b_g2_inf, h->num_vars, h->delta_g2, 1, &pk->b_g2_query);
+  rc = rc ? rc : upload_plus(1, h->a_query, h->a_inf, h->num_vars, h->delta_g1, 0, h->alpha_g1, &pk->a_query);        // r * delta + alpha
+  rc = rc ? rc : upload_plus(1, h->b_g1_query, h->b_g1_inf, h->num_vars, h->delta_g1, 1, h->beta_g1, &pk->b_g1_query);  // s * delta + beta
+  rc = rc ? rc : upload_plus(2, h->b_g2_query, h->b_g2_inf, h->num_vars, h->delta_g2, 1, h->beta_g2, &pk->b_g2_query);
   rc = rc ? rc : pcdhip_bases_upload(ctx, cid, 1, h->h_query, h->h_inf, h->h_len, &pk->h_query);
-  rc = rc ? rc : upload_plus(1, h->l_query, h->l_inf, h->l_len, h->delta_g1, 2, &pk->l_query);           // -rs * delta
-  if (!rc) {
-    const size_t w1 = (size_t)pcdhip_point_limbs(cid, 1) * 8, w2 = (size_t)pcdhip_point_limbs(cid, 2) * 8;
-    const CurveEntry& ce = curve_entry(cid);
-    hipError_t e = hipMalloc(&pk->singles, ce.singles_bytes);
-    if (e == hipSuccess) e = ctx->aux_ws.ensure(AUX_MISC, ce.singles_abi_bytes);
-    char* d = (char*)ctx->aux_ws.buf[AUX_MISC];  // C-ABI staging
-    const uint64_t* g1s[5] = {h->alpha_g1, h->beta_g1, h->delta_g1, h->a_query, h->b_g1_query};
-    for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipMemcpyAsync(d + i * w1, g1s[i], w1, hipMemcpyHostToDevice, ctx->stream);
-    const uint64_t* g2s[3] = {h->beta_g2, h->delta_g2, h->b_g2_query};
-    for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipMemcpyAsync(d + 5 * w1 + i * w2, g2s[i], w2, hipMemcpyHostToDevice, ctx->stream);
-    // query[0] flagged infinite -> (0,0)
-    if (e == hipSuccess && h->a_inf && h->a_inf[0]) e = hipMemsetAsync(d + 3 * w1, 0, w1, ctx->stream);
-    if (e == hipSuccess && h->b_g1_inf && h->b_g1_inf[0]) e = hipMemsetAsync(d + 4 * w1, 0, w1, ctx->stream);
-    if (e == hipSuccess && h->b_g2_inf && h->b_g2_inf[0]) e = hipMemsetAsync(d + 5 * w1 + 2 * w2, 0, w2, ctx->stream);
-    if (e == hipSuccess) e = ce.singles_in(ctx->stream, (const uint32_t*)d, pk->singles);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) rc = fail(ctx, e);
-  }
+  rc = rc ? rc : upload_plus(1, h->l_query, h->l_inf, h->l_len, h->delta_g1, 2, nullptr, &pk->l_query);                 // -rs * delta
   if (rc) { pcdhip_g16_pk_free(ctx, pk); return rc; }
   *out = pk;
   return PCDHIP_OK;
@@ -688,7 +672,6 @@ void pcdhip_g16_pk_free(pcdhip_ctx* ctx, pcdhip_g16_pk* pk) {
   if (pk->r1cs_dev) (void)hipFree(pk->r1cs_dev);
   pcdhip_bases_free(ctx, pk->a_query); pcdhip_bases_free(ctx, pk->b_g1_query); pcdhip_bases_free(ctx, pk->b_g2_query);
   pcdhip_bases_free(ctx, pk->h_query); pcdhip_bases_free(ctx, pk->l_query);
-  if (pk->singles) (void)hipFree(pk->singles);
   delete pk;
 }
 
@@ -705,16 +688,24 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   hipEvent_t ev[8];
   for (auto& e : ev) TRY(hipEventCreate(&e));
   TRY(hipEventRecord(ev[0], st));
-  // z (C-ABI Montgomery) -> device image for the SpMV, and canonical words for the MSMs
+  // z (C-ABI Montgomery) -> device image for the SpMV; canonical words of z, s*z and r*z (each followed by its
+  // 4-entry tail, see inst_g16.hip) for the MSMs
   TRY(ctx->aux_ws.ensure(AUX_Z, m * fe.words * 4));
   TRY(ctx->aux_ws.ensure(AUX_SCAL, m * sb));
-  TRY(ctx->aux_ws.ensure(AUX_Z_CANON, (m + 4) * sb));  // assignment followed by the delta scalars [r, s, -rs]
+  TRY(ctx->aux_ws.ensure(AUX_Z_CANON, 3 * (m + 4) * sb + 2 * sb));
   uint32_t* z_dev = (uint32_t*)ctx->aux_ws.buf[AUX_Z];
   uint32_t* z_abi = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
   uint32_t* z_can = (uint32_t*)ctx->aux_ws.buf[AUX_Z_CANON];
+  uint32_t* sz_can = z_can + (m + 4) * sw;
+  uint32_t* rz_can = sz_can + (m + 4) * sw;
+  uint32_t* rs_dev = rz_can + (m + 4) * sw;  // r, s (C-ABI Montgomery)
   TRY(hipMemcpyAsync(z_abi, z, m * sb, hipMemcpyHostToDevice, st));
+  TRY(hipMemcpyAsync(rs_dev, r_mont, sb, hipMemcpyHostToDevice, st));
+  TRY(hipMemcpyAsync(rs_dev + sw, s_mont, sb, hipMemcpyHostToDevice, st));
   TRY(fe.convert(st, z_abi, z_dev, (uint32_t)m, 0));
-  TRY(fe.convert(st, z_abi, z_can, (uint32_t)m, 3));
+  TRY(fe.scale_canon(st, z_dev, nullptr, z_can, (uint32_t)m, 1));
+  TRY(fe.scale_canon(st, z_dev, rs_dev + sw, sz_can, (uint32_t)m, 1));
+  TRY(fe.scale_canon(st, z_dev, rs_dev, rz_can, (uint32_t)m, 1));
   // K1: h
   Dom dom;
   DevCsr mats[3];
@@ -731,27 +722,21 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   uint32_t* h_can = (uint32_t*)ctx->aux_ws.buf[AUX_H_CANON];
   TRY(fe.convert(st, (const uint32_t*)ctx->aux_ws.buf[AUX_A], h_can, (uint32_t)n, 2));
   TRY(hipEventRecord(ev[1], st));
-  // K3/K4: five MSMs, results stay on device (device image)
+  // K3/K4/K5: six concurrent MSMs (h, l', A, s*A, r*B_1 on G1; B on G2), results stay on device (device image)
   const GroupEntry& g1 = group_entry(cid, 1);
   const GroupEntry& g2 = group_entry(cid, 2);
   const size_t j1 = (size_t)g1.point_words / 2 * 3 * 4, j2 = (size_t)g2.point_words / 2 * 3 * 4;
   const CurveEntry& ce = curve_entry(cid);
-  TRY(ctx->aux_ws.ensure(AUX_G16, 4 * j1 + j2 + 2 * sb + ce.proof_abi_bytes + ce.assemble_scratch_bytes + 256));
+  TRY(ctx->aux_ws.ensure(AUX_G16, 5 * j1 + j2 + ce.proof_abi_bytes + 256));
   char* gbase = (char*)ctx->aux_ws.buf[AUX_G16];
   uint32_t* msm_g1 = (uint32_t*)gbase;
-  uint32_t* msm_g2 = (uint32_t*)(gbase + 4 * j1);
-  uint32_t* rs_dev = (uint32_t*)(gbase + 4 * j1 + j2);
-  uint32_t* proof_dev = (uint32_t*)(gbase + 4 * j1 + j2 + 2 * sb);
-  uint32_t* scratch = (uint32_t*)(gbase + 4 * j1 + j2 + 2 * sb + ce.proof_abi_bytes);
-  TRY(hipMemcpyAsync(rs_dev, r_mont, sb, hipMemcpyHostToDevice, st));
-  TRY(hipMemcpyAsync((char*)rs_dev + sb, s_mont, sb, hipMemcpyHostToDevice, st));
+  uint32_t* msm_g2 = (uint32_t*)(gbase + 5 * j1);
+  uint32_t* proof_dev = (uint32_t*)(gbase + 5 * j1 + j2);
   const size_t hl = std::min<size_t>(pk->h_query->n, n);
-  uint32_t* extra = z_can + m * sw;  // canonical [r, s, -rs] right after the assignment: the scalars of the delta slots
-  TRY(ce.prepare_scalars(st, rs_dev, extra));
-  // five concurrent MSMs
+  TRY(ce.prepare_scalars(st, rs_dev, z_can + m * sw, sz_can + m * sw, rz_can + m * sw));
   if (!ctx->g16_ready) {
     TRY(hipEventCreateWithFlags(&ctx->g16_ready, hipEventDisableTiming));
-    for (int k = 0; k < 5; k++) {
+    for (int k = 0; k < 6; k++) {
       TRY(hipStreamCreateWithFlags(&ctx->g16_streams[k], hipStreamNonBlocking));
       TRY(hipEventCreate(&ctx->g16_begin[k]));
       TRY(hipEventCreate(&ctx->g16_end[k]));
@@ -759,14 +744,15 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   }
   TRY(hipEventRecord(ctx->g16_ready, st));
   struct Job { const GroupEntry* ge; MsmBasesView bv; const uint32_t* sc; uint32_t n; uint32_t* out; };
-  const Job jobs[5] = {
-      {&g2, pk->b_g2_query->view(1), z_can + sw, (uint32_t)(m + 2), msm_g2},                       // heaviest first
-      {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, msm_g1},
-      {&g1, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni + 3), (uint32_t*)((char*)msm_g1 + j1)},
-      {&g1, pk->a_query->view(1), z_can + sw, (uint32_t)(m + 2), (uint32_t*)((char*)msm_g1 + 2 * j1)},
-      {&g1, pk->b_g1_query->view(1), z_can + sw, (uint32_t)(m + 2), (uint32_t*)((char*)msm_g1 + 3 * j1)},
+  const Job jobs[6] = {
+      {&g2, pk->b_g2_query->view(0), z_can, (uint32_t)(m + 4), msm_g2},                                      // B (heaviest first)
+      {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, msm_g1},                                              // h
+      {&g1, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni + 4), (uint32_t*)((char*)msm_g1 + j1)},  // l' (with -rs delta)
+      {&g1, pk->a_query->view(0), z_can, (uint32_t)(m + 4), (uint32_t*)((char*)msm_g1 + 2 * j1)},            // A
+      {&g1, pk->a_query->view(0), sz_can, (uint32_t)(m + 4), (uint32_t*)((char*)msm_g1 + 3 * j1)},           // s * A
+      {&g1, pk->b_g1_query->view(0), rz_can, (uint32_t)(m + 4), (uint32_t*)((char*)msm_g1 + 4 * j1)},        // r * B_1
   };
-  for (int k = 0; k < 5; k++) {
+  for (int k = 0; k < 6; k++) {
     hipStream_t sk = ctx->g16_streams[k];
     TRY(hipStreamWaitEvent(sk, ctx->g16_ready, 0));
     TRY(hipEventRecord(ctx->g16_begin[k], sk));
@@ -775,8 +761,8 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
     TRY(hipStreamWaitEvent(st, ctx->g16_end[k], 0));
   }
   TRY(hipEventRecord(ev[6], st));
-  // K5: assembly (writes the proof in the C-ABI image)
-  TRY(ce.assemble(st, msm_g1, msm_g2, pk->singles, rs_dev, scratch, proof_dev));
+  // assembly: three additions and three affine conversions (writes the proof in the C-ABI image)
+  TRY(ce.assemble(st, msm_g1, msm_g2, proof_dev));
   TRY(hipEventRecord(ev[7], st));
   TRY(hipMemcpyAsync(proof_out, proof_dev, ce.proof_abi_bytes, hipMemcpyDeviceToHost, st));
   TRY(hipStreamSynchronize(st));
@@ -789,10 +775,16 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
       inf_out[i] = (o == 0) ? 1 : 0;
     }
   }
-  // [witness_map, msm_h, msm_l, msm_a, msm_b_g1, msm_b_g2 (each on its own stream: they overlap), assembly, total]
+  // [witness_map, msm_h, msm_l, msm_a (A and s*A, the longer one), msm_b_g1 (r*B_1), msm_b_g2 (each on its own stream:
+  //  they overlap), assembly, total]
   (void)hipEventElapsedTime(&ctx->g16_ms[0], ev[0], ev[1]);
-  const int order[5] = {5, 1, 2, 3, 4};  // job k -> timing slot
-  for (int k = 0; k < 5; k++) (void)hipEventElapsedTime(&ctx->g16_ms[order[k]], ctx->g16_begin[k], ctx->g16_end[k]);
+  const int order[6] = {5, 1, 2, 3, 3, 4};  // job k -> timing slot
+  for (int k = 0; k < 8; k++) if (k >= 1 && k <= 5) ctx->g16_ms[k] = 0;
+  for (int k = 0; k < 6; k++) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->g16_begin[k], ctx->g16_end[k]);
+    ctx->g16_ms[order[k]] = std::max(ctx->g16_ms[order[k]], ms);
+  }
   (void)hipEventElapsedTime(&ctx->g16_ms[6], ev[6], ev[7]);
   (void)hipEventElapsedTime(&ctx->g16_ms[7], ev[0], ev[7]);
   for (auto& e : ev) (void)hipEventDestroy(e);

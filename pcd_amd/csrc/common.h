@@ -46,8 +46,8 @@ struct pcdhip_g16_pk {
   uint32_t rows;
   int curve_id;
   uint64_t num_vars, num_inputs, domain_size;
+  // a / b / l queries carry four trailing slots [delta_r, delta_s, delta_rs, vk point] (see inst_g16.hip)
   pcdhip_bases *a_query, *b_g1_query, *b_g2_query, *h_query, *l_query;
-  uint32_t* singles;  // device: alpha_g1, beta_g1, delta_g1, a0, b1_0 (G1 affine) then beta_g2, delta_g2, b2_0 (G2 affine)
 };
 struct pcdhip_ctx {
   int device;
@@ -56,9 +56,9 @@ struct pcdhip_ctx {
   pcd::MsmWorkspace aux_ws;  // fft ping-pong, witness-map vectors, groth16 scratch
   // the five MSMs of a Groth16 proof run concurrently, each on its own stream with its own workspace: the
   // latency-bound bucket-reduction tail of one overlaps the throughput-bound accumulation of the others
-  hipStream_t g16_streams[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  pcd::MsmWorkspace g16_ws[5];
-  hipEvent_t g16_ready = nullptr, g16_begin[5] = {nullptr}, g16_end[5] = {nullptr};
+  hipStream_t g16_streams[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  pcd::MsmWorkspace g16_ws[6];
+  hipEvent_t g16_ready = nullptr, g16_begin[6] = {nullptr}, g16_end[6] = {nullptr};
   std::map<uint64_t, pcd::FftTables> fft_tables;
   int msm_c = 0;
   uint32_t msm_chunk = 0;
@@ -118,21 +118,20 @@ struct FieldEntry {
   hipError_t (*mixed_run)(hipStream_t, const FftTables& t, const FftTables& t2, uint32_t* x, uint32_t* tmp, uint32_t m, int a,
                           int inverse, int coset);
   hipError_t (*mixed_mul_sub_divz)(hipStream_t, const FftTables& t, uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t n);
+  // out = canonical words of in[i] * k (k: ABI Montgomery element on the device, or null for 1); element 0 read as 1 if asked
+  hipError_t (*scale_canon)(hipStream_t, const uint32_t* in_internal, const uint32_t* k_abi, uint32_t* out, uint32_t n, int first_is_one);
 };
 const FieldEntry& field_entry(int field_id);
 
 // ---- per-curve entries (inst_g16.hip) --------------------------------------------------------------
 struct CurveEntry {
-  // out3 = canonical [r, s, -(r s)] from Montgomery (r, s) on device
-  hipError_t (*prepare_scalars)(hipStream_t, const uint32_t* rs_dev, uint32_t* out3);
-  // singles_abi (5 G1 + 3 G2 affine points, C-ABI image) -> device-internal image
-  hipError_t (*singles_in)(hipStream_t, const uint32_t* singles_abi, uint32_t* singles_internal);
-  size_t singles_abi_bytes, singles_bytes, proof_abi_bytes;
-  // msm_results: Jacobian points on device (internal image) in the order h, l, a, b_g1 (G1) and b_g2 (G2)
-  // singles: see pcdhip_g16_pk (internal);  rs: r, s Fr ABI Montgomery (device);  proof_out: C-ABI affine A || B || C
-  hipError_t (*assemble)(hipStream_t, const uint32_t* msm_g1, const uint32_t* msm_g2, const uint32_t* singles,
-                         const uint32_t* rs_dev, uint32_t* scratch, uint32_t* proof_out);
-  size_t assemble_scratch_bytes;
+  // three scalar tails of 4 canonical words-vectors each, from ABI Montgomery (r, s) on the device:
+  //   t1 = [r, s, -rs, 1]   ts = s * t1   tr = r * t1
+  hipError_t (*prepare_scalars)(hipStream_t, const uint32_t* rs_dev, uint32_t* t1, uint32_t* ts, uint32_t* tr);
+  size_t proof_abi_bytes;
+  // msm_g1: Jacobian points on device (internal image) in the order h, l', A, s*A, r*B1;  msm_g2: B (G2)
+  // proof_out: C-ABI affine A || B || C with C = s*A + r*B1 + l' + h
+  hipError_t (*assemble)(hipStream_t, const uint32_t* msm_g1, const uint32_t* msm_g2, uint32_t* proof_out);
 };
 const CurveEntry& curve_entry(int curve_id);
 

@@ -197,6 +197,22 @@ hipError_t mixed_mul_sub_divz(hipStream_t st, const FftTables& t, uint32_t* a, c
   return hipGetLastError();
 }
 
+// out[i] = canonical words of in[i] * k (in: device image, k: C-ABI Montgomery element on the device).  first_is_one:
+// element 0 is taken as 1 (the leading one of an R1CS assignment, whatever the caller stored there).
+__global__ void __launch_bounds__(256) scale_canon_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ k_abi,
+                                                          uint32_t* __restrict__ out, uint32_t n, int has_k, int first_is_one) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  FT v = (i == 0 && first_is_one) ? FT::one() : FT::load(in + (size_t)i * EW);
+  if (has_k) v = v * FT::from_abi(k_abi);
+  v.to_canonical_words(out + (size_t)i * FT::ABI_WORDS);
+}
+hipError_t scale_canon(hipStream_t st, const uint32_t* in, const uint32_t* k_abi, uint32_t* out, uint32_t n, int first_is_one) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(scale_canon_kernel, dim3((n + 255) / 256), dim3(256), 0, st, in, k_abi, out, n, k_abi ? 1 : 0, first_is_one);
+  return hipGetLastError();
+}
+
 hipError_t convert(hipStream_t st, const uint32_t* in, uint32_t* out, uint32_t n, int mode) {
   if (n == 0) return hipSuccess;
   dim3 gd((n + 255) / 256), bd(256);
@@ -245,7 +261,7 @@ hipError_t mul_sub_divz(hipStream_t st, const FftTables& t, uint32_t* a, const u
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const FieldEntry* PCD_CAT(pcd_field_entry_, PCD_FIELD_IDX)() {
   static const FieldEntry e = {EW, FT::ABI_WORDS, FT::Params::TWO_ADICITY, make_tables, run, convert, spmv, mul_sub_divz,
-                               mixed_make_tables, mixed_run, mixed_mul_sub_divz};
+                               mixed_make_tables, mixed_run, mixed_mul_sub_divz, scale_canon};
   return &e;
 }
 
