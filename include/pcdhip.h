@@ -165,6 +165,42 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
 /* Device time of the stages of the last prove, milliseconds:
  * [witness_map, msm_h, msm_l, msm_a, msm_b_g1, msm_b_g2, assembly, total]. */
 int pcdhip_groth16_last_timings(pcdhip_ctx* ctx, float out_ms[8]);
+/* How pcdhip_groth16_prove obtains the two variable-base products s*A and r*B_1 of upstream's assembly
+ * (ark-groth16 create_proof, reached from src/ec_cycle_pcd/mod.rs:171,179); the proof is the same either way:
+ *   0 (default) one-lane windowed products queued behind the A / B_1 MSMs on high-priority streams, hidden under the
+ *               longer MSMs (B in G2, h, l) of the same proof;
+ *   1           folded into two more MSMs over the a / b_g1 bases with every scalar multiplied by s / r. */
+int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode);
+
+/* ---- the caller side of the path -- key generation -------------------------------------
+ * Replaces ark-ec `FixedBaseMSM::{get_window_table, multi_scalar_mul}` + `batch_normalization_into_affine`:
+ * out[i] = scalars[i] * base as affine points (x||y Montgomery, flag).  This is the primitive every query of
+ * ark-groth16 `generate_parameters` is made of (reference call sites: circuit_specific_setup,
+ * src/ec_cycle_pcd/mod.rs:69,78) and the KZG powers of `universal_setup` (mod.rs:346-354). */
+int pcdhip_fixed_base_mul(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* base_xy_mont,
+                          const uint64_t* scalars_canonical, size_t n, uint64_t* out_xy_mont, uint8_t* out_inf);
+/* Replaces ark-groth16 `generate_parameters` (the body of `Groth16::circuit_specific_setup`, mod.rs:69,78) after
+ * constraint synthesis, with the caller's randomness: toxic = [alpha, beta, gamma, delta, tau] (5 scalar-field
+ * elements, Montgomery; tau must lie outside the evaluation domain, as upstream's
+ * `sample_element_outside_domain` guarantees -- PCDHIP_E_ARG otherwise) and the two group generators.
+ * QAP evaluation at tau (`instance_map_with_evaluation`: Lagrange coefficients, transposed mat-vecs) and every
+ * fixed-base batch run on the device.  All output arrays are caller-allocated:
+ * a / b_g1 / b_g2: num_vars points; gamma_abc_g1: num_inputs; l: num_vars - num_inputs;
+ * h: n - 1 with n = pcdhip_domain_size(scalar field, num_constraints + num_inputs) (also returned in domain_size). */
+typedef struct {
+  uint64_t *alpha_g1, *beta_g1, *delta_g1;   /* one G1 point each */
+  uint64_t *beta_g2, *gamma_g2, *delta_g2;   /* one G2 point each */
+  uint64_t* a_query;      uint8_t* a_inf;
+  uint64_t* b_g1_query;   uint8_t* b_g1_inf;
+  uint64_t* b_g2_query;   uint8_t* b_g2_inf;
+  uint64_t* h_query;      uint8_t* h_inf;
+  uint64_t* l_query;      uint8_t* l_inf;
+  uint64_t* gamma_abc_g1; uint8_t* gamma_abc_inf;
+  uint64_t domain_size;   /* out */
+} pcdhip_g16_setup_out;
+int pcdhip_groth16_setup(pcdhip_ctx* ctx, int curve_id, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C,
+                         size_t num_vars, size_t num_inputs, const uint64_t* g1_xy_mont, const uint64_t* g2_xy_mont,
+                         const uint64_t* toxic_mont, pcdhip_g16_setup_out* out);
 
 /* ---- K6: pairing ---------------------------------------------------------------------------------
  * Replaces ark-ec `PairingEngine::product_of_pairings`: gt_out = final_exponentiation(prod_i miller_loop(P_i, Q_i)),

@@ -105,6 +105,16 @@ def scalar_mul(curve, group, xy, scalar_canonical):
     return out
 
 
+def fixed_base_mul(curve, group, base_xy, scalars_canonical, nthreads=1):
+    """FixedBaseMSM::multi_scalar_mul + batch normalisation: (n affine points, flags)."""
+    sc = _u64(scalars_canonical).reshape(-1, FIELD_N64[CURVE_FR[curve]])
+    n = sc.shape[0]
+    out = np.zeros((n, point_words(curve, group)), dtype=np.uint64)
+    inf = np.zeros(n, dtype=np.uint8)
+    assert lib().orc_fixed_base_mul(curve, group, _p(_u64(base_xy)), _p(sc), C.c_size_t(n), nthreads, _p(out), _p(inf)) == 0
+    return out, inf
+
+
 def on_curve(curve, group, xy):
     return lib().orc_on_curve(curve, group, _p(_u64(xy))) == 1
 

@@ -3,6 +3,7 @@
 // (SNARK::prove -> Groth16 create_proof -> 4 G1 MSMs + 1 G2 MSM).  SURVEY.md Appendix A.4/A.5.
 // PARITY UNPINNED (see field.hpp / DESIGN.md); validated against oracle/pyoracle.py.
 #pragma once
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -153,6 +154,71 @@ Jac<F> msm_pippenger(const Group<F>& G, const Affine<F>* bases, const u64* scala
     for (int k = 0; k < c; k++) total = G.dbl(total);
   }
   return G.add(window_sums[0], total);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ark-ec `FixedBaseMSM` (fixed_base.rs): get_mul_window_size, get_window_table, windowed_mul, multi_scalar_mul, followed
+// by batch normalisation into affine -- what ark-groth16 `generate_parameters` (circuit_specific_setup,
+// src/ec_cycle_pcd/mod.rs:69,78) calls for every query of the key.  out[i] = k_i * g.
+inline int fixed_base_window(size_t n) { return n < 32 ? 3 : ln_without_floats(n); }
+
+template <class F>
+std::vector<Affine<F>> fixed_base_msm(const Group<F>& G, const Affine<F>& g, const u64* scalars, int NS, size_t n, int scalar_bits,
+                                      int nthreads) {
+  const int window = fixed_base_window(n);
+  const int outerc = (scalar_bits + window - 1) / window;
+  const size_t last_in_window = (size_t)1 << (scalar_bits - (outerc - 1) * window);
+  // table[outer][inner] = inner * 2^(window * outer) * g, normalised to affine
+  std::vector<std::vector<Affine<F>>> table(outerc);
+  Jac<F> g_outer = Jac<F>::from_affine(g);
+  std::vector<Jac<F>> g_outers(outerc);
+  for (int outer = 0; outer < outerc; outer++) {
+    g_outers[outer] = g_outer;
+    for (int k = 0; k < window; k++) g_outer = G.dbl(g_outer);
+  }
+  auto run = [&](size_t count, const std::function<void(size_t)>& fn) {
+    if (nthreads <= 1) { for (size_t i = 0; i < count; i++) fn(i); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back([&, t]() { for (size_t i = t; i < count; i += nthreads) fn(i); });
+    for (auto& x : th) x.join();
+  };
+  run(outerc, [&](size_t outer) {
+    const size_t cur = (outer == (size_t)outerc - 1) ? last_in_window : ((size_t)1 << window);
+    std::vector<Jac<F>> row(cur);
+    Jac<F> g_inner = Jac<F>::infinity();
+    for (size_t inner = 0; inner < cur; inner++) { row[inner] = g_inner; g_inner = G.add(g_inner, g_outers[outer]); }
+    // batch normalisation (Montgomery's trick over the non-zero Z)
+    table[outer].resize(cur);
+    std::vector<F> pre(cur);
+    F acc = F::one();
+    for (size_t i = 0; i < cur; i++) { pre[i] = acc; if (!row[i].is_inf()) acc = acc * row[i].Z; }
+    F inv = acc.inv();
+    for (size_t i = cur; i-- > 0;) {
+      if (row[i].is_inf()) { table[outer][i] = Affine<F>::infinity(); continue; }
+      F zi = inv * pre[i];
+      inv = inv * row[i].Z;
+      F zi2 = zi.sqr();
+      table[outer][i] = {row[i].X * zi2, row[i].Y * zi2 * zi, false};
+    }
+  });
+  std::vector<Affine<F>> out(n);
+  const size_t blocks = (n + 255) / 256;
+  run(blocks, [&](size_t blk) {
+    for (size_t i = blk * 256; i < std::min(n, blk * 256 + 256); i++) {
+      const u64* s = scalars + i * NS;
+      Jac<F> res = Jac<F>::infinity();
+      for (int outer = 0; outer < outerc; outer++) {
+        size_t inner = 0;
+        for (int b = 0; b < window; b++) {
+          const int bit = outer * window + b;
+          if (bit < scalar_bits && ((s[bit / 64] >> (bit % 64)) & 1)) inner |= (size_t)1 << b;
+        }
+        res = G.madd(res, table[outer][inner]);
+      }
+      out[i] = G.to_affine(res);
+    }
+  });
+  return out;
 }
 
 }  // namespace orc

@@ -210,20 +210,26 @@ struct G16 {
     K.alpha_g1 = mul1(alpha); K.beta_g1 = mul1(beta); K.delta_g1 = mul1(delta);
     K.beta_g2 = mul2(beta); K.delta_g2 = mul2(delta); K.gamma_g2 = mul2(gamma);
     Fr dinv = delta.inv(), ginv = gamma.inv();
-    K.a_query.resize(m); K.b_g1_query.resize(m); K.b_g2_query.resize(m);
-    K.h_query.resize(n - 1); K.l_query.resize(m - num_inputs); K.gamma_abc_g1.resize(num_inputs);
-    std::vector<Fr> tp(n - 1);
+    // every query is a fixed-base batch (ark-groth16 generate_parameters -> FixedBaseMSM::multi_scalar_mul)
+    std::vector<Fr> tp(n - 1), lt(m);
     { Fr cur = zt * dinv; for (size_t i = 0; i + 1 < n; i++) { tp[i] = cur; cur = cur * tau; } }
-    Radix2Domain<Fr>::parallel_for(m, nthreads, [&](size_t lo, size_t hi) {
-      for (size_t i = lo; i < hi; i++) {
-        K.a_query[i] = mul1(At[i]); K.b_g1_query[i] = mul1(Bt[i]); K.b_g2_query[i] = mul2(Bt[i]);
-        Fr t = beta * At[i] + alpha * Bt[i] + Ct[i];
-        if (i < num_inputs) K.gamma_abc_g1[i] = mul1(t * ginv); else K.l_query[i - num_inputs] = mul1(t * dinv);
-      }
-    });
-    Radix2Domain<Fr>::parallel_for(n - 1, nthreads, [&](size_t lo, size_t hi) {
-      for (size_t i = lo; i < hi; i++) K.h_query[i] = mul1(tp[i]);
-    });
+    for (size_t i = 0; i < m; i++) lt[i] = (beta * At[i] + alpha * Bt[i] + Ct[i]) * (i < num_inputs ? ginv : dinv);
+    auto batch1 = [&](const std::vector<Fr>& k) {
+      std::vector<u64> can(k.size() * NS);
+      for (size_t i = 0; i < k.size(); i++) k[i].to_canonical(&can[i * NS]);
+      return fixed_base_msm(G1, C::g1(), can.data(), NS, k.size(), Fr::Params::BITS, nthreads);
+    };
+    K.a_query = batch1(At);
+    K.b_g1_query = batch1(Bt);
+    {
+      std::vector<u64> can(m * NS);
+      for (size_t i = 0; i < m; i++) Bt[i].to_canonical(&can[i * NS]);
+      K.b_g2_query = fixed_base_msm(G2, C::g2(), can.data(), NS, m, Fr::Params::BITS, nthreads);
+    }
+    K.h_query = batch1(tp);
+    auto lq = batch1(lt);
+    K.gamma_abc_g1.assign(lq.begin(), lq.begin() + num_inputs);
+    K.l_query.assign(lq.begin() + num_inputs, lq.end());
     return K;
   }
 

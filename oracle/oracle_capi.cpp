@@ -207,6 +207,17 @@ int orc_scalar_mul(int curve, int group, const u64* xy, const u64* scalar_canoni
   return 0;
 }
 
+// FixedBaseMSM::multi_scalar_mul + batch normalisation (curve.hpp): out[i] = k_i * base, affine
+int orc_fixed_base_mul(int curve, int group, const u64* base_xy, const u64* scalars_canonical, size_t n, int nthreads, u64* out_xy,
+                       uint8_t* out_inf) {
+  DISPATCH_GROUP(curve, group, {
+    constexpr size_t EL = sizeof(F) / sizeof(u64);
+    auto pts = fixed_base_msm(G, load_affine1<F>(base_xy), scalars_canonical, C::Fr::N, n, C::Fr::Params::BITS, nthreads);
+    for (size_t i = 0; i < n; i++) store_affine(pts[i], out_xy + i * 2 * EL, out_inf + i);
+  });
+  return 0;
+}
+
 int orc_on_curve(int curve, int group, const u64* xy) {
   DISPATCH_GROUP(curve, group, {
     Affine<F> p = load_affine1<F>(xy);

@@ -47,7 +47,7 @@ EXPORTS = [
     "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config",
     "pcdhip_set_precompute", "pcdhip_msm_set_sort", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
-    "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings",
+    "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
     "pcdhip_multi_pairing", "pcdhip_groth16_verify", "pcdhip_timer_start", "pcdhip_timer_stop",
 ]
 
@@ -246,10 +246,49 @@ class Context:
                                                _p(_u64(r_mont)), _p(_u64(s_mont)), _p(proof), _p(inf)))
         return proof, inf
 
+    def groth16_set_assembly(self, mode):
+        """0: chained one-lane products s*A, r*B_1 overlapping the other MSMs (default); 1: folded into two extra MSMs."""
+        self._check(lib().pcdhip_groth16_set_assembly(self._ctx, int(mode)))
+
     def groth16_last_timings(self):
         out = (C.c_float * 8)()
         self._check(lib().pcdhip_groth16_last_timings(self._ctx, out))
         return dict(zip(["witness_map", "msm_h", "msm_l", "msm_a", "msm_b_g1", "msm_b_g2", "assembly", "total"], list(out)))
+
+    # ---- key generation (SURVEY.md 8f rank 2)
+    def fixed_base_mul(self, curve, group, base_xy, scalars_canonical):
+        """FixedBaseMSM::multi_scalar_mul + batch normalisation: (n affine points, n flags) = scalars[i] * base."""
+        sc = _u64(scalars_canonical).reshape(-1, FIELD_LIMBS[CURVE_FR[curve]])
+        n = sc.shape[0]
+        out = np.zeros((n, point_limbs(curve, group)), dtype=np.uint64)
+        inf = np.zeros(n, dtype=np.uint8)
+        self._check(lib().pcdhip_fixed_base_mul(self._ctx, curve, group, _p(_u64(base_xy)), _p(sc), C.c_size_t(n), _p(out), _p(inf)))
+        return out, inf
+
+    def groth16_setup(self, curve, r1cs, g1_xy, g2_xy, toxic_mont):
+        """ark-groth16 generate_parameters after synthesis (circuit_specific_setup, src/ec_cycle_pcd/mod.rs:69,78);
+        toxic_mont = (alpha, beta, gamma, delta, tau).  Returns a dict of arrays named like the key's fields."""
+        w1, w2 = point_limbs(curve, G1), point_limbs(curve, G2)
+        m, ni = r1cs.num_vars, r1cs.num_inputs
+        n = lib().pcdhip_domain_size(CURVE_FR[curve], C.c_size_t(r1cs.num_constraints + ni))
+        z64 = lambda *sh: np.zeros(sh, dtype=np.uint64)
+        z8 = lambda k: np.zeros(k, dtype=np.uint8)
+        K = dict(alpha_g1=z64(w1), beta_g1=z64(w1), delta_g1=z64(w1), beta_g2=z64(w2), gamma_g2=z64(w2), delta_g2=z64(w2),
+                 a_query=z64(m, w1), a_inf=z8(m), b_g1_query=z64(m, w1), b_g1_inf=z8(m), b_g2_query=z64(m, w2), b_g2_inf=z8(m),
+                 h_query=z64(max(n - 1, 0), w1), h_inf=z8(max(n - 1, 0)), l_query=z64(m - ni, w1), l_inf=z8(m - ni),
+                 gamma_abc_g1=z64(ni, w1), gamma_abc_inf=z8(ni))
+        out = G16SetupOut()
+        for name, _ in G16SetupOut._fields_:
+            if name != "domain_size":
+                setattr(out, name, K[name].ctypes.data if K[name].size else None)
+        A = self._csr(r1cs.rp_a, r1cs.col_a, r1cs.coeff_a)
+        B = self._csr(r1cs.rp_b, r1cs.col_b, r1cs.coeff_b)
+        Cm = self._csr(r1cs.rp_c, r1cs.col_c, r1cs.coeff_c)
+        self._check(lib().pcdhip_groth16_setup(self._ctx, curve, C.byref(A), C.byref(B), C.byref(Cm), C.c_size_t(m), C.c_size_t(ni),
+                                               _p(_u64(g1_xy)), _p(_u64(g2_xy)), _p(_u64(toxic_mont)), C.byref(out)))
+        assert out.domain_size == n
+        K["domain_size"] = n
+        return K
 
     # ---- pairing
     def multi_pairing(self, curve, g1_xy, g2_xy, g1_inf=None, g2_inf=None):
@@ -284,6 +323,13 @@ class Context:
         ms = C.c_float()
         self._check(lib().pcdhip_timer_stop(self._ctx, C.byref(ms)))
         return ms.value
+
+
+class G16SetupOut(C.Structure):
+    """Mirror of `pcdhip_g16_setup_out` (include/pcdhip.h)."""
+    _fields_ = [(k, C.c_void_p) for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "gamma_g2", "delta_g2", "a_query", "a_inf",
+                                          "b_g1_query", "b_g1_inf", "b_g2_query", "b_g2_inf", "h_query", "h_inf", "l_query", "l_inf",
+                                          "gamma_abc_g1", "gamma_abc_inf")] + [("domain_size", C.c_uint64)]
 
 
 class DeviceBuf:

@@ -68,7 +68,7 @@ int fail(pcdhip_ctx* ctx, hipError_t e) {
 #define BIND() do { hipError_t e_ = hipSetDevice(ctx->device); if (e_ != hipSuccess) return fail(ctx, e_); } while (0)
 
 enum { AUX_FFT_X = 0, AUX_FFT_TMP, AUX_A, AUX_B, AUX_C, AUX_Z, AUX_CSR_RP, AUX_CSR_COL, AUX_CSR_COEF, AUX_SCAL, AUX_OUT,
-       AUX_G16, AUX_Z_CANON, AUX_H_CANON, AUX_MISC };
+       AUX_G16, AUX_Z_CANON, AUX_H_CANON, AUX_MISC, AUX_FB_TABLE, AUX_FB_JAC, AUX_FB_OUT };
 
 // Evaluation domain as ark-poly `GeneralEvaluationDomain::new(min_size)` picks it: radix-2 when 2^ceil(log2 min_size)
 // fits the field's 2-adicity, otherwise the mixed-radix size 2^a q^b (b <= 2) of `best_mixed_domain_size`.
@@ -347,6 +347,11 @@ int pcdhip_msm_config(pcdhip_ctx* ctx, int window_bits, int chunk) {
 int pcdhip_msm_set_sort(pcdhip_ctx* ctx, int mode) {
   if (!ctx || mode < 0 || mode > 2) return PCDHIP_E_ARG;
   ctx->msm_sort = mode;
+  return PCDHIP_OK;
+}
+int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 1) return PCDHIP_E_ARG;
+  ctx->g16_assembly = mode;
   return PCDHIP_OK;
 }
 int pcdhip_msm_profile(pcdhip_ctx* ctx, int on) {
@@ -722,41 +727,60 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   uint32_t* h_can = (uint32_t*)ctx->aux_ws.buf[AUX_H_CANON];
   TRY(fe.convert(st, (const uint32_t*)ctx->aux_ws.buf[AUX_A], h_can, (uint32_t)n, 2));
   TRY(hipEventRecord(ev[1], st));
-  // K3/K4/K5: six concurrent MSMs (h, l', A, s*A, r*B_1 on G1; B on G2), results stay on device (device image)
+  // K3/K4/K5: concurrent MSMs (h, l', A, B_1 on G1; B on G2), results stay on device (device image).  The two
+  // variable-base products of the assembly, s*A and r*B_1, are either (assembly mode 0) one-lane products queued right
+  // behind the A / B_1 MSMs on their high-priority streams, where they overlap the longer MSMs, or (mode 1) two more
+  // MSMs over the same bases with every scalar scaled by s / r.
   const GroupEntry& g1 = group_entry(cid, 1);
   const GroupEntry& g2 = group_entry(cid, 2);
   const size_t j1 = (size_t)g1.point_words / 2 * 3 * 4, j2 = (size_t)g2.point_words / 2 * 3 * 4;
   const CurveEntry& ce = curve_entry(cid);
-  TRY(ctx->aux_ws.ensure(AUX_G16, 5 * j1 + j2 + ce.proof_abi_bytes + 256));
+  TRY(ctx->aux_ws.ensure(AUX_G16, 6 * j1 + j2 + 2 * 16 * j1 + ce.proof_abi_bytes + 256));
   char* gbase = (char*)ctx->aux_ws.buf[AUX_G16];
-  uint32_t* msm_g1 = (uint32_t*)gbase;
-  uint32_t* msm_g2 = (uint32_t*)(gbase + 5 * j1);
-  uint32_t* proof_dev = (uint32_t*)(gbase + 5 * j1 + j2);
+  uint32_t* msm_g1 = (uint32_t*)gbase;  // h, l', A, s*A, r*B_1, B_1
+  uint32_t* msm_g2 = (uint32_t*)(gbase + 6 * j1);
+  uint32_t* mul_scratch = (uint32_t*)(gbase + 6 * j1 + j2);
+  uint32_t* proof_dev = (uint32_t*)(gbase + 6 * j1 + j2 + 2 * 16 * j1);
+  auto slot = [&](int i) { return (uint32_t*)((char*)msm_g1 + i * j1); };
   const size_t hl = std::min<size_t>(pk->h_query->n, n);
-  TRY(ce.prepare_scalars(st, rs_dev, z_can + m * sw, sz_can + m * sw, rz_can + m * sw));
+  uint32_t* t1 = z_can + m * sw;  // [r, s, -rs, 1] canonical
+  TRY(ce.prepare_scalars(st, rs_dev, t1, sz_can + m * sw, rz_can + m * sw));
   if (!ctx->g16_ready) {
     TRY(hipEventCreateWithFlags(&ctx->g16_ready, hipEventDisableTiming));
+    int least = 0, greatest = 0;
+    TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
     for (int k = 0; k < 6; k++) {
-      TRY(hipStreamCreateWithFlags(&ctx->g16_streams[k], hipStreamNonBlocking));
+      TRY(hipStreamCreateWithPriority(&ctx->g16_streams[k], hipStreamNonBlocking, k < 2 ? greatest : k == 2 ? (least + greatest) / 2 : least));
       TRY(hipEventCreate(&ctx->g16_begin[k]));
       TRY(hipEventCreate(&ctx->g16_end[k]));
     }
   }
   TRY(hipEventRecord(ctx->g16_ready, st));
-  struct Job { const GroupEntry* ge; MsmBasesView bv; const uint32_t* sc; uint32_t n; uint32_t* out; };
-  const Job jobs[6] = {
-      {&g2, pk->b_g2_query->view(0), z_can, (uint32_t)(m + 4), msm_g2},                                      // B (heaviest first)
-      {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, msm_g1},                                              // h
-      {&g1, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni + 4), (uint32_t*)((char*)msm_g1 + j1)},  // l' (with -rs delta)
-      {&g1, pk->a_query->view(0), z_can, (uint32_t)(m + 4), (uint32_t*)((char*)msm_g1 + 2 * j1)},            // A
-      {&g1, pk->a_query->view(0), sz_can, (uint32_t)(m + 4), (uint32_t*)((char*)msm_g1 + 3 * j1)},           // s * A
-      {&g1, pk->b_g1_query->view(0), rz_can, (uint32_t)(m + 4), (uint32_t*)((char*)msm_g1 + 4 * j1)},        // r * B_1
-  };
-  for (int k = 0; k < 6; k++) {
+  struct Job { const GroupEntry* ge; MsmBasesView bv; const uint32_t* sc; uint32_t n; uint32_t* out; int tslot; const uint32_t* k; uint32_t* kout; };
+  const uint32_t mt = (uint32_t)(m + 4);
+  const bool folded = ctx->g16_assembly == 1;
+  Job jobs[6];
+  int nj = 0;
+  if (folded) {
+    jobs[nj++] = {&g2, pk->b_g2_query->view(0), z_can, mt, msm_g2, 5, nullptr, nullptr};                       // B (heaviest: high priority)
+    jobs[nj++] = {&g1, pk->a_query->view(0), z_can, mt, slot(2), 3, nullptr, nullptr};                         // A
+    jobs[nj++] = {&g1, pk->a_query->view(0), sz_can, mt, slot(3), 3, nullptr, nullptr};                        // s * A
+    jobs[nj++] = {&g1, pk->b_g1_query->view(0), rz_can, mt, slot(4), 4, nullptr, nullptr};                     // r * B_1
+    jobs[nj++] = {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, slot(0), 1, nullptr, nullptr};               // h
+    jobs[nj++] = {&g1, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni + 4), slot(1), 2, nullptr, nullptr};  // l' (with -rs delta)
+  } else {
+    jobs[nj++] = {&g1, pk->a_query->view(0), z_can, mt, slot(2), 3, t1 + sw, slot(3)};                         // A, then s * A
+    jobs[nj++] = {&g1, pk->b_g1_query->view(0), z_can, mt, slot(5), 4, t1, slot(4)};                           // B_1, then r * B_1
+    jobs[nj++] = {&g2, pk->b_g2_query->view(0), z_can, mt, msm_g2, 5, nullptr, nullptr};                       // B
+    jobs[nj++] = {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, slot(0), 1, nullptr, nullptr};               // h
+    jobs[nj++] = {&g1, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni + 4), slot(1), 2, nullptr, nullptr};  // l'
+  }
+  for (int k = 0; k < nj; k++) {
     hipStream_t sk = ctx->g16_streams[k];
     TRY(hipStreamWaitEvent(sk, ctx->g16_ready, 0));
     TRY(hipEventRecord(ctx->g16_begin[k], sk));
     TRY(jobs[k].ge->msm(ctx->g16_ws[k], sk, jobs[k].bv, jobs[k].sc, jobs[k].n, jobs[k].out, ctx->msm_c, ctx->msm_chunk, ctx->msm_sort, nullptr));
+    if (jobs[k].k) TRY(ce.scale_g1(sk, jobs[k].out, jobs[k].k, mul_scratch + (size_t)k * 16 * (j1 / 4), jobs[k].kout));
     TRY(hipEventRecord(ctx->g16_end[k], sk));
     TRY(hipStreamWaitEvent(st, ctx->g16_end[k], 0));
   }
@@ -775,21 +799,204 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
       inf_out[i] = (o == 0) ? 1 : 0;
     }
   }
-  // [witness_map, msm_h, msm_l, msm_a (A and s*A, the longer one), msm_b_g1 (r*B_1), msm_b_g2 (each on its own stream:
-  //  they overlap), assembly, total]
+  // [witness_map, msm_h, msm_l, msm_a (A and s*A), msm_b_g1 (B_1 and r*B_1), msm_b_g2 (each on its own stream: they
+  //  overlap), assembly, total]
   (void)hipEventElapsedTime(&ctx->g16_ms[0], ev[0], ev[1]);
-  const int order[6] = {5, 1, 2, 3, 3, 4};  // job k -> timing slot
-  for (int k = 0; k < 8; k++) if (k >= 1 && k <= 5) ctx->g16_ms[k] = 0;
-  for (int k = 0; k < 6; k++) {
+  for (int k = 1; k <= 5; k++) ctx->g16_ms[k] = 0;
+  for (int k = 0; k < nj; k++) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->g16_begin[k], ctx->g16_end[k]);
-    ctx->g16_ms[order[k]] = std::max(ctx->g16_ms[order[k]], ms);
+    ctx->g16_ms[jobs[k].tslot] = std::max(ctx->g16_ms[jobs[k].tslot], ms);
   }
   (void)hipEventElapsedTime(&ctx->g16_ms[6], ev[6], ev[7]);
   (void)hipEventElapsedTime(&ctx->g16_ms[7], ev[0], ev[7]);
   for (auto& e : ev) (void)hipEventDestroy(e);
   return PCDHIP_OK;
 }
+// ------------------------------------------------------------------------------------------------ fixed-base batches, setup
+namespace {
+// out (device, AUX_FB_OUT): n affine points in the C-ABI image followed by n flag bytes; scalars canonical words on the device
+int fixed_base_dev(pcdhip_ctx* ctx, const GroupEntry& ge, const uint32_t* base_abi_dev, const uint32_t* scalars_dev, size_t n,
+                   uint32_t** out_pts, uint8_t** out_inf) {
+  const size_t ab = (size_t)ge.point_abi_words * 4, jb = (size_t)ge.point_words / 2 * 3 * 4;
+  TRY(ctx->aux_ws.ensure(AUX_FB_TABLE, ge.fb_table_words * 4));
+  TRY(ctx->aux_ws.ensure(AUX_FB_JAC, std::max<size_t>(n, 1) * jb));
+  TRY(ctx->aux_ws.ensure(AUX_FB_OUT, std::max<size_t>(n, 1) * (ab + 1) + 64));
+  *out_pts = (uint32_t*)ctx->aux_ws.buf[AUX_FB_OUT];
+  *out_inf = (uint8_t*)ctx->aux_ws.buf[AUX_FB_OUT] + n * ab;
+  TRY(ge.fixed_base(ctx->stream, base_abi_dev, scalars_dev, (uint32_t)n, (uint32_t*)ctx->aux_ws.buf[AUX_FB_TABLE],
+                    (uint32_t*)ctx->aux_ws.buf[AUX_FB_JAC], *out_pts, *out_inf));
+  return PCDHIP_OK;
+}
+}  // namespace
+
+int pcdhip_fixed_base_mul(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* base_xy, const uint64_t* scalars, size_t n,
+                          uint64_t* out_xy, uint8_t* out_inf) {
+  if (!ctx || !valid_curve(curve_id) || !valid_group(group_id) || !base_xy || (n && (!scalars || !out_xy || !out_inf)) || (n >> 31))
+    return PCDHIP_E_ARG;
+  BIND();
+  const GroupEntry& ge = group_entry(curve_id, group_id);
+  const size_t ab = (size_t)ge.point_abi_words * 4, sb = (size_t)ge.scalar_words * 4;
+  TRY(ctx->aux_ws.ensure(AUX_SCAL, n * sb + ab + 64));
+  uint32_t* sc = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
+  uint32_t* base_dev = (uint32_t*)((char*)sc + (n * sb + 63) / 64 * 64);
+  TRY(ctx->aux_ws.ensure(AUX_SCAL, (n * sb + 63) / 64 * 64 + ab));
+  sc = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
+  base_dev = (uint32_t*)((char*)sc + (n * sb + 63) / 64 * 64);
+  if (n) TRY(hipMemcpyAsync(sc, scalars, n * sb, hipMemcpyHostToDevice, ctx->stream));
+  TRY(hipMemcpyAsync(base_dev, base_xy, ab, hipMemcpyHostToDevice, ctx->stream));
+  uint32_t* pts;
+  uint8_t* inf;
+  int rc = fixed_base_dev(ctx, ge, base_dev, sc, n, &pts, &inf);
+  if (rc) return rc;
+  if (n) {
+    TRY(hipMemcpyAsync(out_xy, pts, n * ab, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(hipMemcpyAsync(out_inf, inf, n, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  TRY(hipStreamSynchronize(ctx->stream));
+  return PCDHIP_OK;
+}
+
+namespace {
+// transpose of a CSR matrix with `cols` columns, as CSR (host side: an index permutation, no field arithmetic)
+struct HostCsrT {
+  std::vector<uint64_t> rp;
+  std::vector<uint32_t> col;
+  std::vector<uint64_t> coeff;
+  pcdhip_csr view;
+};
+int transpose_csr(const pcdhip_csr* m, size_t cols, size_t limbs, HostCsrT* t) {
+  if (!m || !m->row_ptr) return PCDHIP_E_ARG;
+  const uint64_t nnz = m->row_ptr[m->num_rows];
+  if (nnz && (!m->col || !m->coeff)) return PCDHIP_E_ARG;
+  t->rp.assign(cols + 1, 0);
+  for (uint64_t k = 0; k < nnz; k++) {
+    if (m->col[k] >= cols) return PCDHIP_E_ARG;
+    t->rp[m->col[k] + 1]++;
+  }
+  for (size_t c = 0; c < cols; c++) t->rp[c + 1] += t->rp[c];
+  t->col.resize(nnz);
+  t->coeff.resize(nnz * limbs);
+  std::vector<uint64_t> fill(t->rp.begin(), t->rp.end() - 1);
+  for (uint64_t r = 0; r < m->num_rows; r++)
+    for (uint64_t k = m->row_ptr[r]; k < m->row_ptr[r + 1]; k++) {
+      const uint64_t d = fill[m->col[k]]++;
+      t->col[d] = (uint32_t)r;
+      memcpy(&t->coeff[d * limbs], m->coeff + k * limbs, limbs * 8);
+    }
+  t->view = {cols, t->rp.data(), t->col.data(), t->coeff.data()};
+  return PCDHIP_OK;
+}
+}  // namespace
+
+int pcdhip_groth16_setup(pcdhip_ctx* ctx, int curve_id, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C, size_t num_vars,
+                         size_t num_inputs, const uint64_t* g1_xy, const uint64_t* g2_xy, const uint64_t* toxic, pcdhip_g16_setup_out* out) {
+  if (!ctx || !valid_curve(curve_id) || !A || !B || !C || !g1_xy || !g2_xy || !toxic || !out) return PCDHIP_E_ARG;
+  if (num_inputs < 1 || num_inputs > num_vars || (num_vars >> 31) || A->num_rows != B->num_rows || A->num_rows != C->num_rows) return PCDHIP_E_ARG;
+  if (!out->alpha_g1 || !out->beta_g1 || !out->delta_g1 || !out->beta_g2 || !out->gamma_g2 || !out->delta_g2 || !out->a_query ||
+      !out->a_inf || !out->b_g1_query || !out->b_g1_inf || !out->b_g2_query || !out->b_g2_inf || !out->gamma_abc_g1 || !out->gamma_abc_inf)
+    return PCDHIP_E_ARG;
+  BIND();
+  const int fr = kCurveFr[curve_id];
+  const FieldEntry& fe = field_entry(fr);
+  const size_t m = num_vars, ni = num_inputs, nc = A->num_rows, limbs = (size_t)kFieldLimbs[fr];
+  if (m > ni && (!out->l_query || !out->l_inf)) return PCDHIP_E_ARG;
+  Dom d;
+  int rc = pick_domain(fr, nc + ni, &d);
+  if (rc) return rc;
+  const size_t n = d.n;
+  if (n > 1 && (!out->h_query || !out->h_inf)) return PCDHIP_E_ARG;
+  hipStream_t st = ctx->stream;
+  const size_t sb = (size_t)fe.abi_words * 4, eb = (size_t)fe.words * 4;
+  // domain constants (generator, 1/n): the tables of the transforms over the same domain
+  const FftTables* t;
+  rc = d.m == 1 ? get_tables(ctx, fr, d.a, &t) : get_mixed_tables(ctx, fr, d, &t);
+  if (rc) return rc;
+  // scalars:  G1 [a (m) | b (m) | gamma_abc, l (m) | h (n - 1) | alpha, beta, delta]   G2 [b (m) | beta, gamma, delta]
+  const size_t n1 = 3 * m + (n - 1) + 3, n2 = m + 3;
+  TRY(ctx->aux_ws.ensure(AUX_FFT_X, n * eb));
+  TRY(ctx->aux_ws.ensure(AUX_A, m * eb));
+  TRY(ctx->aux_ws.ensure(AUX_B, m * eb));
+  TRY(ctx->aux_ws.ensure(AUX_C, m * eb));
+  TRY(ctx->aux_ws.ensure(AUX_Z_CANON, n1 * sb));
+  TRY(ctx->aux_ws.ensure(AUX_H_CANON, n2 * sb));
+  const GroupEntry& g1 = group_entry(curve_id, 1);
+  const GroupEntry& g2 = group_entry(curve_id, 2);
+  const size_t a1 = (size_t)g1.point_abi_words * 4, a2 = (size_t)g2.point_abi_words * 4;
+  TRY(ctx->aux_ws.ensure(AUX_Z, 5 * sb + (size_t)fe.setup_consts * eb + a1 + a2 + 256));
+  uint32_t* toxic_dev = (uint32_t*)ctx->aux_ws.buf[AUX_Z];
+  uint32_t* consts_dev = toxic_dev + 5 * fe.abi_words;
+  uint32_t* err_dev = consts_dev + (size_t)fe.setup_consts * fe.words;
+  uint32_t* g1_dev = err_dev + 16;
+  uint32_t* g2_dev = g1_dev + g1.point_abi_words;
+  uint32_t* u = (uint32_t*)ctx->aux_ws.buf[AUX_FFT_X];
+  uint32_t *at = (uint32_t*)ctx->aux_ws.buf[AUX_A], *bt = (uint32_t*)ctx->aux_ws.buf[AUX_B], *ct = (uint32_t*)ctx->aux_ws.buf[AUX_C];
+  uint32_t* s1 = (uint32_t*)ctx->aux_ws.buf[AUX_Z_CANON];
+  uint32_t* s2 = (uint32_t*)ctx->aux_ws.buf[AUX_H_CANON];
+  TRY(hipMemcpyAsync(toxic_dev, toxic, 5 * sb, hipMemcpyHostToDevice, st));
+  TRY(hipMemcpyAsync(g1_dev, g1_xy, a1, hipMemcpyHostToDevice, st));
+  TRY(hipMemcpyAsync(g2_dev, g2_xy, a2, hipMemcpyHostToDevice, st));
+  TRY(hipMemsetAsync(err_dev, 0, 4, st));
+  TRY(fe.setup_scalars(st, t->consts, toxic_dev, (uint32_t)n, (uint32_t)nc, (uint32_t)m, (uint32_t)ni, nullptr, nullptr, nullptr, u, consts_dev,
+                       err_dev, nullptr, nullptr, nullptr, nullptr, nullptr, 0));
+  // At, Bt, Ct: a_i(tau) = sum_j A[j][i] u_j  -- the transposed matrices times u
+  const pcdhip_csr* ms[3] = {A, B, C};
+  uint32_t* vecs[3] = {at, bt, ct};
+  for (int k = 0; k < 3; k++) {
+    HostCsrT tr;
+    rc = transpose_csr(ms[k], m, limbs, &tr);
+    if (rc) return rc;
+    DevCsr dm;
+    rc = upload_csr(ctx, AUX_CSR_RP, &tr.view, fe, &dm);
+    if (rc) return rc;
+    TRY(fe.spmv(st, dm.rp, dm.col, dm.coeff, dm.rows, u, 0, 0, (uint32_t)m, vecs[k]));
+    TRY(hipStreamSynchronize(st));  // `tr` and the staging slot are reused by the next matrix
+  }
+  uint32_t err = 0;
+  TRY(hipMemcpyAsync(&err, err_dev, 4, hipMemcpyDeviceToHost, st));
+  TRY(hipStreamSynchronize(st));
+  if (err) return PCDHIP_E_ARG;  // tau lies in the evaluation domain
+  TRY(fe.setup_scalars(st, t->consts, toxic_dev, (uint32_t)n, (uint32_t)nc, (uint32_t)m, (uint32_t)ni, at, bt, ct, u, consts_dev, err_dev, s1,
+                       s1 + m * fe.abi_words, s1 + 2 * m * fe.abi_words, s1 + 3 * m * fe.abi_words, s2, 1));
+  // alpha, beta, delta | beta, gamma, delta: C-ABI Montgomery -> canonical
+  uint32_t* tail1 = s1 + (3 * m + (n - 1)) * fe.abi_words;
+  uint32_t* tail2 = s2 + m * fe.abi_words;
+  const int idx1[3] = {0, 1, 3}, idx2[3] = {1, 2, 3};
+  for (int k = 0; k < 3; k++) {
+    TRY(fe.convert(st, toxic_dev + idx1[k] * fe.abi_words, tail1 + k * fe.abi_words, 1, 3));
+    TRY(fe.convert(st, toxic_dev + idx2[k] * fe.abi_words, tail2 + k * fe.abi_words, 1, 3));
+  }
+  // the fixed-base batches, then scatter into the caller's arrays
+  uint32_t* pts;
+  uint8_t* inf;
+  rc = fixed_base_dev(ctx, g1, g1_dev, s1, n1, &pts, &inf);
+  if (rc) return rc;
+  auto fetch = [&](uint64_t* dst, uint8_t* dst_inf, size_t first, size_t cnt, size_t ab) -> hipError_t {
+    if (!cnt) return hipSuccess;
+    hipError_t e = hipMemcpyAsync(dst, (char*)pts + first * ab, cnt * ab, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && dst_inf) e = hipMemcpyAsync(dst_inf, inf + first, cnt, hipMemcpyDeviceToHost, st);
+    return e;
+  };
+  TRY(fetch(out->a_query, out->a_inf, 0, m, a1));
+  TRY(fetch(out->b_g1_query, out->b_g1_inf, m, m, a1));
+  TRY(fetch(out->gamma_abc_g1, out->gamma_abc_inf, 2 * m, ni, a1));
+  TRY(fetch(out->l_query, out->l_inf, 2 * m + ni, m - ni, a1));
+  TRY(fetch(out->h_query, out->h_inf, 3 * m, n - 1, a1));
+  TRY(fetch(out->alpha_g1, nullptr, 3 * m + n - 1, 1, a1));
+  TRY(fetch(out->beta_g1, nullptr, 3 * m + n, 1, a1));
+  TRY(fetch(out->delta_g1, nullptr, 3 * m + n + 1, 1, a1));
+  TRY(hipStreamSynchronize(st));
+  rc = fixed_base_dev(ctx, g2, g2_dev, s2, n2, &pts, &inf);
+  if (rc) return rc;
+  TRY(fetch(out->b_g2_query, out->b_g2_inf, 0, m, a2));
+  TRY(fetch(out->beta_g2, nullptr, m, 1, a2));
+  TRY(fetch(out->gamma_g2, nullptr, m + 1, 1, a2));
+  TRY(fetch(out->delta_g2, nullptr, m + 2, 1, a2));
+  TRY(hipStreamSynchronize(st));
+  out->domain_size = n;
+  return PCDHIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ pairing
 int pcdhip_multi_pairing(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy,
                          const uint8_t* g2_inf, size_t n_pairs, uint64_t* gt_out) {

@@ -54,8 +54,9 @@ struct pcdhip_ctx {
   hipStream_t stream;
   pcd::MsmWorkspace msm_ws;
   pcd::MsmWorkspace aux_ws;  // fft ping-pong, witness-map vectors, groth16 scratch
-  // the five MSMs of a Groth16 proof run concurrently, each on its own stream with its own workspace: the
-  // latency-bound bucket-reduction tail of one overlaps the throughput-bound accumulation of the others
+  // the MSMs of a Groth16 proof run concurrently, each on its own stream with its own workspace: the
+  // latency-bound bucket-reduction tail of one overlaps the throughput-bound accumulation of the others.
+  // Streams 0 and 1 are created with the highest priority, 2 with the default one, 3..5 with the lowest.
   hipStream_t g16_streams[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   pcd::MsmWorkspace g16_ws[6];
   hipEvent_t g16_ready = nullptr, g16_begin[6] = {nullptr}, g16_end[6] = {nullptr};
@@ -69,6 +70,7 @@ struct pcdhip_ctx {
   float fft_ms[8] = {0};
   int fft_passes = 0;
   float g16_ms[8] = {0};
+  int g16_assembly = 0;  // s*A and r*B_1: 0 chained one-lane products overlapping the other MSMs, 1 folded into two extra MSMs
   hipEvent_t t0 = nullptr, t1 = nullptr;
   std::string last_hip_error;
 };
@@ -92,6 +94,11 @@ struct GroupEntry {
   hipError_t (*jac_out)(hipStream_t, const uint32_t* internal_dev, uint32_t n, uint32_t* abi_dev);   // Jacobian, internal -> ABI
   PointsSumFn points_sum;  // ABI in, ABI out
   ToAffineFn to_affine;    // ABI in, ABI out
+  // out[i] = k_i * base (fixed_base.cuh): base / out in the C-ABI affine image, scalars canonical words; scratch sizes in
+  // u32 words: fb_table_words (window table + per-window powers), 3/2 * point_words per scalar for the Jacobian results
+  size_t fb_table_words;
+  hipError_t (*fixed_base)(hipStream_t, const uint32_t* base_abi, const uint32_t* scalars, uint32_t n, uint32_t* table_scratch,
+                           uint32_t* jac_scratch, uint32_t* out_abi, uint8_t* out_inf);
 };
 const GroupEntry& group_entry(int curve_id, int group_id);  // group_id 1 / 2
 
@@ -120,6 +127,14 @@ struct FieldEntry {
   hipError_t (*mixed_mul_sub_divz)(hipStream_t, const FftTables& t, uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t n);
   // out = canonical words of in[i] * k (k: ABI Montgomery element on the device, or null for 1); element 0 read as 1 if asked
   hipError_t (*scale_canon)(hipStream_t, const uint32_t* in_internal, const uint32_t* k_abi, uint32_t* out, uint32_t n, int first_is_one);
+  // Groth16 generator scalars (inst_field.hip): phase 0 writes the Lagrange coefficients u (n elements) at tau and the
+  // constants block (setup_consts elements); phase 1 turns the transposed mat-vecs At, Bt, Ct (m elements) into the canonical
+  // scalars of the a / b / (gamma_abc | l) / h queries.  domain_consts = FftTables::consts of the domain.
+  int setup_consts;
+  hipError_t (*setup_scalars)(hipStream_t, const void* domain_consts, const uint32_t* toxic_abi, uint32_t n, uint32_t nc, uint32_t m,
+                              uint32_t ni, const uint32_t* at, const uint32_t* bt, const uint32_t* ct, uint32_t* u, uint32_t* consts_dev,
+                              uint32_t* err_dev, uint32_t* a_can, uint32_t* b_can, uint32_t* t_can, uint32_t* h_can, uint32_t* b2_can,
+                              int phase);
 };
 const FieldEntry& field_entry(int field_id);
 
@@ -132,6 +147,8 @@ struct CurveEntry {
   // msm_g1: Jacobian points on device (internal image) in the order h, l', A, s*A, r*B1;  msm_g2: B (G2)
   // proof_out: C-ABI affine A || B || C with C = s*A + r*B1 + l' + h
   hipError_t (*assemble)(hipStream_t, const uint32_t* msm_g1, const uint32_t* msm_g2, uint32_t* proof_out);
+  // out = k * in for one G1 point (device image; k canonical words); one lane, meant to overlap other work
+  hipError_t (*scale_g1)(hipStream_t, const uint32_t* in, const uint32_t* k, uint32_t* scratch, uint32_t* out);
 };
 const CurveEntry& curve_entry(int curve_id);
 

@@ -158,6 +158,21 @@ struct EC {
     }
     return r;
   }
+  // the same product with a fixed 4-bit window (one lane: 14 group operations for the table, then 4 doublings and at
+  // most one addition per nibble, leading zero nibbles skipped); `table` = 15 caller-provided Jacobian slots
+  PCD_HD static J mul_w4(const J& p, const uint32_t* k, int nwords, J* table) {
+    table[0] = p;
+    for (int i = 1; i < 15; i++) table[i] = (i & 1) ? dbl(table[i >> 1]) : add(table[i - 1], p);
+    int top = nwords * 8 - 1;
+    while (top >= 0 && ((k[top >> 3] >> ((top & 7) * 4)) & 15) == 0) top--;
+    J r = J::infinity();
+    for (int i = top; i >= 0; i--) {
+      if (i != top) { r = dbl(r); r = dbl(r); r = dbl(r); r = dbl(r); }
+      const uint32_t nib = (k[i >> 3] >> ((i & 7) * 4)) & 15;
+      if (nib) r = (i == top) ? table[nib - 1] : add(r, table[nib - 1]);
+    }
+    return r;
+  }
 };
 
 }  // namespace pcd

@@ -255,13 +255,110 @@ hipError_t mul_sub_divz(hipStream_t st, const FftTables& t, uint32_t* a, const u
   return hipGetLastError();
 }
 
+// ---- Groth16 generator scalars (ark-groth16 `generate_parameters` -> `R1CSToQAP::instance_map_with_evaluation`, reached
+// from the reference through circuit_specific_setup, src/ec_cycle_pcd/mod.rs:69,78): SURVEY.md 8(f) rank 2.
+// toxic = [alpha, beta, gamma, delta, tau] (C-ABI Montgomery, on the device).
+// consts (device image): [0] Z(tau)/n  [1] 1/delta  [2] 1/gamma  [3] Z(tau)/delta  [4] alpha  [5] beta  [6] tau
+constexpr int SETUP_CONSTS = 7;
+__global__ void setup_consts_kernel(const uint32_t* __restrict__ toxic, uint32_t n, FT ninv, uint32_t* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  constexpr int AW = FT::ABI_WORDS;
+  const FT alpha = FT::from_abi(toxic), beta = FT::from_abi(toxic + AW), gamma = FT::from_abi(toxic + 2 * AW);
+  const FT delta = FT::from_abi(toxic + 3 * AW), tau = FT::from_abi(toxic + 4 * AW);
+  const FT zt = tau.pow_u64(n) - FT::one();
+  const FT dinv = delta.inv();
+  (zt * ninv).store(out);
+  dinv.store(out + EW);
+  gamma.inv().store(out + 2 * EW);
+  (zt * dinv).store(out + 3 * EW);
+  alpha.store(out + 4 * EW);
+  beta.store(out + 5 * EW);
+  tau.store(out + 6 * EW);
+}
+// u[i] = L_i(tau) = Z(tau) w^i / (n (tau - w^i)): `evaluate_all_lagrange_coefficients`; LAGRANGE_BATCH consecutive i per
+// lane share one inversion.  tau inside the domain (upstream samples it outside) raises *err.
+constexpr int LAGRANGE_BATCH = 8;
+__global__ void __launch_bounds__(256) setup_lagrange_kernel(const uint32_t* __restrict__ consts, FT w, uint32_t n, uint32_t* __restrict__ u,
+                                                             uint32_t* __restrict__ err) {
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t lo = (uint64_t)lane * LAGRANGE_BATCH;
+  if (lo >= n) return;
+  const int cnt = (int)((n - lo) < (uint64_t)LAGRANGE_BATCH ? (n - lo) : (uint64_t)LAGRANGE_BATCH);
+  const FT scale = FT::load(consts), tau = FT::load(consts + 6 * EW);
+  FT pre[LAGRANGE_BATCH], den[LAGRANGE_BATCH];
+  FT wi = w.pow_u64(lo), run = FT::one();
+  const FT w0 = wi;
+  for (int k = 0; k < cnt; k++) {
+    den[k] = tau - wi;
+    if (den[k].is_zero()) { atomicOr(err, 1u); den[k] = FT::one(); }
+    pre[k] = run;
+    run = run * den[k];
+    wi = wi * w;
+  }
+  FT inv = run.inv();
+  // w^(lo + k) again, from the top: wi / w = w^(lo + cnt - 1)
+  FT wk[LAGRANGE_BATCH];
+  wi = w0;
+  for (int k = 0; k < cnt; k++) { wk[k] = wi; wi = wi * w; }
+  for (int k = cnt - 1; k >= 0; k--) {
+    const FT di = inv * pre[k];
+    inv = inv * den[k];
+    (scale * wk[k] * di).store(u + (lo + k) * EW);
+  }
+}
+// per variable i < m:  a = At_i (+ u[nc + i] for the instance variables), b = Bt_i, t = (beta a + alpha b + Ct_i) / gamma (instance)
+// or / delta (witness);  per i < h_len:  h = Z(tau)/delta * tau^i.  Canonical words out; b goes to both scalar arrays.
+__global__ void __launch_bounds__(256) setup_scalars_kernel(const uint32_t* __restrict__ at, const uint32_t* __restrict__ bt,
+                                                            const uint32_t* __restrict__ ct, const uint32_t* __restrict__ u,
+                                                            const uint32_t* __restrict__ consts, uint32_t nc, uint32_t m, uint32_t ni,
+                                                            uint32_t h_len, uint32_t* __restrict__ a_can, uint32_t* __restrict__ b_can,
+                                                            uint32_t* __restrict__ t_can, uint32_t* __restrict__ h_can,
+                                                            uint32_t* __restrict__ b2_can) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int AW = FT::ABI_WORDS;
+  if (i < m) {
+    FT a = FT::load(at + (size_t)i * EW);
+    if (i < ni) a = a + FT::load(u + (size_t)(nc + i) * EW);
+    const FT b = FT::load(bt + (size_t)i * EW), c = FT::load(ct + (size_t)i * EW);
+    const FT alpha = FT::load(consts + 4 * EW), beta = FT::load(consts + 5 * EW);
+    FT t = beta * a + alpha * b + c;
+    t = t * FT::load(consts + (i < ni ? 2 : 1) * EW);
+    a.to_canonical_words(a_can + (size_t)i * AW);
+    b.to_canonical_words(b_can + (size_t)i * AW);
+    b.to_canonical_words(b2_can + (size_t)i * AW);
+    t.to_canonical_words(t_can + (size_t)i * AW);
+  }
+  if (i < h_len) {
+    const FT tau = FT::load(consts + 6 * EW);
+    (FT::load(consts + 3 * EW) * tau.pow_u64(i)).to_canonical_words(h_can + (size_t)i * AW);
+  }
+}
+hipError_t setup_scalars(hipStream_t st, const void* domain_consts, const uint32_t* toxic_abi, uint32_t n, uint32_t nc, uint32_t m,
+                         uint32_t ni, const uint32_t* at, const uint32_t* bt, const uint32_t* ct, uint32_t* u, uint32_t* consts_dev,
+                         uint32_t* err_dev, uint32_t* a_can, uint32_t* b_can, uint32_t* t_can, uint32_t* h_can, uint32_t* b2_can, int phase) {
+  // both DomainConsts and MixedConsts start with the domain generator and keep 1/n in slot 4
+  FT w, ninv;
+  memcpy(&w, domain_consts, sizeof w);
+  memcpy(&ninv, (const char*)domain_consts + 4 * sizeof(FT), sizeof ninv);
+  if (phase == 0) {  // u = Lagrange coefficients at tau (needed by the transposed mat-vecs)
+    hipLaunchKernelGGL(setup_consts_kernel, dim3(1), dim3(64), 0, st, toxic_abi, n, ninv, consts_dev);
+    const uint32_t lanes = (n + LAGRANGE_BATCH - 1) / LAGRANGE_BATCH;
+    hipLaunchKernelGGL(setup_lagrange_kernel, dim3((lanes + 255) / 256), dim3(256), 0, st, consts_dev, w, n, u, err_dev);
+  } else {
+    const uint32_t h_len = n - 1, cnt = m > h_len ? m : h_len;
+    hipLaunchKernelGGL(setup_scalars_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, at, bt, ct, u, consts_dev, nc, m, ni, h_len, a_can,
+                       b_can, t_can, h_can, b2_can);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace
 
 #define PCD_CAT_(a, b) a##b
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const FieldEntry* PCD_CAT(pcd_field_entry_, PCD_FIELD_IDX)() {
   static const FieldEntry e = {EW, FT::ABI_WORDS, FT::Params::TWO_ADICITY, make_tables, run, convert, spmv, mul_sub_divz,
-                               mixed_make_tables, mixed_run, mixed_mul_sub_divz, scale_canon};
+                               mixed_make_tables, mixed_run, mixed_mul_sub_divz, scale_canon, SETUP_CONSTS, setup_scalars};
   return &e;
 }
 

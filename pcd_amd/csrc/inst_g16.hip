@@ -2,7 +2,8 @@
 // section 8) -- ark-groth16 `create_proof` after the five MSMs:
 //   A = alpha + a_query[0] + r*delta + M_a          B = beta + b_query[0] + s*delta + M_b   (G1 and G2)
 //   C = s*A + r*B_1 - r s*delta + M_l + M_h  =  s*(alpha + a_0 + M_a) + r*(beta_1 + b_0 + M_b1) + r s*delta + M_l + M_h
-// every scalar multiplication of create_proof is folded into the MSMs (see below).
+// The two variable-base products s*A and r*B_1 are either folded into MSMs (below) or computed by one lane each on the
+// stream of the MSM that produced the point, where they overlap the longer MSMs of the same proof (capi.hip).
 #include "common.h"
 
 namespace pcd {
@@ -66,6 +67,20 @@ __global__ void __launch_bounds__(64) g16_finish(const uint32_t* __restrict__ ms
   }
 }
 
+// out = k * in (k: canonical words, one lane; 4-bit window, table in `scratch`: 15 Jacobian slots)
+__global__ void __launch_bounds__(64) g16_scale_point(const uint32_t* __restrict__ in, const uint32_t* __restrict__ k,
+                                                      uint32_t* __restrict__ scratch, uint32_t* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  typedef EC<GA> E1;
+  Jac<F1> table[15];
+  (void)scratch;
+  E1::mul_w4(Jac<F1>::load(in), k, SWA, table).store(out);
+}
+
+hipError_t scale_g1(hipStream_t st, const uint32_t* in, const uint32_t* k, uint32_t* scratch, uint32_t* out) {
+  hipLaunchKernelGGL(g16_scale_point, dim3(1), dim3(64), 0, st, in, k, scratch, out);
+  return hipGetLastError();
+}
 hipError_t prepare_scalars(hipStream_t st, const uint32_t* rs_dev, uint32_t* t1, uint32_t* ts, uint32_t* tr) {
   hipLaunchKernelGGL(g16_prepare_scalars, dim3(1), dim3(64), 0, st, rs_dev, t1, ts, tr);
   return hipGetLastError();
@@ -80,7 +95,7 @@ hipError_t assemble(hipStream_t st, const uint32_t* msm_g1, const uint32_t* msm_
 #define PCD_CAT_(a, b) a##b
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const CurveEntry* PCD_CAT(pcd_curve_entry_, PCD_CURVE_IDX)() {
-  static const CurveEntry e = {prepare_scalars, (size_t)(2 * A1A + A2A) * 4, assemble};
+  static const CurveEntry e = {prepare_scalars, (size_t)(2 * A1A + A2A) * 4, assemble, scale_g1};
   return &e;
 }
 

@@ -1,6 +1,7 @@
 // One object per group (compile with -DPCD_GROUP_IDX=0..7, idx = 2 * curve_id + (group_id - 1)):
 // MSM driver + small point utilities instantiated for that group.
 #include "common.h"
+#include "fixed_base.cuh"
 
 namespace pcd {
 
@@ -70,13 +71,21 @@ hipError_t to_affine_entry(hipStream_t st, const uint32_t* jac, uint32_t n, uint
   return hipGetLastError();
 }
 
+constexpr int FB_NWIN = (GT::FR::BITS + FB_WINDOW - 1) / FB_WINDOW;
+constexpr size_t FB_TABLE_WORDS = ((size_t)FB_NWIN << FB_WINDOW) * Aff<F>::WORDS + (size_t)FB_NWIN * Jac<F>::WORDS;
+hipError_t fixed_base_entry(hipStream_t st, const uint32_t* base_abi, const uint32_t* scalars, uint32_t n, uint32_t* table_scratch,
+                            uint32_t* jac_scratch, uint32_t* out_abi, uint8_t* out_inf) {
+  uint32_t* bj = table_scratch + ((size_t)FB_NWIN << FB_WINDOW) * Aff<F>::WORDS;
+  return fixed_base_run<GT>(st, base_abi, scalars, n, bj, table_scratch, jac_scratch, out_abi, out_inf);
+}
+
 }  // namespace
 
 #define PCD_CAT_(a, b) a##b
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const GroupEntry* PCD_CAT(pcd_group_entry_, PCD_GROUP_IDX)() {
   static const GroupEntry e = {Aff<F>::WORDS, Aff<F>::ABI_WORDS, GT::FR::N32, GT::FR::BITS, msm_entry, precompute_entry,
-                               points_in_entry, jac_out_entry, points_sum_entry, to_affine_entry};
+                               points_in_entry, jac_out_entry, points_sum_entry, to_affine_entry, FB_TABLE_WORDS, fixed_base_entry};
   return &e;
 }
 

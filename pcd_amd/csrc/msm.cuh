@@ -354,7 +354,10 @@ PCD_DEV uint32_t msm_entry(const MsmEntrySource& src, bool compact, const MsmCur
 }
 
 template <class G>
-__global__ void __launch_bounds__(64) msm_accumulate_kernel(const uint32_t* __restrict__ bases, const MsmEntrySource src,
+#ifndef PCD_ACC_MIN_WAVES
+#define PCD_ACC_MIN_WAVES 2
+#endif
+__global__ void __launch_bounds__(64, PCD_ACC_MIN_WAVES) msm_accumulate_kernel(const uint32_t* __restrict__ bases, const MsmEntrySource src,
                                                             const uint32_t* __restrict__ off, uint32_t nkeys,
                                                             uint32_t chunk, uint32_t* __restrict__ buckets,
                                                             uint32_t* __restrict__ piece_first, uint32_t* __restrict__ piece_last) {

@@ -136,12 +136,74 @@ def test_groth16_roundtrip(co, gpu_ctx, cid, nc):
     proof, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
     gpu_ctx.g16_pk_set_r1cs(pk, r)
     proof2, inf2 = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
+    gpu_ctx.groth16_set_assembly(1)  # s*A and r*B_1 as two more MSMs instead of chained one-lane products
+    proof3, inf3 = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
+    gpu_ctx.groth16_set_assembly(0)
     pk.free()
     want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=16)
     assert np.array_equal(proof, want) and np.array_equal(inf, winf)
     assert np.array_equal(proof2, want) and np.array_equal(inf2, winf)
+    assert np.array_equal(proof3, want) and np.array_equal(inf3, winf)
     pub = np.ascontiguousarray(r.z[1:r.num_inputs])
     assert co.groth16_verify(keys, pub, proof)
     bad = pub.copy()
     bad[1] = co.fp_op(fr, "add", bad[1:2], r.z[:1])[0]
     assert not co.groth16_verify(keys, bad, proof)
+
+
+# ---- key generation: fixed-base batches and generate_parameters ------------------------------
+@pytest.mark.parametrize("cid,group,n", [(0, 1, 300), (0, 2, 100), (1, 1, 300), (1, 2, 70), (2, 1, 40), (2, 2, 20), (3, 1, 40), (3, 2, 12)])
+def test_fixed_base_mul_vs_oracle(co, gpu_ctx, cid, group, n):
+    """FixedBaseMSM::multi_scalar_mul + batch normalisation: out[i] = k_i * G, affine, against the oracle's
+    double-and-add; scalars include 0, 1, r - 1 and window-boundary values."""
+    fr = co.CURVE_FR[cid]
+    sc = co.gen_scalars(fr, n, seed=40 + cid)
+    sc[0] = 0
+    sc[1] = 0; sc[1, 0] = 1
+    sc[2] = 0; sc[2, 0] = 255
+    sc[3] = 0; sc[3, 0] = 256
+    one = np.zeros_like(sc[:1]); one[0, 0] = 1
+    sc[4] = co.fp_op(fr, "to_canonical", co.fp_op(fr, "neg", co.fp_op(fr, "from_canonical", one)))[0]   # r - 1
+    base = co.generator(cid, group)
+    got, inf = gpu_ctx.fixed_base_mul(cid, group, base, sc)
+    for i in list(range(8)) + list(range(8, n, max(1, n // 24))):
+        want, winf = co.to_affine(cid, group, co.scalar_mul(cid, group, base, sc[i])[None])
+        assert inf[i] == winf[0] and (inf[i] or np.array_equal(got[i], want[0])), i
+    assert inf[0] == 1 and not got[0].any() and np.array_equal(got[1], base)
+    # an infinity base and an empty batch
+    z, zinf = gpu_ctx.fixed_base_mul(cid, group, np.zeros_like(base), sc[:9])
+    assert zinf.all() and not z.any()
+    e, einf = gpu_ctx.fixed_base_mul(cid, group, base, sc[:0])
+    assert e.shape[0] == 0
+
+
+@pytest.mark.parametrize("cid,nc", [(0, 700), (1, 500), (2, 90), (3, 40)])
+def test_groth16_setup_vs_oracle(co, gpu_ctx, cid, nc):
+    """generate_parameters on the device == the oracle's generator on the same toxic waste, every query bit-exact;
+    the GPU-made key then proves (GPU) and verifies (oracle pairing), as tests/mnt4_groth16.rs:84-87 does end to end."""
+    fr = co.CURVE_FR[cid]
+    r = co.synthetic_r1cs(fr, nc, 3, seed=300 + cid)
+    toxic = co.gen_field(fr, 5, seed=17)
+    want = co.groth16_setup(cid, r, toxic, nthreads=32)
+    K = gpu_ctx.groth16_setup(cid, r, co.generator(cid, 1), co.generator(cid, 2), toxic)
+    for name in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "gamma_g2", "delta_g2", "a_query", "a_inf", "b_g1_query", "b_g1_inf",
+                 "b_g2_query", "b_g2_inf", "h_query", "h_inf", "l_query", "l_inf", "gamma_abc_g1", "gamma_abc_inf"):
+        assert np.array_equal(K[name], getattr(want, name)), name
+    keys = co.Keys(cid, r, {k: v for k, v in K.items() if k != "domain_size"})
+    rs = co.gen_field(fr, 2, seed=18)
+    pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
+    proof, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
+    pk.free()
+    assert co.groth16_verify(keys, np.ascontiguousarray(r.z[1:r.num_inputs]), proof)
+
+
+def test_groth16_setup_rejects_tau_in_domain(co, gpu_ctx):
+    """tau = 1 is a domain element: upstream never samples it (sample_element_outside_domain); the library refuses."""
+    from pcd_amd import capi
+    fr = co.CURVE_FR[0]
+    r = co.synthetic_r1cs(fr, 100, 2, seed=5)
+    toxic = co.gen_field(fr, 5, seed=17)
+    one = np.zeros_like(toxic[:1]); one[0, 0] = 1
+    toxic[4] = co.fp_op(fr, "from_canonical", one)[0]
+    with pytest.raises(capi.PcdHipError):
+        gpu_ctx.groth16_setup(0, r, co.generator(0, 1), co.generator(0, 2), toxic)

@@ -71,3 +71,22 @@ def test_mixed_radix_domain_vs_bigint(co, fid, q):
                 assert O.unpack_fp(f, co.fft_general(fid, X, m, inverse=inv, coset=coset, nthreads=2)) == want
     assert co.domain_size(fid, (1 << f.two_adicity) + 1) == O.best_mixed_domain_size(f, (1 << f.two_adicity) + 1, q)
     assert co.domain_size(fid, 1000) == 1024
+
+
+@pytest.mark.parametrize("cid,group", [(0, 1), (0, 2), (1, 1), (1, 2), (2, 1), (3, 2)])
+def test_fixed_base_msm_matches_double_and_add(co, cid, group):
+    """The oracle's restatement of ark-ec FixedBaseMSM (window table + mixed additions + batch normalisation)
+    against plain double-and-add, including 0, 1, r - 1 and both window-size regimes (n < 32 and n >= 32)."""
+    fr = co.CURVE_FR[cid]
+    base = co.generator(cid, group)
+    for n in (5, 40):
+        sc = co.gen_scalars(fr, n, seed=90 + n)
+        sc[0] = 0
+        sc[1] = 0; sc[1, 0] = 1
+        one = np.zeros_like(sc[:1]); one[0, 0] = 1
+        sc[2] = co.fp_op(fr, "to_canonical", co.fp_op(fr, "neg", co.fp_op(fr, "from_canonical", one)))[0]
+        got, inf = co.fixed_base_mul(cid, group, base, sc, nthreads=4)
+        for i in range(n if n < 32 else 6):
+            want, winf = co.to_affine(cid, group, co.scalar_mul(cid, group, base, sc[i])[None])
+            assert inf[i] == winf[0] and np.array_equal(got[i], want[0])
+        assert inf[0] == 1 and np.array_equal(got[1], base)
