@@ -15,6 +15,14 @@ pub struct pcdhip_g16_pk_host {
     pub l_query: *const u64, pub l_inf: *const u8, pub l_len: u64,
 }
 
+#[repr(C)]
+pub struct pcdhip_g16_setup_out {
+    pub alpha_g1: *mut u64, pub beta_g1: *mut u64, pub delta_g1: *mut u64, pub beta_g2: *mut u64, pub gamma_g2: *mut u64, pub delta_g2: *mut u64,
+    pub a_query: *mut u64, pub a_inf: *mut u8, pub b_g1_query: *mut u64, pub b_g1_inf: *mut u8, pub b_g2_query: *mut u64, pub b_g2_inf: *mut u8,
+    pub h_query: *mut u64, pub h_inf: *mut u8, pub l_query: *mut u64, pub l_inf: *mut u8, pub gamma_abc_g1: *mut u64, pub gamma_abc_inf: *mut u8,
+    pub domain_size: u64,
+}
+
 #[link(name = "pcdhip")]
 extern "C" {
     pub fn pcdhip_init(device_id: c_int, out: *mut *mut pcdhip_ctx) -> c_int;
@@ -30,6 +38,13 @@ extern "C" {
     pub fn pcdhip_g16_pk_free(ctx: *mut pcdhip_ctx, pk: *mut pcdhip_g16_pk);
     pub fn pcdhip_groth16_prove(ctx: *mut pcdhip_ctx, pk: *const pcdhip_g16_pk, a: *const pcdhip_csr, b: *const pcdhip_csr, c: *const pcdhip_csr,
                                 z: *const u64, r: *const u64, s: *const u64, proof: *mut u64, inf: *mut u8) -> c_int;
+    pub fn pcdhip_groth16_set_assembly(ctx: *mut pcdhip_ctx, mode: c_int) -> c_int;
+    // key generation: generate_parameters after synthesis / FixedBaseMSM::multi_scalar_mul + batch normalisation
+    pub fn pcdhip_groth16_setup(ctx: *mut pcdhip_ctx, curve: c_int, a: *const pcdhip_csr, b: *const pcdhip_csr, c: *const pcdhip_csr,
+                                num_vars: usize, num_inputs: usize, g1_xy: *const u64, g2_xy: *const u64, toxic: *const u64,
+                                out: *mut pcdhip_g16_setup_out) -> c_int;
+    pub fn pcdhip_fixed_base_mul(ctx: *mut pcdhip_ctx, curve: c_int, group: c_int, base_xy: *const u64, scalars: *const u64, n: usize,
+                                 out_xy: *mut u64, out_inf: *mut u8) -> c_int;
 }
 
 pub enum Error { Arg, SizeUnsupported, NoDevice, Oom, Hip }
