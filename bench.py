@@ -193,7 +193,9 @@ def synthetic_keys(co, curve, r, seed):
 
 def pcd_step(ctx, co):
     """Prover arithmetic of one PCD step: main proof (MNT4-298, domain 2^20) + help proof (MNT6-298, domain
-    2^16: its scalar field has 2-adicity 17), witness-like assignment; keys resident; bit-exact vs the oracle."""
+    2^16: its scalar field has 2-adicity 17); the assignment is uniformly random field elements -- the worst case for
+    the MSMs (a real witness is full of 0 / 1 values, which cost nothing / go to the pseudo bucket: `--dist 1`);
+    keys resident; bit-exact vs the oracle."""
     info = {"unit": "ms", "what": "witness map + the proof's MSMs (h, l, A, B1 on G1; B on G2) + assembly (s*A, r*B1 chained behind their MSMs, overlapping the others), per proof; R1CS synthesis (Rust host) excluded"}
     total_gpu, total_cpu = 0.0, 0.0
     for name, curve, log_n in (("main_mnt4_298", 0, 20), ("help_mnt6_298", 1, 16)):

@@ -775,8 +775,9 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
     jobs[nj++] = {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, slot(0), 1, nullptr, nullptr};               // h
     jobs[nj++] = {&g1, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni + 4), slot(1), 2, nullptr, nullptr};  // l'
   }
+  static const int serial_streams = getenv("PCD_G16_STREAMS") ? atoi(getenv("PCD_G16_STREAMS")) : 6;
   for (int k = 0; k < nj; k++) {
-    hipStream_t sk = ctx->g16_streams[k];
+    hipStream_t sk = ctx->g16_streams[k % serial_streams];
     TRY(hipStreamWaitEvent(sk, ctx->g16_ready, 0));
     TRY(hipEventRecord(ctx->g16_begin[k], sk));
     TRY(jobs[k].ge->msm(ctx->g16_ws[k], sk, jobs[k].bv, jobs[k].sc, jobs[k].n, jobs[k].out, ctx->msm_c, ctx->msm_chunk, ctx->msm_sort, nullptr));

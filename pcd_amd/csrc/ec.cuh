@@ -81,6 +81,10 @@ typedef G1Cfg<F298B, F298A, PCD_MNT6_298_A_SMALL, 1, false> G1_MNT6_298_C;
 typedef G2Cfg2<F298A, F298B, PCD_MNT4_298_A_SMALL, PCD_MNT4_298_NR_SMALL, 0, false> G2_MNT4_298_C;
 typedef G2Cfg3<F298B, F298A, PCD_MNT6_298_A_SMALL, PCD_MNT6_298_NR_SMALL, 1, false> G2_MNT6_298_C;
 
+// fields whose mixed addition has the lazily reduced form (EC::madd_lz): the inlined 298-bit prime fields
+template <class F> struct LazyCapable { static constexpr bool value = false; };
+template <class P> struct LazyCapable<Fp<P, true>> { static constexpr bool value = (P::N <= 11); };
+
 // ------------------------------------------------------------------------------------------------ group law
 template <class G>
 struct EC {
@@ -158,6 +162,66 @@ struct EC {
     }
     return r;
   }
+  // ---- mixed addition with lazily reduced coordinates (G1 of the 298-bit curves: F = Fp with the Lz helpers of fp.cuh) ----
+  // The bucket accumulation is a long chain acc <- acc + P_i; here the accumulator keeps X and Y unreduced between steps:
+  //   X  carry-propagated limbs, value < 16p      Y  = 2 D, limbs < 2^29, value < 4p      Z  in [0, 2p) as usual
+  // and every addition / subtraction of madd-2007-bl is limb-wise (no carry chain, no reduction); the products absorb it.
+  // Rewritten with r = 2 r0:  X3 = 4 r0^2 - J - 2V,  Y3 = 2 (r0 (V - X3) - Y1 J) (one fused two-term product),  Z3 = 2 Z1 H.
+  // Bounds (value as a multiple of p | needed for the product: ca cb <= 1024; limb products per column < 2^63):
+  //   H = U2 - X1 + 16p < 18p (carried)   r0 = S2 - Y1 + 4p < 6p (carried)   I = 4 HH < 8p, limbs < 2^30
+  //   J = H I: 144   V = X1 I: 128   X3 = 4 r0^2 - J - 2V + 8p in (0, 16p) (carried)
+  //   t2 = V - X3 + 16p < 18p, limbs in (-2^28, 1.25 * 2^30)   Y1' = 4p - Y1 in (0, 4p]
+  //   D = r0 t2 + Y1' J: 6 * 18 + 4 * 2 = 116;  columns < 11 (2^28 * 1.25 * 2^30 + 2^29 * 2^28) + 11 * 2^56 < 2^62
+  struct AccLz {
+    typename F::Lz X, Y;
+    F Z;
+    bool inf;
+  };
+  PCD_HD static AccLz lz_infinity() { AccLz a; a.X = F::zero().lz(); a.Y = F::one().lz(); a.Z = F::zero(); a.inf = true; return a; }
+  PCD_HD static AccLz lz_from(const J& p) { AccLz a; a.X = p.X.lz(); a.Y = p.Y.lz(); a.Z = p.Z; a.inf = p.is_inf(); return a; }
+  // fully reduced Jacobian point (each lazy coordinate times the Montgomery one)
+  PCD_HD static J lz_to_jac(const AccLz& a) {
+    if (a.inf) return J::infinity();
+    const typename F::Lz one = F::one().lz();
+    return {F::lz_mul(a.X, one), F::lz_mul(a.Y, one), a.Z};
+  }
+  PCD_HD static AccLz madd_lz(const AccLz& p, const A& q) {
+    typedef typename F::Lz L;
+    if (q.is_inf()) return p;
+    if (p.inf) { AccLz o; o.X = q.x.lz(); o.Y = q.y.lz(); o.Z = F::one(); o.inf = false; return o; }
+    const L Z1 = p.Z.lz();
+    const F Z1Z1 = F::lz_sqr(Z1);
+    const L zz = Z1Z1.lz();
+    const F U2 = F::lz_mul(q.x.lz(), zz);
+    const F S2 = F::lz_mul(F::lz_mul(q.y.lz(), Z1).lz(), zz);
+    const L H = F::lz_carry(F::template lz_sub<2>(U2.lz(), p.X));
+    const L r0 = F::lz_carry(F::template lz_sub<0>(S2.lz(), p.Y));
+    const F HH = F::lz_sqr(H);
+    const F rr0 = F::lz_sqr(r0);
+    if (HH.is_zero()) {  // same x: the same point (double it the ordinary way) or opposite points
+      if (!rr0.is_zero()) return lz_infinity();
+      return lz_from(dbl(lz_to_jac(p)));
+    }
+    const L I = F::lz_shl(HH.lz(), 2);
+    const F Jv = F::lz_mul(H, I);
+    const F V = F::lz_mul(p.X, I);
+    AccLz o;
+    o.inf = false;
+    {  // X3 = 4 r0^2 - J - 2V + 8p
+      L t;
+#pragma unroll
+      for (int i = 0; i < F::N; i++)
+        t.v[i] = (int32_t)(rr0.v[i] << 2) - (int32_t)Jv.v[i] - (int32_t)(V.v[i] << 1) + (int32_t)(F::Params::mod4(i) << 1);
+      o.X = F::lz_carry(t);
+    }
+    const L t2 = F::template lz_sub<2>(V.lz(), o.X);
+    const L y1n = F::template lz_sub<0>(F::zero().lz(), p.Y);
+    const F D = F::lz_dot2(r0, t2, y1n, Jv.lz());
+    o.Y = F::lz_shl(D.lz(), 1);
+    o.Z = F::lz_mul(F::lz_shl(Z1, 1), H);
+    return o;
+  }
+
   // the same product with a fixed 4-bit window (one lane: 14 group operations for the table, then 4 doublings and at
   // most one addition per nibble, leading zero nibbles skipped); `table` = 15 caller-provided Jacobian slots
   PCD_HD static J mul_w4(const J& p, const uint32_t* k, int nwords, J* table) {

@@ -38,6 +38,7 @@ namespace pcd {
     static constexpr uint32_t EST_RECIP = PFX28##_EST_RECIP;                                                  \
     PCD_HD static uint32_t mod(int i) { constexpr uint32_t m[N] = PFX28##_MOD; return m[i]; }                 \
     PCD_HD static uint32_t mod2(int i) { constexpr uint32_t m[N] = PFX28##_MOD2; return m[i]; }               \
+    PCD_HD static uint32_t mod4(int i) { constexpr uint32_t m[N] = PFX28##_MOD4; return m[i]; }               \
     PCD_HD static uint32_t one(int i) { constexpr uint32_t m[N] = PFX28##_ONE; return m[i]; }                 \
     PCD_HD static uint32_t r2(int i) { constexpr uint32_t m[N] = PFX28##_R2; return m[i]; }                   \
     PCD_HD static uint32_t cin(int i) { constexpr uint32_t m[N] = PFX28##_CIN; return m[i]; }                 \
@@ -195,6 +196,124 @@ struct Fp {
   }
   PCD_HD Fp operator*(const Fp& b) const { return mul(*this, b); }
   PCD_HD Fp sqr() const { return sqr_(*this); }
+
+  // ---- lazily reduced arithmetic (298-bit fields only: R'/p > 2^10 leaves room) -----------------------------------------------
+  // Lz = an integer >= 0 held in SIGNED 28-bit-radix limbs that are not carry-propagated: additions and subtractions are
+  // limb-wise, without any carry chain or reduction mod p.  Only the products reduce: for values a < ca p, b < cb p with
+  // ca cb <= 1024 the Montgomery product (a b + m p) / R' is < 2p with normalised limbs.  The callers (ec.cuh madd_lz) keep
+  // track of the value bounds (the multiple of p) and of the limb magnitudes (|a_i| |b_j| summed over a column < 2^63).
+  struct Lz { int32_t v[N]; };
+  // host-side harness only (tests/hostcheck, -DPCD_LZ_CHECK): every column sum is recomputed in 128 bits and compared
+#if defined(PCD_LZ_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+#define PCD_LZ_WIDE_DECL __int128 wide_ = 0;
+#define PCD_LZ_WIDE_MAC(x, y) wide_ += (__int128)(x) * (__int128)(y);
+#define PCD_LZ_WIDE_CHECK() do { if (wide_ != (__int128)acc) abort(); wide_ >>= 28; } while (0)
+#else
+#define PCD_LZ_WIDE_DECL
+#define PCD_LZ_WIDE_MAC(x, y)
+#define PCD_LZ_WIDE_CHECK() do { } while (0)
+#endif
+  PCD_HD Lz lz() const { Lz r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = (int32_t)v[i];
+    return r; }
+  PCD_HD static Lz lz_add(const Lz& a, const Lz& b) { Lz r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = a.v[i] + b.v[i];
+    return r; }
+  // a - b + (4 << S) p: non-negative as long as b < (4 << S) p
+  template <int S>
+  PCD_HD static Lz lz_sub(const Lz& a, const Lz& b) { Lz r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = a.v[i] - b.v[i] + (int32_t)(P::mod4(i) << S);
+    return r; }
+  PCD_HD static Lz lz_shl(const Lz& a, int s) { Lz r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = a.v[i] * (1 << s);
+    return r; }
+  // one carry chain: limbs 0 .. N-2 into [0, 2^28), the top limb takes the rest (value unchanged, still unreduced)
+  PCD_HD static Lz lz_carry(const Lz& a) { Lz r; int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) { int32_t x = a.v[i] + c; r.v[i] = x & (int32_t)MASK; c = x >> 28; }
+    r.v[N - 1] = a.v[N - 1] + c;
+    return r; }
+  // (a0 b0 [+ a1 b1]) / R' in [0, 2p), limbs normalised
+  template <int TERMS>
+  PCD_HD static Fp lz_dot(const Lz& a0, const Lz& b0, const Lz& a1, const Lz& b1) {
+    int32_t m[N];
+    int64_t acc = 0;
+    PCD_LZ_WIDE_DECL
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        acc += (int64_t)a0.v[i] * b0.v[k - i];
+        PCD_LZ_WIDE_MAC(a0.v[i], b0.v[k - i])
+        if (TERMS == 2) { acc += (int64_t)a1.v[i] * b1.v[k - i]; PCD_LZ_WIDE_MAC(a1.v[i], b1.v[k - i]) }
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_LZ_WIDE_MAC(m[i], P::mod(k - i)) }
+      m[k] = (int32_t)(((uint32_t)acc * P::INV) & MASK);
+      acc += (int64_t)m[k] * (int32_t)P::mod(0);
+      PCD_LZ_WIDE_MAC(m[k], P::mod(0))
+      PCD_LZ_WIDE_CHECK();
+      acc >>= 28;
+    }
+    Fp r;
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) {
+        acc += (int64_t)a0.v[i] * b0.v[k - i];
+        PCD_LZ_WIDE_MAC(a0.v[i], b0.v[k - i])
+        if (TERMS == 2) { acc += (int64_t)a1.v[i] * b1.v[k - i]; PCD_LZ_WIDE_MAC(a1.v[i], b1.v[k - i]) }
+      }
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_LZ_WIDE_MAC(m[i], P::mod(k - i)) }
+      r.v[k - N] = (uint32_t)acc & MASK;
+      PCD_LZ_WIDE_CHECK();
+      acc >>= 28;
+    }
+    if (acc < 0 || acc >= ((int64_t)1 << 28)) {
+#if defined(PCD_LZ_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+      abort();
+#endif
+    }
+    r.v[N - 1] = (uint32_t)acc;
+    return r;
+  }
+  PCD_HD static Fp lz_mul(const Lz& a, const Lz& b) { return lz_dot<1>(a, b, a, b); }
+  PCD_HD static Fp lz_dot2(const Lz& a0, const Lz& b0, const Lz& a1, const Lz& b1) { return lz_dot<2>(a0, b0, a1, b1); }
+  PCD_HD static Fp lz_sqr(const Lz& a) {
+    int32_t m[N], a2[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) a2[i] = a.v[i] * 2;
+    int64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+      for (int i = 0; 2 * i < k; i++) acc += (int64_t)a2[i] * a.v[k - i];
+      if ((k & 1) == 0) acc += (int64_t)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (int64_t)m[i] * (int32_t)P::mod(k - i);
+      m[k] = (int32_t)(((uint32_t)acc * P::INV) & MASK);
+      acc += (int64_t)m[k] * (int32_t)P::mod(0);
+      acc >>= 28;
+    }
+    Fp r;
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+      for (int i = k - N + 1; 2 * i < k; i++) acc += (int64_t)a2[i] * a.v[k - i];
+      if ((k & 1) == 0) acc += (int64_t)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) acc += (int64_t)m[i] * (int32_t)P::mod(k - i);
+      r.v[k - N] = (uint32_t)acc & MASK;
+      acc >>= 28;
+    }
+    r.v[N - 1] = (uint32_t)acc;
+    return r;
+  }
 
   // Fused sums of products (a0 b0 + a1 b1 [+ a2 b2]) / R' with ONE Montgomery reduction: the building block of the
   // Fq2 / Fq3 products (schoolbook with lazy reduction: no Karatsuba additions, one reduction per output coefficient).

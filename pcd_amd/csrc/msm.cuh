@@ -21,9 +21,11 @@
 // atomics are wave-aggregated so that bit-decomposition-heavy witnesses do not serialise on one
 // counter.
 #pragma once
+#include <cstdlib>
 #include <math.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "ec.cuh"
@@ -354,6 +356,21 @@ PCD_DEV uint32_t msm_entry(const MsmEntrySource& src, bool compact, const MsmCur
 }
 
 template <class G>
+struct MsmRunPlain {
+  typedef typename G::F F;
+  Jac<F> a = Jac<F>::infinity();
+  PCD_DEV void add(const Aff<F>& q) { a = EC<G>::madd(a, q); }
+  PCD_DEV void flush(uint32_t* dst) { a.store(dst); a = Jac<F>::infinity(); }
+};
+template <class G>
+struct MsmRunLazy {
+  typedef typename G::F F;
+  typename EC<G>::AccLz a = EC<G>::lz_infinity();
+  PCD_DEV void add(const Aff<F>& q) { a = EC<G>::madd_lz(a, q); }
+  PCD_DEV void flush(uint32_t* dst) { EC<G>::lz_to_jac(a).store(dst); a = EC<G>::lz_infinity(); }
+};
+
+template <class G>
 #ifndef PCD_ACC_MIN_WAVES
 #define PCD_ACC_MIN_WAVES 2
 #endif
@@ -373,13 +390,13 @@ __global__ void __launch_bounds__(64, PCD_ACC_MIN_WAVES) msm_accumulate_kernel(c
   cur.seek(off, nkeys, start);
   nxt_cur = cur;
   bool open_start = cur.key_start < start;  // current run began in an earlier chunk
-  Jac<F> acc = Jac<F>::infinity();
+  // the running sum: Jacobian, or (G1 of the 298-bit curves) the lazily reduced accumulator of EC::madd_lz
+  typename std::conditional<LazyCapable<F>::value, MsmRunLazy<G>, MsmRunPlain<G>>::type acc;
   Aff<F> nxt = Aff<F>::load(bases + (size_t)msm_entry(src, compact, cur, start) * Aff<F>::WORDS);
   for (uint32_t p = start; p < end; p++) {
     if (p >= cur.key_end) {  // run of `key` is complete
-      if (open_start) { acc.store(piece_first + (size_t)t * Jac<F>::WORDS); open_start = false; }
-      else acc.store(buckets + (size_t)cur.key * Jac<F>::WORDS);
-      acc = Jac<F>::infinity();
+      if (open_start) { acc.flush(piece_first + (size_t)t * Jac<F>::WORDS); open_start = false; }
+      else acc.flush(buckets + (size_t)cur.key * Jac<F>::WORDS);
       cur.advance_to(off, p);
     }
     Aff<F> pt = nxt;
@@ -387,12 +404,12 @@ __global__ void __launch_bounds__(64, PCD_ACC_MIN_WAVES) msm_accumulate_kernel(c
       nxt_cur.advance_to(off, p + 1);
       nxt = Aff<F>::load(bases + (size_t)msm_entry(src, compact, nxt_cur, p + 1) * Aff<F>::WORDS);
     }
-    acc = E::madd(acc, pt);
+    acc.add(pt);
   }
   bool open_end = cur.key_end > end;
-  if (open_end) acc.store(piece_last + (size_t)t * Jac<F>::WORDS);          // also the "middle piece" case
-  else if (open_start) acc.store(piece_first + (size_t)t * Jac<F>::WORDS);
-  else acc.store(buckets + (size_t)cur.key * Jac<F>::WORDS);
+  if (open_end) acc.flush(piece_last + (size_t)t * Jac<F>::WORDS);          // also the "middle piece" case
+  else if (open_start) acc.flush(piece_first + (size_t)t * Jac<F>::WORDS);
+  else acc.flush(buckets + (size_t)cur.key * Jac<F>::WORDS);
 }
 
 // bucket (window 0, digit 1) += pseudo bucket of the scalars equal to one
@@ -794,7 +811,9 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     uint32_t mA = B, mC = 0;
     int flip = 0, level = 0;
     while (mA > 0 || mC > 1) {
-      int k = (level == 0) ? 3 : 2;
+      // blocks of 8 at the first (throughput-bound) level, then pairs: the later levels are pure latency, and per halving
+      // of the array a pair level costs 2 additions + 1 doubling against 3.6 / 5.3 addition-equivalents for blocks of 4 / 8
+      int k = (level == 0) ? 3 : 1;
       if (mA == 0 && mC <= 8) k = 3;
       uint32_t K = 1u << k;
       uint32_t JA = (mA + K - 1) >> k, JC = (mC + K - 1) >> k;

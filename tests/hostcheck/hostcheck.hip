@@ -62,6 +62,31 @@ extern "C" int hc_msm_naive(int group_idx, const uint32_t* bases, const uint32_t
   return 0;
 }
 
+// chain of mixed additions acc += P_i with the lazily reduced accumulator (EC::madd_lz) and with the ordinary madd:
+// out = lazy result || ordinary result (Jacobian, C-ABI image); points may repeat (doubling branch) and cancel
+template <class G>
+static void madd_chain(const uint32_t* bases, int n, uint32_t* out) {
+  typedef typename G::F F;
+  typedef EC<G> E;
+  typename E::AccLz lz = E::lz_infinity();
+  Jac<F> acc = Jac<F>::infinity();
+  for (int i = 0; i < n; i++) {
+    Aff<F> p = Aff<F>::from_abi(bases + (size_t)i * Aff<F>::ABI_WORDS);
+    lz = E::madd_lz(lz, p);
+    acc = E::madd(acc, p);
+  }
+  E::lz_to_jac(lz).to_abi(out);
+  acc.to_abi(out + Jac<F>::ABI_WORDS);
+}
+extern "C" int hc_madd_chain(int curve, const uint32_t* bases, int n, uint32_t* out) {
+  switch (curve) {
+    case 0: madd_chain<G1_MNT4_298>(bases, n, out); break;
+    case 1: madd_chain<G1_MNT6_298>(bases, n, out); break;
+    default: return -1;
+  }
+  return 0;
+}
+
 #include "../../pcd_amd/csrc/pairing.cuh"
 template <class PC>
 static void pairing_host(const uint32_t* g1, const uint32_t* g2, uint32_t* out) {

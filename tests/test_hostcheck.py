@@ -20,7 +20,7 @@ def hc():
     srcs = [os.path.join(HC, "hostcheck.hip")] + [os.path.join(ROOT, "pcd_amd", "csrc", f) for f in
                                                   ("fp.cuh", "ec.cuh", "pairing.cuh", "params_gen.h", "params28_gen.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared",
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared", "-DPCD_LZ_CHECK",
                                os.path.join(HC, "hostcheck.hip"), "-o", so], stderr=subprocess.DEVNULL)
     return C.CDLL(so)
 
@@ -70,3 +70,35 @@ def test_pairing(hc, golden, cid):
     out = np.zeros_like(g[f"c{cid}_gt"])
     assert hc.hc_pairing(cid, P(p), P(q), P(out)) == 0
     assert np.array_equal(out, g[f"c{cid}_gt"])
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_lazy_madd_chain(hc, co, cid):
+    """EC::madd_lz (the bucket-accumulation step with unreduced X, Y between additions) against the ordinary madd and
+    the oracle, over chains long enough for the coordinate bounds to reach their steady state, with repeated points
+    (doubling branch), P then -P (cancellation to infinity, then restart) and infinity entries in the stream."""
+    w = co.point_words(cid, 1)
+    n = 600
+    pts = co.gen_points(cid, 1, n, seed=21 + cid)
+    pts[7] = pts[6]                      # acc + P where P was just added ... not yet equal to acc
+    neg = pts[10].copy()
+    one = np.zeros((1, w // 2), dtype=np.uint64); one[0, 0] = 1
+    neg[w // 2:] = co.fp_op(co.CURVE_FQ[cid], "neg", pts[10][None, w // 2:])[0]
+    seqs = {
+        "random": pts,
+        "double": np.concatenate([pts[:1], pts[:1], pts[1:50]]),               # acc = P, then + P: doubling branch
+        "cancel": np.concatenate([pts[10:11], neg[None], pts[20:60]]),         # P - P = infinity, then continue
+        "inf": np.concatenate([pts[:5], np.zeros((2, w), dtype=np.uint64), pts[5:30]]),
+        "cancel_mid": np.concatenate([pts[:9], pts[10:11], pts[30:40]]),
+    }
+    for name, seq in seqs.items():
+        seq = np.ascontiguousarray(seq)
+        out = np.zeros(2 * 3 * w // 2, dtype=np.uint64)
+        assert hc.hc_madd_chain(cid, P(seq), seq.shape[0], P(out)) == 0
+        lazy, plain = out[:3 * w // 2], out[3 * w // 2:]
+        sc = np.zeros((seq.shape[0], co.FIELD_N64[co.CURVE_FR[cid]]), dtype=np.uint64); sc[:, 0] = 1
+        inf = np.array([0 if r.any() else 1 for r in seq], dtype=np.uint8)
+        want, winf = co.to_affine(cid, 1, co.msm(cid, 1, seq, sc, inf=inf))
+        for got in (lazy, plain):
+            g, ginf = co.to_affine(cid, 1, got)
+            assert ginf[0] == winf[0] and np.array_equal(g, want), name
