@@ -210,6 +210,7 @@ void pcdhip_destroy(pcdhip_ctx* ctx) {
     if (ctx->g16_end[k]) (void)hipEventDestroy(ctx->g16_end[k]);
   }
   if (ctx->g16_ready) (void)hipEventDestroy(ctx->g16_ready);
+  if (ctx->g16_share.ready) (void)hipEventDestroy(ctx->g16_share.ready);
   for (auto& kv : ctx->fft_tables) {
     (void)hipFree(kv.second.tw_fwd); (void)hipFree(kv.second.tw_inv);
     (void)hipFree(kv.second.coset); (void)hipFree(kv.second.coset_inv_scaled);
@@ -375,7 +376,7 @@ static int msm_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset,
   uint32_t* out_dev = (uint32_t*)ctx->msm_ws.buf[WS_OUT];
   uint32_t* out_abi = out_dev + jac_b / 4;
   TRY(ge.msm(ctx->msm_ws, ctx->stream, bases->view(offset), scalars_dev, (uint32_t)n, out_dev, ctx->msm_c, ctx->msm_chunk,
-             ctx->msm_sort, ctx->msm_profile ? &ctx->msm_tm : nullptr));
+             ctx->msm_sort, ctx->msm_profile ? &ctx->msm_tm : nullptr, nullptr, MSM_SHARE_NONE));
   TRY(ge.jac_out(ctx->stream, out_dev, 1, out_abi));
   TRY(hipMemcpyAsync(out_xyz, out_abi, jac_abi_b, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
@@ -646,7 +647,15 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
   rc = rc ? rc : upload_plus(1, h->b_g1_query, h->b_g1_inf, h->num_vars, h->delta_g1, 1, h->beta_g1, &pk->b_g1_query);  // s * delta + beta
   rc = rc ? rc : upload_plus(2, h->b_g2_query, h->b_g2_inf, h->num_vars, h->delta_g2, 1, h->beta_g2, &pk->b_g2_query);
   rc = rc ? rc : pcdhip_bases_upload(ctx, cid, 1, h->h_query, h->h_inf, h->h_len, &pk->h_query);
-  rc = rc ? rc : upload_plus(1, h->l_query, h->l_inf, h->l_len, h->delta_g1, 2, nullptr, &pk->l_query);                 // -rs * delta
+  {  // l: padded in front with num_inputs points at infinity, so that it is indexed by the variable like a / b (one
+     // sort of the assignment's digits then serves all four MSMs);  -rs * delta in slot 2
+    const size_t pl = (size_t)pcdhip_point_limbs(cid, 1), m = h->num_vars, ni = h->num_inputs;
+    std::vector<uint64_t> tmp(m * pl, 0);
+    std::vector<uint8_t> tinf(m, 1);
+    if (h->l_len) memcpy(tmp.data() + ni * pl, h->l_query, h->l_len * pl * 8);
+    for (size_t i = 0; i < h->l_len; i++) tinf[ni + i] = h->l_inf ? h->l_inf[i] : 0;
+    rc = rc ? rc : upload_plus(1, tmp.data(), tinf.data(), m, h->delta_g1, 2, nullptr, &pk->l_query);
+  }
   if (rc) { pcdhip_g16_pk_free(ctx, pk); return rc; }
   *out = pk;
   return PCDHIP_OK;
@@ -756,31 +765,36 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
     }
   }
   TRY(hipEventRecord(ctx->g16_ready, st));
-  struct Job { const GroupEntry* ge; MsmBasesView bv; const uint32_t* sc; uint32_t n; uint32_t* out; int tslot; const uint32_t* k; uint32_t* kout; };
+  struct Job { const GroupEntry* ge; MsmBasesView bv; const uint32_t* sc; uint32_t n; uint32_t* out; int tslot; const uint32_t* k; uint32_t* kout; int share; };
+  const int PRODUCE = MSM_SHARE_PRODUCE, CONSUME = MSM_SHARE_CONSUME, NONE = MSM_SHARE_NONE;
+  if (!ctx->g16_share.ready) TRY(hipEventCreateWithFlags(&ctx->g16_share.ready, hipEventDisableTiming));
+  ctx->g16_share.valid = false;
   const uint32_t mt = (uint32_t)(m + 4);
   const bool folded = ctx->g16_assembly == 1;
   Job jobs[6];
   int nj = 0;
+  // a', b1', b2', l' are indexed alike and take the same scalars z || t: the first of them sorts, the others reuse its list
   if (folded) {
-    jobs[nj++] = {&g2, pk->b_g2_query->view(0), z_can, mt, msm_g2, 5, nullptr, nullptr};                       // B (heaviest: high priority)
-    jobs[nj++] = {&g1, pk->a_query->view(0), z_can, mt, slot(2), 3, nullptr, nullptr};                         // A
-    jobs[nj++] = {&g1, pk->a_query->view(0), sz_can, mt, slot(3), 3, nullptr, nullptr};                        // s * A
-    jobs[nj++] = {&g1, pk->b_g1_query->view(0), rz_can, mt, slot(4), 4, nullptr, nullptr};                     // r * B_1
-    jobs[nj++] = {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, slot(0), 1, nullptr, nullptr};               // h
-    jobs[nj++] = {&g1, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni + 4), slot(1), 2, nullptr, nullptr};  // l' (with -rs delta)
+    jobs[nj++] = {&g2, pk->b_g2_query->view(0), z_can, mt, msm_g2, 5, nullptr, nullptr, PRODUCE};             // B (heaviest: high priority)
+    jobs[nj++] = {&g1, pk->a_query->view(0), z_can, mt, slot(2), 3, nullptr, nullptr, CONSUME};               // A
+    jobs[nj++] = {&g1, pk->a_query->view(0), sz_can, mt, slot(3), 3, nullptr, nullptr, NONE};                 // s * A
+    jobs[nj++] = {&g1, pk->b_g1_query->view(0), rz_can, mt, slot(4), 4, nullptr, nullptr, NONE};              // r * B_1
+    jobs[nj++] = {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, slot(0), 1, nullptr, nullptr, NONE};        // h
+    jobs[nj++] = {&g1, pk->l_query->view(0), z_can, mt, slot(1), 2, nullptr, nullptr, CONSUME};               // l' (with -rs delta)
   } else {
-    jobs[nj++] = {&g1, pk->a_query->view(0), z_can, mt, slot(2), 3, t1 + sw, slot(3)};                         // A, then s * A
-    jobs[nj++] = {&g1, pk->b_g1_query->view(0), z_can, mt, slot(5), 4, t1, slot(4)};                           // B_1, then r * B_1
-    jobs[nj++] = {&g2, pk->b_g2_query->view(0), z_can, mt, msm_g2, 5, nullptr, nullptr};                       // B
-    jobs[nj++] = {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, slot(0), 1, nullptr, nullptr};               // h
-    jobs[nj++] = {&g1, pk->l_query->view(0), z_can + ni * sw, (uint32_t)(m - ni + 4), slot(1), 2, nullptr, nullptr};  // l'
+    jobs[nj++] = {&g1, pk->a_query->view(0), z_can, mt, slot(2), 3, t1 + sw, slot(3), PRODUCE};               // A, then s * A
+    jobs[nj++] = {&g1, pk->b_g1_query->view(0), z_can, mt, slot(5), 4, t1, slot(4), CONSUME};                 // B_1, then r * B_1
+    jobs[nj++] = {&g2, pk->b_g2_query->view(0), z_can, mt, msm_g2, 5, nullptr, nullptr, CONSUME};             // B
+    jobs[nj++] = {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, slot(0), 1, nullptr, nullptr, NONE};        // h
+    jobs[nj++] = {&g1, pk->l_query->view(0), z_can, mt, slot(1), 2, nullptr, nullptr, CONSUME};               // l'
   }
   static const int serial_streams = getenv("PCD_G16_STREAMS") ? atoi(getenv("PCD_G16_STREAMS")) : 6;
   for (int k = 0; k < nj; k++) {
     hipStream_t sk = ctx->g16_streams[k % serial_streams];
     TRY(hipStreamWaitEvent(sk, ctx->g16_ready, 0));
     TRY(hipEventRecord(ctx->g16_begin[k], sk));
-    TRY(jobs[k].ge->msm(ctx->g16_ws[k], sk, jobs[k].bv, jobs[k].sc, jobs[k].n, jobs[k].out, ctx->msm_c, ctx->msm_chunk, ctx->msm_sort, nullptr));
+    TRY(jobs[k].ge->msm(ctx->g16_ws[k], sk, jobs[k].bv, jobs[k].sc, jobs[k].n, jobs[k].out, ctx->msm_c, ctx->msm_chunk, ctx->msm_sort, nullptr,
+                        jobs[k].share ? &ctx->g16_share : nullptr, jobs[k].share));
     if (jobs[k].k) TRY(ce.scale_g1(sk, jobs[k].out, jobs[k].k, mul_scratch + (size_t)k * 16 * (j1 / 4), jobs[k].kout));
     TRY(hipEventRecord(ctx->g16_end[k], sk));
     TRY(hipStreamWaitEvent(st, ctx->g16_end[k], 0));

@@ -60,6 +60,7 @@ struct pcdhip_ctx {
   hipStream_t g16_streams[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   pcd::MsmWorkspace g16_ws[6];
   hipEvent_t g16_ready = nullptr, g16_begin[6] = {nullptr}, g16_end[6] = {nullptr};
+  pcd::MsmSharedSort g16_share;  // the sort of the assignment's digits, made once per proof and used by four MSMs
   std::map<uint64_t, pcd::FftTables> fft_tables;
   int msm_c = 0;
   uint32_t msm_chunk = 0;
@@ -79,7 +80,8 @@ namespace pcd {
 
 // ---- per-group entries (inst_group.hip, one object per group) ------------------------------------
 typedef hipError_t (*MsmFn)(MsmWorkspace&, hipStream_t, const MsmBasesView& bases, const uint32_t* scalars, uint32_t n,
-                            uint32_t* out_dev, int c, uint32_t chunk, int sort_mode, MsmTimings* tm);
+                            uint32_t* out_dev, int c, uint32_t chunk, int sort_mode, MsmTimings* tm, MsmSharedSort* share,
+                            int share_role);
 typedef hipError_t (*PrecomputeFn)(hipStream_t, uint32_t* pts, uint32_t n, int groups, int shift);
 typedef hipError_t (*PointsSumFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* out_dev);
 typedef hipError_t (*ToAffineFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* aff_dev);

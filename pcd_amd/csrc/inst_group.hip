@@ -45,8 +45,8 @@ __global__ void __launch_bounds__(64) to_affine_kernel(const uint32_t* __restric
 }
 
 hipError_t msm_entry(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bases, const uint32_t* scalars, uint32_t n,
-                     uint32_t* out_dev, int c, uint32_t chunk, int sort_mode, MsmTimings* tm) {
-  return msm_run<GT>(ws, st, bases, scalars, n, out_dev, c, chunk, sort_mode, tm);
+                     uint32_t* out_dev, int c, uint32_t chunk, int sort_mode, MsmTimings* tm, MsmSharedSort* share, int share_role) {
+  return msm_run<GT>(ws, st, bases, scalars, n, out_dev, c, chunk, sort_mode, tm, share, share_role);
 }
 hipError_t precompute_entry(hipStream_t st, uint32_t* pts, uint32_t n, int groups, int shift) {
   return msm_precompute<GT>(st, pts, n, groups, shift);

@@ -645,9 +645,24 @@ struct MsmBasesView {
   int groups;            // 1: no precomputation
 };
 
+// Several MSMs over the SAME scalar vector and identically laid-out base arrays (the a, b_g1, b_g2 and l queries of one
+// Groth16 proof all take the assignment z) need the digit extraction and the sort of the (bucket, base index) entries
+// only once: the producer publishes its sorted list, the consumers wait for `ready` and start at the accumulation.
+struct MsmSharedSort {
+  bool valid = false;
+  uint32_t n = 0, n_total = 0, offset = 0, tkeys = 0;
+  int c = 0, W = 0, groups = 0;
+  const uint32_t* scalars = nullptr;
+  MsmEntrySource src{};
+  const uint32_t* off = nullptr;
+  hipEvent_t ready = nullptr;  // created by the caller (timing disabled); recorded by the producer after the sort
+};
+enum { MSM_SHARE_NONE = 0, MSM_SHARE_PRODUCE = 1, MSM_SHARE_CONSUME = 2 };
+
 template <class G>
 hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, const uint32_t* scalars_dev, uint32_t n,
-                   uint32_t* out_dev, int c_override, uint32_t chunk_override, int sort_mode, MsmTimings* tm) {
+                   uint32_t* out_dev, int c_override, uint32_t chunk_override, int sort_mode, MsmTimings* tm,
+                   MsmSharedSort* share = nullptr, int share_role = MSM_SHARE_NONE) {
   const bool single_pass = sort_mode == 1;  // pcdhip_msm_set_sort(ctx, 1)
   const uint32_t* bases_dev = bv.dptr;
   typedef typename G::F F;
@@ -671,6 +686,9 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
 
   // keys: pl.nkeys real buckets + 1 pseudo bucket (scalars equal to one)
   const uint32_t tkeys = pl.nkeys + 1, ones_key = pl.nkeys;
+  const bool consume = share && share_role == MSM_SHARE_CONSUME && share->valid && share->n == n && share->n_total == bv.n_total &&
+                       share->offset == bv.offset && share->tkeys == tkeys && share->c == pl.c && share->W == pl.W &&
+                       share->groups == bv.groups && share->scalars == scalars_dev;
   PCD_HIP_TRY(ws.ensure(WS_CNT, (size_t)tkeys * 4 + 16));
   PCD_HIP_TRY(ws.ensure(WS_OFF, ((size_t)tkeys + 1) * 4));
   const uint32_t scan_per_block = 16384;
@@ -706,9 +724,15 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
 
   PCD_HIP_TRY(mark(0));
   dim3 gd((n + 255) / 256), bd(256);
-  PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)tkeys * 4, st));
   MsmEntrySource src;
-  if (use_slots) {
+  if (consume) {
+    // the producer's sorted list (its workspace is not touched again before every consumer has finished)
+    PCD_HIP_TRY(hipStreamWaitEvent(st, share->ready, 0));
+    src = share->src;
+    off = const_cast<uint32_t*>(share->off);
+    PCD_HIP_TRY(mark(1)); PCD_HIP_TRY(mark(2)); PCD_HIP_TRY(mark(3));
+  } else if (use_slots) {
+    PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)tkeys * 4, st));
     // 1. one pass: slots + exact histogram
     PCD_HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
     hipLaunchKernelGGL((msm_digits_kernel<NS, MODE_BIN>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, pl.nkeys, cnt,
@@ -727,6 +751,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     PCD_HIP_TRY(mark(3));
     src = {sorted, slots, ones_idx, flag, cap, ones_key};
   } else if (use_partition) {
+    PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)tkeys * 4, st));
     // 1. coarse histogram  2. bin bases  3. partition + per-bin counting sort (see "partition sort" above)
     const uint32_t tiles = (n + MSM_TILE - 1) / MSM_TILE;
     PCD_HIP_TRY(ws.ensure(WS_ENTRIES, (size_t)maxM * 8));
@@ -747,6 +772,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     PCD_HIP_TRY(mark(3));
     src = {sorted, nullptr, ones_idx, nullptr, 0u, ones_key};
   } else {
+    PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)tkeys * 4, st));
     // 1. histogram  2. scan  3. scatter (cursor = cnt reset to zero)
     hipLaunchKernelGGL((msm_digits_kernel<NS, MODE_HIST>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, pl.nkeys, cnt,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, 0);
@@ -759,6 +785,13 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
                        off, sorted, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, 0);
     PCD_HIP_TRY(mark(3));
     src = {sorted, nullptr, nullptr, nullptr, 0u, ones_key};
+  }
+  if (share && share_role == MSM_SHARE_PRODUCE) {
+    share->valid = true;
+    share->n = n; share->n_total = bv.n_total; share->offset = bv.offset; share->tkeys = tkeys;
+    share->c = pl.c; share->W = pl.W; share->groups = bv.groups; share->scalars = scalars_dev;
+    share->src = src; share->off = off;
+    PCD_HIP_TRY(hipEventRecord(share->ready, st));
   }
   // 4. accumulate.  Nothing below waits for the host: grids are sized for the largest possible list (n W entries;
   //    the actual count M = off[nkeys] is read on the device) so the whole MSM is one asynchronous chain of launches.
