@@ -552,6 +552,44 @@ __global__ void __launch_bounds__(64) msm_tail_level_kernel(const uint32_t* __re
   }
 }
 
+// The same level for blocks of two, with the three dependent-free pieces of work on separate workgroups (blockIdx.z) so that
+// the critical path of a level is one addition and one doubling instead of two additions and a doubling -- these levels
+// are pure latency (a handful of lanes), so the extra doubling is free:
+//   z = 0:  A'_{j-1} = 2 (A_{2j} + A_{2j+1})        z = 1:  L_j = A_{2j} + 2 A_{2j+1} -> C'[JC + j]        z = 2:  C'_j = C_{2j} + C_{2j+1}
+template <class G>
+__global__ void __launch_bounds__(64) msm_tail_pair_kernel(const uint32_t* __restrict__ A_in, uint32_t mA, size_t strideA_in,
+                                                           const uint32_t* __restrict__ C_in, uint32_t mC, size_t strideC_in,
+                                                           uint32_t* __restrict__ A_out, size_t strideA_out,
+                                                           uint32_t* __restrict__ C_out, size_t strideC_out) {
+  typedef typename G::F F;
+  typedef EC<G> E;
+  constexpr int PW = Jac<F>::WORDS;
+  const uint32_t JA = (mA + 1) >> 1, JC = (mC + 1) >> 1;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t w = blockIdx.y;
+  const int role = blockIdx.z;
+  if (role < 2) {
+    if (j >= JA) return;
+    const uint32_t* A = A_in + w * strideA_in * PW;
+    const bool two = 2 * j + 1 < mA;
+    const Jac<F> a0 = Jac<F>::load(A + (size_t)(2 * j) * PW);
+    if (role == 0) {
+      if (j == 0) return;
+      Jac<F> run = two ? E::add(a0, Jac<F>::load(A + (size_t)(2 * j + 1) * PW)) : a0;
+      E::dbl(run).store(A_out + (w * strideA_out + j - 1) * PW);
+    } else {
+      Jac<F> acc = two ? E::add(E::dbl(Jac<F>::load(A + (size_t)(2 * j + 1) * PW)), a0) : a0;
+      acc.store(C_out + (w * strideC_out + JC + j) * PW);
+    }
+  } else {
+    if (j >= JC) return;
+    const uint32_t* Cw = C_in + w * strideC_in * PW;
+    Jac<F> acc = Jac<F>::load(Cw + (size_t)(2 * j) * PW);
+    if (2 * j + 1 < mC) acc = E::add(acc, Jac<F>::load(Cw + (size_t)(2 * j + 1) * PW));
+    acc.store(C_out + (w * strideC_out + j) * PW);
+  }
+}
+
 // total = sum_w 2^(c w) V_w, V_w = C[w * strideC];  plus `extra` points added at the end
 template <class G>
 __global__ void __launch_bounds__(64) msm_horner_kernel(const uint32_t* __restrict__ C, size_t strideC, int W, int c, uint32_t* __restrict__ out) {
@@ -846,15 +884,20 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     while (mA > 0 || mC > 1) {
       // blocks of 8 at the first (throughput-bound) level, then pairs: the later levels are pure latency, and per halving
       // of the array a pair level costs 2 additions + 1 doubling against 3.6 / 5.3 addition-equivalents for blocks of 4 / 8
-      int k = (level == 0) ? 3 : 1;
+      // (the first level of a large bucket array is throughput-bound: blocks of 8 there)
+      int k = (level == 0 && B >= (1u << 17)) ? 3 : 1;
       if (mA == 0 && mC <= 8) k = 3;
       uint32_t K = 1u << k;
       uint32_t JA = (mA + K - 1) >> k, JC = (mC + K - 1) >> k;
       uint32_t* A_out = (uint32_t*)ws.buf[flip ? WS_A1 : WS_A0];
       uint32_t* C_out = (uint32_t*)ws.buf[flip ? WS_C1 : WS_C0];
       uint32_t threads = JA + JC;
-      hipLaunchKernelGGL((msm_tail_level_kernel<G>), dim3((threads + 63) / 64, Wg), dim3(64), 0, st, A_in, mA, strideA_in, C_in, mC,
-                         strideC_in, A_out, strideAC, C_out, strideAC, k);
+      if (k == 1)
+        hipLaunchKernelGGL((msm_tail_pair_kernel<G>), dim3((std::max(JA, JC) + 63) / 64, Wg, 3), dim3(64), 0, st, A_in, mA, strideA_in, C_in,
+                           mC, strideC_in, A_out, strideAC, C_out, strideAC);
+      else
+        hipLaunchKernelGGL((msm_tail_level_kernel<G>), dim3((threads + 63) / 64, Wg), dim3(64), 0, st, A_in, mA, strideA_in, C_in, mC,
+                           strideC_in, A_out, strideAC, C_out, strideAC, k);
       mA = JA ? JA - 1 : 0;
       mC = JC + JA;
       A_in = A_out; strideA_in = strideAC;

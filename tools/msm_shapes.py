@@ -8,14 +8,16 @@ from pcd_amd import capi
 
 ctx = capi.Context(0)
 ctx.msm_profile(True)
-n = 1 << 20
+curve = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
+fr = co.CURVE_FR[curve]
 out = {}
 for group in (1, 2):
-    pts = co.gen_points(0, group, n, seed=5)
-    bases = ctx.bases_upload(0, group, pts)
+    pts = co.gen_points(curve, group, n, seed=5)
+    bases = ctx.bases_upload(curve, group, pts)
     for dist in (0, 1):
-        sc = co.gen_scalars(1, n, seed=6, dist=dist)
-        sbuf = ctx.buf_upload(1, sc)
+        sc = co.gen_scalars(fr, n, seed=6, dist=dist)
+        sbuf = ctx.buf_upload(fr, sc)
         for _ in range(3):
             ctx.msm(bases, sbuf)
         tms = []
