@@ -258,7 +258,14 @@ static __global__ void __launch_bounds__(256) msm_bin_sort_kernel(const uint64_t
   const uint32_t b = blockIdx.x, lo = bin_base[b], hi = bin_base[b + 1];
   for (uint32_t k = threadIdx.x; k < KB; k += blockDim.x) hist[k] = 0;
   __syncthreads();
-  for (uint32_t p = lo + threadIdx.x; p < hi; p += blockDim.x) atomicAdd(&hist[(uint32_t)(entries[p] >> 32) & (KB - 1)], 1u);
+  // (four entries per lane in flight: the loop is a chain of global load -> LDS atomic -> scattered store latencies)
+  for (uint32_t p0 = lo + threadIdx.x; p0 < hi; p0 += 4 * blockDim.x) {
+    uint32_t kk[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { uint32_t p = p0 + u * blockDim.x; kk[u] = p < hi ? (uint32_t)(entries[p] >> 32) & (KB - 1) : KB; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (kk[u] < KB) atomicAdd(&hist[kk[u]], 1u);
+  }
   __syncthreads();
   // exclusive scan of the 512 counters: two per lane, wave scan, then the four wave totals
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -275,10 +282,15 @@ static __global__ void __launch_bounds__(256) msm_bin_sort_kernel(const uint64_t
   off[(size_t)b * KB + 2 * t] = ex;
   off[(size_t)b * KB + 2 * t + 1] = ex + c0;
   __syncthreads();
-  for (uint32_t p = lo + threadIdx.x; p < hi; p += blockDim.x) {
-    uint64_t e = entries[p];
-    uint32_t pos = atomicAdd(&hist[(uint32_t)(e >> 32) & (KB - 1)], 1u);
-    sorted_idx[pos] = (uint32_t)e;
+  for (uint32_t p0 = lo + threadIdx.x; p0 < hi; p0 += 4 * blockDim.x) {
+    uint64_t e[4];
+    uint32_t pos[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { uint32_t p = p0 + u * blockDim.x; e[u] = p < hi ? entries[p] : ~0ull; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (e[u] != ~0ull) pos[u] = atomicAdd(&hist[(uint32_t)(e[u] >> 32) & (KB - 1)], 1u);
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (e[u] != ~0ull) sorted_idx[pos[u]] = (uint32_t)e[u];
   }
 }
 
@@ -886,7 +898,6 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
       // of the array a pair level costs 2 additions + 1 doubling against 3.6 / 5.3 addition-equivalents for blocks of 4 / 8
       // (the first level of a large bucket array is throughput-bound: blocks of 8 there)
       int k = (level == 0 && B >= (1u << 17)) ? 3 : 1;
-      if (mA == 0 && mC <= 8) k = 3;
       uint32_t K = 1u << k;
       uint32_t JA = (mA + K - 1) >> k, JC = (mC + K - 1) >> k;
       uint32_t* A_out = (uint32_t*)ws.buf[flip ? WS_A1 : WS_A0];
