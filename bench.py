@@ -84,12 +84,13 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
+    exchange = None
+    if use_dist:
+        from pcd_amd.dist import DeviceExchange
+        exchange = DeviceExchange(ctx, CURVE, GROUP, device)   # partial -> RCCL all-gather -> EC sum, all on the device
+
     def step():
-        part = ctx.msm(bases, sbuf)
-        if use_dist:
-            from pcd_amd.dist import all_gather_points
-            part = ctx.points_sum(CURVE, GROUP, all_gather_points(part, device))
-        return part
+        return exchange.msm(bases, sbuf) if use_dist else ctx.msm(bases, sbuf)
 
     for _ in range(args.warmup):
         res = step()

@@ -103,6 +103,14 @@ int pcdhip_msm_last_timings(pcdhip_ctx* ctx, float out_ms[8]);
 /* Sum of n Jacobian points (the multi-GPU combine step after the all-gather of partial results). */
 int pcdhip_points_sum(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xyz_mont, size_t n,
                       uint64_t* out_xyz_mont);
+/* The same exchange without host round trips (bench.py / pcd_amd.dist at N > 1): pcdhip_msm_dev_partial leaves the Jacobian
+ * result (X||Y||Z Montgomery limbs) in DEVICE memory owned by the caller -- the send buffer of the RCCL all-gather --
+ * asynchronously on the context's stream (pcdhip_sync before another stream reads it); pcdhip_points_sum_dev sums n
+ * Jacobian points that already sit in device memory (the receive buffer) and returns the sum to the host. */
+int pcdhip_msm_dev_partial(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars,
+                           size_t scalar_offset, size_t n, uint64_t* out_xyz_device);
+int pcdhip_points_sum_dev(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xyz_device, size_t n,
+                          uint64_t* out_xyz_mont);
 /* Jacobian -> affine (x||y, flag) for n points, as `into_affine()`. */
 int pcdhip_to_affine(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xyz_mont, size_t n,
                      uint64_t* out_xy_mont, uint8_t* out_inf);

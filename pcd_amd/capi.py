@@ -45,7 +45,7 @@ EXPORTS = [
     "pcdhip_field_limbs", "pcdhip_curve_base_field", "pcdhip_curve_scalar_field", "pcdhip_point_limbs",
     "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
     "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config",
-    "pcdhip_set_precompute", "pcdhip_msm_set_sort", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_to_affine",
+    "pcdhip_set_precompute", "pcdhip_msm_set_sort", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
     "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
     "pcdhip_multi_pairing", "pcdhip_groth16_verify", "pcdhip_timer_start", "pcdhip_timer_stop",
@@ -140,6 +140,19 @@ class Context:
             scalars = _u64(scalars)
             n = scalars.shape[0] if n is None else n
             self._check(lib().pcdhip_msm(self._ctx, bases._h, C.c_size_t(offset), _p(scalars), C.c_size_t(n), _p(out)))
+        return out
+
+    def msm_partial_to_device(self, bases, scalars, out_device_ptr, offset=0, n=None):
+        """The MSM of a shard with its Jacobian result left at `out_device_ptr` (device memory of the caller, e.g. a torch
+        tensor's data_ptr(): the send buffer of the all-gather).  Asynchronous: call sync() before another stream reads it."""
+        n = scalars.n if n is None else n
+        self._check(lib().pcdhip_msm_dev_partial(self._ctx, bases._h, C.c_size_t(offset), scalars._h, C.c_size_t(0), C.c_size_t(n),
+                                                 C.c_void_p(out_device_ptr)))
+
+    def points_sum_device(self, curve, group, xyz_device_ptr, n):
+        """Sum of n Jacobian points that sit in device memory (the receive buffer of the all-gather) -> host limbs."""
+        out = np.zeros(3 * point_limbs(curve, group) // 2, dtype=np.uint64)
+        self._check(lib().pcdhip_points_sum_dev(self._ctx, curve, group, C.c_void_p(xyz_device_ptr), C.c_size_t(n), _p(out)))
         return out
 
     def msm_config(self, window_bits=0, chunk=0):

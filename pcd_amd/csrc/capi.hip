@@ -369,7 +369,7 @@ int pcdhip_msm_last_timings(pcdhip_ctx* ctx, float out_ms[8]) {
 }
 
 static int msm_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const uint32_t* scalars_dev, size_t n,
-                      uint64_t* out_xyz) {
+                      uint64_t* out_xyz, bool out_on_device = false) {
   const GroupEntry& ge = group_entry(bases->curve_id, bases->group_id);
   const size_t jac_b = (size_t)ge.point_words / 2 * 3 * 4, jac_abi_b = (size_t)ge.point_abi_words / 2 * 3 * 4;
   TRY(ctx->msm_ws.ensure(WS_OUT, jac_b + jac_abi_b + 64));
@@ -377,6 +377,7 @@ static int msm_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset,
   uint32_t* out_abi = out_dev + jac_b / 4;
   TRY(ge.msm(ctx->msm_ws, ctx->stream, bases->view(offset), scalars_dev, (uint32_t)n, out_dev, ctx->msm_c, ctx->msm_chunk,
              ctx->msm_sort, ctx->msm_profile ? &ctx->msm_tm : nullptr, nullptr, MSM_SHARE_NONE));
+  if (out_on_device) { TRY(ge.jac_out(ctx->stream, out_dev, 1, (uint32_t*)out_xyz)); return PCDHIP_OK; }  // asynchronous
   TRY(ge.jac_out(ctx->stream, out_dev, 1, out_abi));
   TRY(hipMemcpyAsync(out_xyz, out_abi, jac_abi_b, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
@@ -393,6 +394,16 @@ int pcdhip_msm_dev(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, co
   return msm_common(ctx, bases, offset, scalars->dptr + scalar_offset * sw, n, out_xyz);
 }
 
+int pcdhip_msm_dev_partial(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset,
+                           size_t n, uint64_t* out_xyz_device) {
+  if (!ctx || !bases || !scalars || !out_xyz_device) return PCDHIP_E_ARG;
+  if (offset + n > bases->n || scalar_offset + n > scalars->n || n >= (1ull << 31)) return PCDHIP_E_ARG;
+  if (scalars->field_id != kCurveFr[bases->curve_id]) return PCDHIP_E_ARG;
+  BIND();
+  const size_t sw = (size_t)kFieldLimbs[scalars->field_id] * 2;
+  return msm_common(ctx, bases, offset, scalars->dptr + scalar_offset * sw, n, out_xyz_device, true);
+}
+
 int pcdhip_msm(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const uint64_t* scalars, size_t n, uint64_t* out_xyz) {
   if (!ctx || !bases || (!scalars && n) || !out_xyz) return PCDHIP_E_ARG;
   if (offset + n > bases->n || n >= (1ull << 31)) return PCDHIP_E_ARG;
@@ -403,18 +414,29 @@ int pcdhip_msm(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const 
   return msm_common(ctx, bases, offset, (const uint32_t*)ctx->msm_ws.buf[WS_SCAL], n, out_xyz);
 }
 
-int pcdhip_points_sum(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xyz, size_t n, uint64_t* out_xyz) {
-  if (!ctx || !valid_curve(curve_id) || !valid_group(group_id) || (!xyz && n) || !out_xyz) return PCDHIP_E_ARG;
+static int points_sum_common(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xyz, size_t n, uint64_t* out_xyz, bool in_on_device) {
+  if (!ctx || !valid_curve(curve_id) || !valid_group(group_id) || (!xyz && n) || !out_xyz || (n >> 24)) return PCDHIP_E_ARG;
   BIND();
   const GroupEntry& ge = group_entry(curve_id, group_id);
-  const size_t jb = (size_t)ge.point_abi_words / 2 * 3 * 4;
-  TRY(ctx->aux_ws.ensure(AUX_MISC, (n + 1) * jb));
-  uint32_t* d = (uint32_t*)ctx->aux_ws.buf[AUX_MISC];
-  TRY(hipMemcpyAsync(d + jb / 4, xyz, n * jb, hipMemcpyHostToDevice, ctx->stream));
-  TRY(ge.points_sum(ctx->stream, d + jb / 4, (uint32_t)n, d));
+  const size_t jb = (size_t)ge.point_abi_words / 2 * 3 * 4, ji = (size_t)ge.point_words / 2 * 3 * 4;
+  TRY(ctx->aux_ws.ensure(AUX_MISC, (n + 1) * jb + 64 * ji + 64));
+  uint32_t* d = (uint32_t*)ctx->aux_ws.buf[AUX_MISC];  // result | staged input | tree scratch
+  uint32_t* scratch = d + (n + 1) * jb / 4;
+  const uint32_t* in = (const uint32_t*)xyz;
+  if (!in_on_device) {
+    TRY(hipMemcpyAsync(d + jb / 4, xyz, n * jb, hipMemcpyHostToDevice, ctx->stream));
+    in = d + jb / 4;
+  }
+  TRY(ge.points_sum(ctx->stream, in, (uint32_t)n, scratch, d));
   TRY(hipMemcpyAsync(out_xyz, d, jb, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
   return PCDHIP_OK;
+}
+int pcdhip_points_sum(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xyz, size_t n, uint64_t* out_xyz) {
+  return points_sum_common(ctx, curve_id, group_id, xyz, n, out_xyz, false);
+}
+int pcdhip_points_sum_dev(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xyz_device, size_t n, uint64_t* out_xyz) {
+  return points_sum_common(ctx, curve_id, group_id, xyz_device, n, out_xyz, true);
 }
 
 int pcdhip_to_affine(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xyz, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
@@ -788,9 +810,8 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
     jobs[nj++] = {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, slot(0), 1, nullptr, nullptr, NONE};        // h
     jobs[nj++] = {&g1, pk->l_query->view(0), z_can, mt, slot(1), 2, nullptr, nullptr, CONSUME};               // l'
   }
-  static const int serial_streams = getenv("PCD_G16_STREAMS") ? atoi(getenv("PCD_G16_STREAMS")) : 6;
   for (int k = 0; k < nj; k++) {
-    hipStream_t sk = ctx->g16_streams[k % serial_streams];
+    hipStream_t sk = ctx->g16_streams[k];
     TRY(hipStreamWaitEvent(sk, ctx->g16_ready, 0));
     TRY(hipEventRecord(ctx->g16_begin[k], sk));
     TRY(jobs[k].ge->msm(ctx->g16_ws[k], sk, jobs[k].bv, jobs[k].sc, jobs[k].n, jobs[k].out, ctx->msm_c, ctx->msm_chunk, ctx->msm_sort, nullptr,
@@ -852,12 +873,10 @@ int pcdhip_fixed_base_mul(pcdhip_ctx* ctx, int curve_id, int group_id, const uin
   BIND();
   const GroupEntry& ge = group_entry(curve_id, group_id);
   const size_t ab = (size_t)ge.point_abi_words * 4, sb = (size_t)ge.scalar_words * 4;
-  TRY(ctx->aux_ws.ensure(AUX_SCAL, n * sb + ab + 64));
+  const size_t base_off = (n * sb + 63) / 64 * 64;  // the base point sits behind the scalars
+  TRY(ctx->aux_ws.ensure(AUX_SCAL, base_off + ab));
   uint32_t* sc = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
-  uint32_t* base_dev = (uint32_t*)((char*)sc + (n * sb + 63) / 64 * 64);
-  TRY(ctx->aux_ws.ensure(AUX_SCAL, (n * sb + 63) / 64 * 64 + ab));
-  sc = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
-  base_dev = (uint32_t*)((char*)sc + (n * sb + 63) / 64 * 64);
+  uint32_t* base_dev = (uint32_t*)((char*)sc + base_off);
   if (n) TRY(hipMemcpyAsync(sc, scalars, n * sb, hipMemcpyHostToDevice, ctx->stream));
   TRY(hipMemcpyAsync(base_dev, base_xy, ab, hipMemcpyHostToDevice, ctx->stream));
   uint32_t* pts;

@@ -83,7 +83,7 @@ typedef hipError_t (*MsmFn)(MsmWorkspace&, hipStream_t, const MsmBasesView& base
                             uint32_t* out_dev, int c, uint32_t chunk, int sort_mode, MsmTimings* tm, MsmSharedSort* share,
                             int share_role);
 typedef hipError_t (*PrecomputeFn)(hipStream_t, uint32_t* pts, uint32_t n, int groups, int shift);
-typedef hipError_t (*PointsSumFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* out_dev);
+typedef hipError_t (*PointsSumFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* scratch /* 64 Jacobians */, uint32_t* out_dev);
 typedef hipError_t (*ToAffineFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* aff_dev);
 struct GroupEntry {
   int point_words;      // u32 words per affine point, device-internal image (Jacobian = 3/2 of it)

@@ -30,10 +30,22 @@ namespace {
 typedef typename GT::F F;
 
 // host-facing utilities: inputs and outputs in the C-ABI image
-__global__ void __launch_bounds__(64) points_sum_kernel(const uint32_t* __restrict__ in_abi, uint32_t n, uint32_t* __restrict__ out_abi) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__global__ void __launch_bounds__(64) points_sum_kernel(const uint32_t* __restrict__ in_abi, uint32_t n, uint32_t* __restrict__ scratch,
+                                                        uint32_t* __restrict__ out_abi) {
+  // one wave: strided partial sums per lane, then a tree through `scratch` (64 Jacobian points, device image)
+  if (blockIdx.x != 0) return;
   Jac<F> acc = Jac<F>::infinity();
-  for (uint32_t i = 0; i < n; i++) acc = EC<GT>::add(acc, Jac<F>::from_abi(in_abi + (size_t)i * Jac<F>::ABI_WORDS));
+  for (uint32_t i = threadIdx.x; i < n; i += 64) acc = EC<GT>::add(acc, Jac<F>::from_abi(in_abi + (size_t)i * Jac<F>::ABI_WORDS));
+  acc.store(scratch + (size_t)threadIdx.x * Jac<F>::WORDS);
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s && threadIdx.x + s < n) {  // (lanes >= n hold the identity)
+      acc = EC<GT>::add(acc, Jac<F>::load(scratch + (size_t)(threadIdx.x + s) * Jac<F>::WORDS));
+      acc.store(scratch + (size_t)threadIdx.x * Jac<F>::WORDS);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
   if (acc.is_inf()) acc = Jac<F>::infinity();
   acc.to_abi(out_abi);
 }
@@ -61,8 +73,8 @@ hipError_t jac_out_entry(hipStream_t st, const uint32_t* in, uint32_t n, uint32_
   hipLaunchKernelGGL((jac_internal_to_abi_kernel<GT>), dim3((n + 63) / 64), dim3(64), 0, st, in, n, abi);
   return hipGetLastError();
 }
-hipError_t points_sum_entry(hipStream_t st, const uint32_t* jac, uint32_t n, uint32_t* out) {
-  hipLaunchKernelGGL(points_sum_kernel, dim3(1), dim3(64), 0, st, jac, n, out);
+hipError_t points_sum_entry(hipStream_t st, const uint32_t* jac, uint32_t n, uint32_t* scratch, uint32_t* out) {
+  hipLaunchKernelGGL(points_sum_kernel, dim3(1), dim3(64), 0, st, jac, n, scratch, out);
   return hipGetLastError();
 }
 hipError_t to_affine_entry(hipStream_t st, const uint32_t* jac, uint32_t n, uint32_t* aff) {

@@ -33,3 +33,27 @@ def sharded_msm(msm_fn, sum_fn, n, device=None):
     lo, hi = shard_range(n, dist.get_rank(), dist.get_world_size())
     part = msm_fn(lo, hi)
     return sum_fn(all_gather_points(part, device))
+
+
+class DeviceExchange:
+    """The exchange step with no host round trip (GPU ranks): the shard's partial lands in a torch tensor that is the send
+    buffer of `all_gather_into_tensor` (RCCL), the receive buffer is summed in place on the device."""
+
+    def __init__(self, ctx, curve, group, device):
+        import torch
+        import torch.distributed as dist
+        from . import capi
+        self.ctx, self.curve, self.group = ctx, curve, group
+        self.world = dist.get_world_size()
+        limbs = 3 * capi.point_limbs(curve, group) // 2
+        self.send = torch.zeros(limbs, dtype=torch.int64, device=device)
+        self.recv = torch.zeros(self.world * limbs, dtype=torch.int64, device=device)
+
+    def msm(self, bases, scalars_buf):
+        import torch
+        import torch.distributed as dist
+        self.ctx.msm_partial_to_device(bases, scalars_buf, self.send.data_ptr())
+        self.ctx.sync()                                   # the library's stream -> torch's
+        dist.all_gather_into_tensor(self.recv, self.send)
+        torch.cuda.current_stream().synchronize()         # torch's stream -> the library's
+        return self.ctx.points_sum_device(self.curve, self.group, self.recv.data_ptr(), self.world)
