@@ -34,6 +34,10 @@ def golden():
 @pytest.fixture(scope="session")
 def gpu_ctx():
     """libpcdhip.so context on cuda:0.  No fallback: a missing library or GPU is an error, not a skip."""
+    # torch first, as in bench.py: its wheel carries its own HIP runtime, and whichever runtime is loaded first owns the
+    # device for the process (the device-resident exchange test hands torch tensors to the library)
+    import torch
+    torch.zeros(1, device="cuda:0")
     from pcd_amd import capi
     ctx = capi.Context(0)
     yield ctx

@@ -126,6 +126,32 @@ def test_points_sum_and_device_scalars(co, gpu_ctx):
     b.free(); sb.free()
 
 
+@pytest.mark.parametrize("cid,grp,world", [(0, 1, 8), (1, 2, 5), (2, 1, 3), (0, 2, 70)])
+def test_device_resident_exchange(co, gpu_ctx, cid, grp, world):
+    """The N > 1 exchange without host round trips (pcdhip_msm_dev_partial / pcdhip_points_sum_dev): partials written
+    into device memory that stands in for the RCCL buffers, summed there; also infinity partials and n > 64 points."""
+    import torch
+    fr = co.CURVE_FR[cid]
+    n = 64 * world
+    pts = co.gen_points(cid, grp, n, seed=31)
+    sc = co.gen_scalars(fr, n, seed=32)
+    sc[:64] = 0                                               # the first shard sums to infinity
+    limbs = 3 * co.point_words(cid, grp) // 2
+    recv = torch.zeros(world * limbs, dtype=torch.int64, device="cuda:0")
+    b = gpu_ctx.bases_upload(cid, grp, pts)
+    for r in range(world):
+        sb = gpu_ctx.buf_upload(fr, sc[64 * r:64 * (r + 1)])
+        gpu_ctx.msm_partial_to_device(b, sb, recv.data_ptr() + 8 * limbs * r, offset=64 * r, n=64)
+        gpu_ctx.sync()
+        sb.free()
+    got = gpu_ctx.points_sum_device(cid, grp, recv.data_ptr(), world)
+    want = co.to_affine(cid, grp, co.msm(cid, grp, pts, sc, nthreads=8))
+    assert np.array_equal(co.to_affine(cid, grp, got)[0], want[0])
+    parts = recv.cpu().numpy().view(np.uint64).reshape(world, limbs)
+    assert co.to_affine(cid, grp, parts[:1])[1][0] == 1       # shard 0: the point at infinity
+    b.free()
+
+
 @pytest.mark.parametrize("dist", [0, 1])
 def test_full_size_2_20(co, gpu_ctx, dist):
     """BASELINE size (MNT4-298 G1, n = 2^20): direct parity with the multi-threaded oracle, plus linearity
