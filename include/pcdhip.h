@@ -175,9 +175,10 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
 int pcdhip_groth16_last_timings(pcdhip_ctx* ctx, float out_ms[8]);
 /* How pcdhip_groth16_prove obtains the two variable-base products s*A and r*B_1 of upstream's assembly
  * (ark-groth16 create_proof, reached from src/ec_cycle_pcd/mod.rs:171,179); the proof is the same either way:
- *   0 (default) one-lane windowed products queued behind the A / B_1 MSMs on high-priority streams, hidden under the
- *               longer MSMs (B in G2, h, l) of the same proof;
- *   1           folded into two more MSMs over the a / b_g1 bases with every scalar multiplied by s / r. */
+ *   2  one-lane windowed products queued behind the A / B_1 MSMs on high-priority streams, hidden under the longer
+ *      MSMs (B in G2, h, l) of the same proof;
+ *   1  folded into two more MSMs over the a / b_g1 bases with every scalar multiplied by s / r;
+ *   0  (default) automatic: 2, except for small proofs over the 753-bit fields, where 1 is faster. */
 int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode);
 
 /* ---- the caller side of the path -- key generation -------------------------------------

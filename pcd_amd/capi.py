@@ -260,7 +260,7 @@ class Context:
         return proof, inf
 
     def groth16_set_assembly(self, mode):
-        """0: chained one-lane products s*A, r*B_1 overlapping the other MSMs (default); 1: folded into two extra MSMs."""
+        """0: automatic (default); 1: s*A, r*B_1 folded into two extra MSMs; 2: chained one-lane products overlapping the other MSMs."""
         self._check(lib().pcdhip_groth16_set_assembly(self._ctx, int(mode)))
 
     def groth16_last_timings(self):

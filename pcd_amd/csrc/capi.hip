@@ -351,7 +351,7 @@ int pcdhip_msm_set_sort(pcdhip_ctx* ctx, int mode) {
   return PCDHIP_OK;
 }
 int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode) {
-  if (!ctx || mode < 0 || mode > 1) return PCDHIP_E_ARG;
+  if (!ctx || mode < 0 || mode > 2) return PCDHIP_E_ARG;
   ctx->g16_assembly = mode;
   return PCDHIP_OK;
 }
@@ -792,7 +792,10 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   if (!ctx->g16_share.ready) TRY(hipEventCreateWithFlags(&ctx->g16_share.ready, hipEventDisableTiming));
   ctx->g16_share.valid = false;
   const uint32_t mt = (uint32_t)(m + 4);
-  const bool folded = ctx->g16_assembly == 1;
+  // automatic choice: the one-lane products cost ~5 ms (298-bit) / ~75 ms (753-bit) of latency that hides under the other
+  // MSMs of a large proof; two more MSMs cost 2 x 3.5 ms (298-bit, 2^20) / 2 x 8 ms (753-bit, 2^16) of throughput.  Measured:
+  // chained wins everywhere except the small 753-bit proofs (help proof at 5 * 2^14: 101 vs 125 ms folded).
+  const bool folded = ctx->g16_assembly == 1 || (ctx->g16_assembly == 0 && fe.abi_words > 12 && m + 4 <= (1u << 18));
   Job jobs[6];
   int nj = 0;
   // a', b1', b2', l' are indexed alike and take the same scalars z || t: the first of them sorts, the others reuse its list

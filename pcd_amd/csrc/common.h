@@ -71,7 +71,7 @@ struct pcdhip_ctx {
   float fft_ms[8] = {0};
   int fft_passes = 0;
   float g16_ms[8] = {0};
-  int g16_assembly = 0;  // s*A and r*B_1: 0 chained one-lane products overlapping the other MSMs, 1 folded into two extra MSMs
+  int g16_assembly = 0;  // s*A and r*B_1: 0 automatic, 1 folded into two extra MSMs, 2 chained one-lane products
   hipEvent_t t0 = nullptr, t1 = nullptr;
   std::string last_hip_error;
 };

@@ -67,6 +67,20 @@ struct G2Cfg3 {  // twist over Fq3: a' = (0, 0, a) = a u^2;  x u^2 = (nr c1, nr 
   PCD_HD static F mul_by_a(const F& x) { return {x.c1.mul_small(A * NR), x.c2.mul_small(A * NR), x.c0.mul_small(A)}; }
 };
 
+// lane-split form of the Fq2 twist (fp.cuh Fp2S): used by the bucket accumulation of the 753-bit G2
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+struct G2Cfg2S {
+  typedef Fp2S<Fp<FQ, false>, NR> F;
+  typedef FRP FR;
+  static constexpr int CURVE_ID = CURVE;
+  static constexpr int GROUP = 2;
+  PCD_DEV static F mul_by_a(const F& x) { return x.mul_small(A * NR); }
+};
+// SplitOf<G>: the group configuration a throughput kernel should compute in, and how many lanes share one point (2^SHIFT)
+template <class G> struct SplitOf { typedef G type; static constexpr int SHIFT = 0; };
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+struct SplitOf<G2Cfg2<FQ, FRP, A, NR, CURVE, false>> { typedef G2Cfg2S<FQ, FRP, A, NR, CURVE> type; static constexpr int SHIFT = 1; };
+
 typedef G1Cfg<F298A, F298B, PCD_MNT4_298_A_SMALL, 0> G1_MNT4_298;
 typedef G1Cfg<F298B, F298A, PCD_MNT6_298_A_SMALL, 1> G1_MNT6_298;
 typedef G1Cfg<F753A, F753B, PCD_MNT4_753_A_SMALL, 2> G1_MNT4_753;

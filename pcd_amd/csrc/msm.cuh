@@ -390,9 +390,12 @@ __global__ void __launch_bounds__(64, PCD_ACC_MIN_WAVES) msm_accumulate_kernel(c
                                                             const uint32_t* __restrict__ off, uint32_t nkeys,
                                                             uint32_t chunk, uint32_t* __restrict__ buckets,
                                                             uint32_t* __restrict__ piece_first, uint32_t* __restrict__ piece_last) {
-  typedef typename G::F F;
-  typedef EC<G> E;
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  // GA: the configuration the arithmetic runs in -- G itself, or its lane-split form (753-bit Fq2: two adjacent lanes
+  // share one chunk, each holding one coefficient of every coordinate; memory images are the same)
+  typedef typename SplitOf<G>::type GA;
+  typedef typename GA::F F;
+  typedef EC<GA> E;
+  uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> SplitOf<G>::SHIFT;
   const uint32_t M = off[nkeys];  // total sorted entries: read on the device, the host never waits for it
   uint64_t start64 = (uint64_t)t * chunk;
   if (start64 >= M) return;
@@ -403,20 +406,30 @@ __global__ void __launch_bounds__(64, PCD_ACC_MIN_WAVES) msm_accumulate_kernel(c
   nxt_cur = cur;
   bool open_start = cur.key_start < start;  // current run began in an earlier chunk
   // the running sum: Jacobian, or (G1 of the 298-bit curves) the lazily reduced accumulator of EC::madd_lz
-  typename std::conditional<LazyCapable<F>::value, MsmRunLazy<G>, MsmRunPlain<G>>::type acc;
-  Aff<F> nxt = Aff<F>::load(bases + (size_t)msm_entry(src, compact, cur, start) * Aff<F>::WORDS);
+  typename std::conditional<LazyCapable<F>::value, MsmRunLazy<GA>, MsmRunPlain<GA>>::type acc;
+  // The next point is prefetched while the current addition runs -- except for the 753-bit fields, whose products are
+  // function calls: the 54 .. 162 registers of a prefetched point are live across eleven calls per addition and get spilled
+  // around every one of them (same-box A/B on MI355X: G1-753 31.4 -> 27.5 ms at 2^19, split Fq2-753 37.6 -> 33.3 ms at 2^17,
+  // Fq3-753 73 -> 47 ms at 2^16 without the prefetch).
+  constexpr bool PREFETCH = F::Base::INLINE_ARITH;
+  Aff<F> nxt;
+  if (PREFETCH) nxt = Aff<F>::load(bases + (size_t)msm_entry(src, compact, cur, start) * Aff<F>::WORDS);
   for (uint32_t p = start; p < end; p++) {
     if (p >= cur.key_end) {  // run of `key` is complete
       if (open_start) { acc.flush(piece_first + (size_t)t * Jac<F>::WORDS); open_start = false; }
       else acc.flush(buckets + (size_t)cur.key * Jac<F>::WORDS);
       cur.advance_to(off, p);
     }
-    Aff<F> pt = nxt;
-    if (p + 1 < end) {
-      nxt_cur.advance_to(off, p + 1);
-      nxt = Aff<F>::load(bases + (size_t)msm_entry(src, compact, nxt_cur, p + 1) * Aff<F>::WORDS);
+    if (PREFETCH) {
+      Aff<F> pt = nxt;
+      if (p + 1 < end) {
+        nxt_cur.advance_to(off, p + 1);
+        nxt = Aff<F>::load(bases + (size_t)msm_entry(src, compact, nxt_cur, p + 1) * Aff<F>::WORDS);
+      }
+      acc.add(pt);
+    } else {
+      acc.add(Aff<F>::load(bases + (size_t)msm_entry(src, compact, cur, p) * Aff<F>::WORDS));
     }
-    acc.add(pt);
   }
   bool open_end = cur.key_end > end;
   if (open_end) acc.flush(piece_last + (size_t)t * Jac<F>::WORDS);          // also the "middle piece" case
@@ -862,8 +875,11 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   PCD_HIP_TRY(hipMemsetAsync(buckets, 0, (size_t)tkeys * PB, st));  // Z = 0: identity
   PCD_HIP_TRY(hipMemsetAsync(big_count, 0, 8, st));
   PCD_HIP_TRY(mark(8));  // the accumulate stage time is the kernel alone (mark 8 -> mark 4)
-  hipLaunchKernelGGL((msm_accumulate_kernel<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, buckets,
-                     pfirst, plast);
+  {
+    const uint64_t acc_lanes = (uint64_t)nchunks << SplitOf<G>::SHIFT;
+    hipLaunchKernelGGL((msm_accumulate_kernel<G>), dim3((uint32_t)((acc_lanes + 63) / 64)), dim3(64), 0, st, bases_dev, src, off, tkeys,
+                       pl.chunk, buckets, pfirst, plast);
+  }
   PCD_HIP_TRY(mark(4));
   // 5. pieces
   hipLaunchKernelGGL((msm_fixup_kernel<G>), dim3((tkeys + 63) / 64), dim3(64), 0, st, off, tkeys, pl.chunk, pfirst, plast, buckets,

@@ -136,14 +136,17 @@ def test_groth16_roundtrip(co, gpu_ctx, cid, nc):
     proof, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
     gpu_ctx.g16_pk_set_r1cs(pk, r)
     proof2, inf2 = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
-    gpu_ctx.groth16_set_assembly(1)  # s*A and r*B_1 as two more MSMs instead of chained one-lane products
+    gpu_ctx.groth16_set_assembly(1)  # s*A and r*B_1 as two more MSMs ...
     proof3, inf3 = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
+    gpu_ctx.groth16_set_assembly(2)  # ... or as chained one-lane products (0, the default, picks one of the two)
+    proof4, inf4 = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
     gpu_ctx.groth16_set_assembly(0)
     pk.free()
     want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=16)
     assert np.array_equal(proof, want) and np.array_equal(inf, winf)
     assert np.array_equal(proof2, want) and np.array_equal(inf2, winf)
     assert np.array_equal(proof3, want) and np.array_equal(inf3, winf)
+    assert np.array_equal(proof4, want) and np.array_equal(inf4, winf)
     pub = np.ascontiguousarray(r.z[1:r.num_inputs])
     assert co.groth16_verify(keys, pub, proof)
     bad = pub.copy()
