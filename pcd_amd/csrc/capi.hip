@@ -721,8 +721,8 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   const uint32_t sw = (uint32_t)fe.abi_words;  // words of a canonical scalar == words of an ABI element
   const size_t sb = (size_t)sw * 4;
   hipStream_t st = ctx->stream;
-  hipEvent_t ev[8];
-  for (auto& e : ev) TRY(hipEventCreate(&e));
+  EventSet<8> ev;
+  TRY(ev.create());
   TRY(hipEventRecord(ev[0], st));
   // z (C-ABI Montgomery) -> device image for the SpMV; canonical words of z, s*z and r*z (each followed by its
   // 4-entry tail, see inst_g16.hip) for the MSMs
@@ -849,7 +849,6 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   }
   (void)hipEventElapsedTime(&ctx->g16_ms[6], ev[6], ev[7]);
   (void)hipEventElapsedTime(&ctx->g16_ms[7], ev[0], ev[7]);
-  for (auto& e : ev) (void)hipEventDestroy(e);
   return PCDHIP_OK;
 }
 // ------------------------------------------------------------------------------------------------ fixed-base batches, setup

@@ -32,6 +32,20 @@
 
 namespace pcd {
 
+// a few HIP events that are destroyed on every exit path
+template <int K>
+struct EventSet {
+  hipEvent_t e[K] = {};
+  bool live = false;
+  hipError_t create() {
+    for (int i = 0; i < K; i++) { hipError_t r = hipEventCreate(&e[i]); if (r != hipSuccess) return r; }
+    live = true;
+    return hipSuccess;
+  }
+  hipEvent_t operator[](int i) const { return e[i]; }
+  ~EventSet() { for (int i = 0; i < K; i++) if (e[i]) (void)hipEventDestroy(e[i]); }
+};
+
 struct MsmPlan {
   uint32_t n = 0;
   int c = 0;           // window bits
@@ -743,8 +757,8 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   const uint64_t maxM = (uint64_t)n * pl.W;
   if (maxM >= 0xFFFFFFF0ull || (uint64_t)bv.n_total * bv.groups >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
 
-  hipEvent_t ev[9];
-  if (tm) for (auto& e : ev) PCD_HIP_TRY(hipEventCreate(&e));
+  EventSet<9> ev;
+  if (tm) PCD_HIP_TRY(ev.create());
   auto mark = [&](int i) -> hipError_t { return tm ? hipEventRecord(ev[i], st) : hipSuccess; };
 
   // keys: pl.nkeys real buckets + 1 pseudo bucket (scalars equal to one)
@@ -943,7 +957,6 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; };
     tm->digits = el(0, 1); tm->scan = el(1, 2); tm->scatter = el(2, 8); tm->accumulate = el(8, 4);
     tm->fixup = el(4, 5); tm->tail = el(5, 6); tm->horner = el(6, 7); tm->total = el(0, 7);
-    for (auto& e : ev) (void)hipEventDestroy(e);
   }
   return hipSuccess;
 }
