@@ -197,6 +197,7 @@ def pcd_step(ctx, co):
     2^16: its scalar field has 2-adicity 17); the assignment is uniformly random field elements -- the worst case for
     the MSMs (a real witness is full of 0 / 1 values, which cost nothing / go to the pseudo bucket: `--dist 1`);
     keys resident; bit-exact vs the oracle."""
+    from pcd_amd import capi
     info = {"unit": "ms", "what": "witness map + the proof's MSMs (h, l, A, B1 on G1; B on G2) + assembly (s*A, r*B1 chained behind their MSMs, overlapping the others), per proof; R1CS synthesis (Rust host) excluded"}
     total_gpu, total_cpu = 0.0, 0.0
     for name, curve, log_n in (("main_mnt4_298", 0, 20), ("help_mnt6_298", 1, 16)):
@@ -207,6 +208,7 @@ def pcd_step(ctx, co):
         rs = co.gen_field(fr, 2, seed=SEED + 20)
         pk = ctx.g16_pk_upload(keys.host_struct(), curve)
         ctx.g16_pk_set_r1cs(pk, r)                              # matrices are fixed per circuit: resident like the key
+        r.z = capi.pinned_like(r.z)                             # the assignment is handed over in page-locked host memory
         ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)   # warm-up (FFT tables, workspaces)
         t0 = time.perf_counter()
         proof, inf = ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)

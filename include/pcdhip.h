@@ -58,6 +58,11 @@ int pcdhip_device_count(void);
 int pcdhip_init(int device_id, pcdhip_ctx** out);
 void pcdhip_destroy(pcdhip_ctx* ctx);
 int pcdhip_sync(pcdhip_ctx* ctx);
+/* Page-locked host memory for the buffers that cross PCIe on every proof (the assignment z: 42 MB at 2^20 x 298 bits):
+ * host-to-device copies from it run at full PCIe rate and without a staging copy.  Optional -- every entry point
+ * accepts ordinary host pointers. */
+int pcdhip_host_alloc(size_t bytes, void** out);
+void pcdhip_host_free(void* p);
 const char* pcdhip_last_hip_error(pcdhip_ctx* ctx);
 /* Static facts (no GPU needed). */
 int pcdhip_field_limbs(int field_id);                 /* L */

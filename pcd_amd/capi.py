@@ -41,7 +41,7 @@ class G16PkHost(C.Structure):
 _LIB = None
 
 EXPORTS = [
-    "pcdhip_strerror", "pcdhip_device_count", "pcdhip_init", "pcdhip_destroy", "pcdhip_sync", "pcdhip_last_hip_error",
+    "pcdhip_strerror", "pcdhip_device_count", "pcdhip_init", "pcdhip_destroy", "pcdhip_sync", "pcdhip_host_alloc", "pcdhip_host_free", "pcdhip_last_hip_error",
     "pcdhip_field_limbs", "pcdhip_curve_base_field", "pcdhip_curve_scalar_field", "pcdhip_point_limbs",
     "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
     "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config",
@@ -64,7 +64,7 @@ def lib():
         _LIB.pcdhip_last_hip_error.restype = C.c_char_p
         _LIB.pcdhip_destroy.restype = None
         _LIB.pcdhip_domain_size.restype = C.c_size_t
-        for name in ("pcdhip_buf_free", "pcdhip_bases_free", "pcdhip_g16_pk_free"):
+        for name in ("pcdhip_buf_free", "pcdhip_bases_free", "pcdhip_g16_pk_free", "pcdhip_host_free"):
             getattr(_LIB, name).restype = None
     return _LIB
 
@@ -336,6 +336,23 @@ class Context:
         ms = C.c_float()
         self._check(lib().pcdhip_timer_stop(self._ctx, C.byref(ms)))
         return ms.value
+
+
+def pinned_like(a):
+    """Copy of `a` in page-locked host memory (pcdhip_host_alloc); the array keeps the allocation alive."""
+    a = np.ascontiguousarray(a)
+    p = C.c_void_p()
+    rc = lib().pcdhip_host_alloc(C.c_size_t(max(a.nbytes, 1)), C.byref(p))
+    if rc:
+        raise PcdHipError(f"pcdhip_host_alloc: {lib().pcdhip_strerror(rc).decode()}")
+    buf = (C.c_char * max(a.nbytes, 1)).from_address(p.value)
+    out = np.frombuffer(buf, dtype=a.dtype, count=a.size).reshape(a.shape)
+    out[...] = a
+    _PINNED.append((out, p))   # freed at interpreter exit with the process
+    return out
+
+
+_PINNED = []
 
 
 class G16SetupOut(C.Structure):

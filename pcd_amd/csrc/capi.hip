@@ -221,6 +221,16 @@ void pcdhip_destroy(pcdhip_ctx* ctx) {
   delete ctx;
 }
 
+int pcdhip_host_alloc(size_t bytes, void** out) {
+  if (!out) return PCDHIP_E_ARG;
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e == hipErrorOutOfMemory) return PCDHIP_E_OOM;
+  return e == hipSuccess ? PCDHIP_OK : PCDHIP_E_HIP;
+}
+void pcdhip_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
 int pcdhip_sync(pcdhip_ctx* ctx) {
   if (!ctx) return PCDHIP_E_ARG;
   BIND();

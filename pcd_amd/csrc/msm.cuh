@@ -476,7 +476,10 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
   uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
   if (key >= nkeys) return;
   uint32_t lo = off[key], hi = off[key + 1];
-  if (hi == lo) return;
+  if (hi == lo) {  // empty bucket: nobody else writes it, and the identity is Z = 0 (X, Y are never looked at then)
+    F::zero().store(buckets + (size_t)key * Jac<F>::WORDS + 2 * F::WORDS);
+    return;
+  }
   uint32_t t0 = lo / chunk, t1 = (hi - 1) / chunk;
   if (t1 == t0) return;  // the whole run lies inside one chunk: msm_accumulate wrote the bucket itself
   if (t1 - t0 + 1 > big_limit) {  // big bucket: its pieces are cut into segments of seg_len, one wave each
@@ -886,7 +889,8 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   uint32_t* seg_list = big + 3 * big_cap;
   uint32_t* big_count = seg_list + 3 * seg_cap;  // [#big buckets, #segments]
   uint32_t* big_partial = (uint32_t*)ws.buf[WS_BIGPART];
-  PCD_HIP_TRY(hipMemsetAsync(buckets, 0, (size_t)tkeys * PB, st));  // Z = 0: identity
+  // (no memset of the bucket array -- 69 MB at c = 19: every bucket is written by exactly one of msm_accumulate, msm_fixup
+  //  (also the empty ones: Z = 0) and msm_big_bucket)
   PCD_HIP_TRY(hipMemsetAsync(big_count, 0, 8, st));
   PCD_HIP_TRY(mark(8));  // the accumulate stage time is the kernel alone (mark 8 -> mark 4)
   {

@@ -37,6 +37,7 @@ for name, curve, nc in (("main_mnt4_753", 2, (1 << 20) - 8), ("help_mnt6_753", 3
         keys = co.Keys(curve, r, A)
         keys.domain_size = dom
     rs = co.gen_field(fr, 2, seed=9)
+    r.z = capi.pinned_like(r.z)
     tsetup = time.time() - t
     t = time.time(); pk = ctx.g16_pk_upload(keys.host_struct(), curve); ctx.g16_pk_set_r1cs(pk, r); tup = time.time() - t
     ctx.groth16_set_assembly(2)
