@@ -752,26 +752,23 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   TRY(fe.scale_canon(st, z_dev, nullptr, z_can, (uint32_t)m, 1));
   TRY(fe.scale_canon(st, z_dev, rs_dev + sw, sz_can, (uint32_t)m, 1));
   TRY(fe.scale_canon(st, z_dev, rs_dev, rz_can, (uint32_t)m, 1));
-  // K1: h
-  Dom dom;
+  // ---- K3/K4/K5 first: the four MSMs that take the assignment (l', A, B_1 on G1; B on G2) do not need h, so they are
+  // launched before the witness map and run concurrently with it; the h MSM follows the witness map.  Results stay on the
+  // device (device image).  The two variable-base products of the assembly, s*A and r*B_1, are either one-lane products
+  // queued right behind the A / B_1 MSMs on their high-priority streams, where they overlap the longer MSMs, or two more
+  // MSMs over the same bases with every scalar scaled by s / r (pcdhip_groth16_set_assembly).
   DevCsr mats[3];
   int rc = PCDHIP_OK;
-  if (A && B && C) { TRY(hipStreamSynchronize(st)); rc = upload_three(ctx, A, B, C, fe, mats); }  // (staging slot AUX_SCAL is reused)
-  else if (!A && !B && !C && pk->r1cs_dev) {
-    for (int k = 0; k < 3; k++) mats[k] = {pk->rp[k], pk->col[k], pk->coeff[k], pk->rows};
-  } else rc = PCDHIP_E_ARG;
-  if (rc) return rc;
-  rc = witness_map_dev(ctx, fr, mats, z_dev, ni, &dom);
+  uint32_t rows = 0;
+  if (A && B && C) rows = (uint32_t)A->num_rows;
+  else if (!A && !B && !C && pk->r1cs_dev) rows = pk->rows;
+  else return PCDHIP_E_ARG;
+  Dom dom;
+  rc = pick_domain(fr, (size_t)rows + ni, &dom);
   if (rc) return rc;
   const size_t n = dom.n;
   TRY(ctx->aux_ws.ensure(AUX_H_CANON, n * sb));
   uint32_t* h_can = (uint32_t*)ctx->aux_ws.buf[AUX_H_CANON];
-  TRY(fe.convert(st, (const uint32_t*)ctx->aux_ws.buf[AUX_A], h_can, (uint32_t)n, 2));
-  TRY(hipEventRecord(ev[1], st));
-  // K3/K4/K5: concurrent MSMs (h, l', A, B_1 on G1; B on G2), results stay on device (device image).  The two
-  // variable-base products of the assembly, s*A and r*B_1, are either (assembly mode 0) one-lane products queued right
-  // behind the A / B_1 MSMs on their high-priority streams, where they overlap the longer MSMs, or (mode 1) two more
-  // MSMs over the same bases with every scalar scaled by s / r.
   const GroupEntry& g1 = group_entry(cid, 1);
   const GroupEntry& g2 = group_entry(cid, 2);
   const size_t j1 = (size_t)g1.point_words / 2 * 3 * 4, j2 = (size_t)g2.point_words / 2 * 3 * 4;
@@ -796,7 +793,7 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
       TRY(hipEventCreate(&ctx->g16_end[k]));
     }
   }
-  TRY(hipEventRecord(ctx->g16_ready, st));
+  TRY(hipEventRecord(ctx->g16_ready, st));  // the scalars z || t (and their scaled copies) are ready
   struct Job { const GroupEntry* ge; MsmBasesView bv; const uint32_t* sc; uint32_t n; uint32_t* out; int tslot; const uint32_t* k; uint32_t* kout; int share; };
   const int PRODUCE = MSM_SHARE_PRODUCE, CONSUME = MSM_SHARE_CONSUME, NONE = MSM_SHARE_NONE;
   if (!ctx->g16_share.ready) TRY(hipEventCreateWithFlags(&ctx->g16_share.ready, hipEventDisableTiming));
@@ -808,31 +805,44 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   const bool folded = ctx->g16_assembly == 1 || (ctx->g16_assembly == 0 && fe.abi_words > 12 && m + 4 <= (1u << 18));
   Job jobs[6];
   int nj = 0;
-  // a', b1', b2', l' are indexed alike and take the same scalars z || t: the first of them sorts, the others reuse its list
+  // a', b1', b2', l' are indexed alike and take the same scalars z || t: the first of them sorts, the others reuse its list.
+  // The h MSM comes last in the table: it is launched after the witness map.
   if (folded) {
     jobs[nj++] = {&g2, pk->b_g2_query->view(0), z_can, mt, msm_g2, 5, nullptr, nullptr, PRODUCE};             // B (heaviest: high priority)
     jobs[nj++] = {&g1, pk->a_query->view(0), z_can, mt, slot(2), 3, nullptr, nullptr, CONSUME};               // A
     jobs[nj++] = {&g1, pk->a_query->view(0), sz_can, mt, slot(3), 3, nullptr, nullptr, NONE};                 // s * A
     jobs[nj++] = {&g1, pk->b_g1_query->view(0), rz_can, mt, slot(4), 4, nullptr, nullptr, NONE};              // r * B_1
-    jobs[nj++] = {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, slot(0), 1, nullptr, nullptr, NONE};        // h
     jobs[nj++] = {&g1, pk->l_query->view(0), z_can, mt, slot(1), 2, nullptr, nullptr, CONSUME};               // l' (with -rs delta)
   } else {
     jobs[nj++] = {&g1, pk->a_query->view(0), z_can, mt, slot(2), 3, t1 + sw, slot(3), PRODUCE};               // A, then s * A
     jobs[nj++] = {&g1, pk->b_g1_query->view(0), z_can, mt, slot(5), 4, t1, slot(4), CONSUME};                 // B_1, then r * B_1
     jobs[nj++] = {&g2, pk->b_g2_query->view(0), z_can, mt, msm_g2, 5, nullptr, nullptr, CONSUME};             // B
-    jobs[nj++] = {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, slot(0), 1, nullptr, nullptr, NONE};        // h
     jobs[nj++] = {&g1, pk->l_query->view(0), z_can, mt, slot(1), 2, nullptr, nullptr, CONSUME};               // l'
   }
-  for (int k = 0; k < nj; k++) {
+  jobs[nj++] = {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, slot(0), 1, nullptr, nullptr, NONE};          // h
+  auto launch = [&](int k, hipEvent_t after) -> int {
     hipStream_t sk = ctx->g16_streams[k];
-    TRY(hipStreamWaitEvent(sk, ctx->g16_ready, 0));
+    TRY(hipStreamWaitEvent(sk, after, 0));
     TRY(hipEventRecord(ctx->g16_begin[k], sk));
     TRY(jobs[k].ge->msm(ctx->g16_ws[k], sk, jobs[k].bv, jobs[k].sc, jobs[k].n, jobs[k].out, ctx->msm_c, ctx->msm_chunk, ctx->msm_sort, nullptr,
                         jobs[k].share ? &ctx->g16_share : nullptr, jobs[k].share));
     if (jobs[k].k) TRY(ce.scale_g1(sk, jobs[k].out, jobs[k].k, mul_scratch + (size_t)k * 16 * (j1 / 4), jobs[k].kout));
     TRY(hipEventRecord(ctx->g16_end[k], sk));
-    TRY(hipStreamWaitEvent(st, ctx->g16_end[k], 0));
-  }
+    return PCDHIP_OK;
+  };
+  for (int k = 0; k + 1 < nj; k++) { rc = launch(k, ctx->g16_ready); if (rc) return rc; }
+  // ---- K1: h, on the context's stream, while the MSMs above run
+  if (A && B && C) { TRY(hipStreamSynchronize(st)); rc = upload_three(ctx, A, B, C, fe, mats); if (rc) return rc; }  // (staging slot AUX_SCAL is reused)
+  else for (int k = 0; k < 3; k++) mats[k] = {pk->rp[k], pk->col[k], pk->coeff[k], pk->rows};
+  Dom dom_used;
+  rc = witness_map_dev(ctx, fr, mats, z_dev, ni, &dom_used);
+  if (rc) return rc;
+  if (dom_used.n != dom.n) return PCDHIP_E_ARG;
+  TRY(fe.convert(st, (const uint32_t*)ctx->aux_ws.buf[AUX_A], h_can, (uint32_t)n, 2));
+  TRY(hipEventRecord(ev[1], st));
+  rc = launch(nj - 1, ev[1]);
+  if (rc) return rc;
+  for (int k = 0; k < nj; k++) TRY(hipStreamWaitEvent(st, ctx->g16_end[k], 0));
   TRY(hipEventRecord(ev[6], st));
   // assembly: three additions and three affine conversions (writes the proof in the C-ABI image)
   TRY(ce.assemble(st, msm_g1, msm_g2, proof_dev));
