@@ -183,7 +183,7 @@ int pcdhip_groth16_last_timings(pcdhip_ctx* ctx, float out_ms[8]);
  *   2  one-lane windowed products queued behind the A / B_1 MSMs on high-priority streams, hidden under the longer
  *      MSMs (B in G2, h, l) of the same proof;
  *   1  folded into two more MSMs over the a / b_g1 bases with every scalar multiplied by s / r;
- *   0  (default) automatic: 2, except for small proofs over the 753-bit fields, where 1 is faster. */
+ *   0  (default) automatic: 2 for large proofs, 1 for small ones (<= 2^17 variables, 2^18 over the 753-bit fields). */
 int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode);
 
 /* ---- the caller side of the path -- key generation -------------------------------------

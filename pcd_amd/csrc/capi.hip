@@ -800,9 +800,11 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   ctx->g16_share.valid = false;
   const uint32_t mt = (uint32_t)(m + 4);
   // automatic choice: the one-lane products cost ~5 ms (298-bit) / ~75 ms (753-bit) of latency that hides under the other
-  // MSMs of a large proof; two more MSMs cost 2 x 3.5 ms (298-bit, 2^20) / 2 x 8 ms (753-bit, 2^16) of throughput.  Measured:
-  // chained wins everywhere except the small 753-bit proofs (help proof at 5 * 2^14: 101 vs 125 ms folded).
-  const bool folded = ctx->g16_assembly == 1 || (ctx->g16_assembly == 0 && fe.abi_words > 12 && m + 4 <= (1u << 18));
+  // MSMs of a large proof; two more MSMs cost 2 x 3.5 ms (298-bit, 2^20) / 2 x 1 ms (298-bit, 2^16) / 2 x 8 ms (753-bit, 2^16)
+  // of throughput.  Measured (folded vs chained): 28.4 vs 26.7 ms (298-bit, 2^20), 7.9 vs 8.2 ms (298-bit, 2^16),
+  // 580 vs 536 ms (753-bit, 2^20), 99 vs 120 ms (753-bit, 5 * 2^14).
+  const size_t fold_below = fe.abi_words > 12 ? (1u << 18) : (1u << 17);
+  const bool folded = ctx->g16_assembly == 1 || (ctx->g16_assembly == 0 && m + 4 <= fold_below);
   Job jobs[6];
   int nj = 0;
   // a', b1', b2', l' are indexed alike and take the same scalars z || t: the first of them sorts, the others reuse its list.
