@@ -396,11 +396,13 @@ struct MsmRunLazy {
   PCD_DEV void flush(uint32_t* dst) { EC<G>::lz_to_jac(a).store(dst); a = EC<G>::lz_infinity(); }
 };
 
+// waves per SIMD the register allocation aims at: 2 for the inlined 298-bit arithmetic; 1 for the call-based 753-bit
+// fields, where the values that are live across the product calls then spill to AGPRs instead of scratch (same-box A/B on
+// MI355X: G1-753 accumulate 28.2 -> 24.5 ms at 2^19, split Fq2-753 34.9 -> 31.3 ms at 2^17)
 template <class G>
-#ifndef PCD_ACC_MIN_WAVES
-#define PCD_ACC_MIN_WAVES 2
-#endif
-__global__ void __launch_bounds__(64, PCD_ACC_MIN_WAVES) msm_accumulate_kernel(const uint32_t* __restrict__ bases, const MsmEntrySource src,
+struct MsmAccWaves { static constexpr int value = SplitOf<G>::type::F::Base::INLINE_ARITH ? 2 : 1; };
+template <class G>
+__global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kernel(const uint32_t* __restrict__ bases, const MsmEntrySource src,
                                                             const uint32_t* __restrict__ off, uint32_t nkeys,
                                                             uint32_t chunk, uint32_t* __restrict__ buckets,
                                                             uint32_t* __restrict__ piece_first, uint32_t* __restrict__ piece_last) {
