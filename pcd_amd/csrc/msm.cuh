@@ -396,11 +396,15 @@ struct MsmRunLazy {
   PCD_DEV void flush(uint32_t* dst) { EC<G>::lz_to_jac(a).store(dst); a = EC<G>::lz_infinity(); }
 };
 
-// waves per SIMD the register allocation aims at: 2 for the inlined 298-bit arithmetic; 1 for the call-based 753-bit
-// fields, where the values that are live across the product calls then spill to AGPRs instead of scratch (same-box A/B on
-// MI355X: G1-753 accumulate 28.2 -> 24.5 ms at 2^19, split Fq2-753 34.9 -> 31.3 ms at 2^17)
+// Waves per SIMD the register allocation of the accumulate kernel aims at: 2 for the 298-bit G1 (194 registers, no spills);
+// 1 wherever the working set does not fit 256 registers -- the extension fields and everything 753-bit -- so that it lives in
+// the 512-register budget (AGPRs) instead of scratch.  Same-box A/B on MI355X (2 -> 1): G1-753 28.2 -> 24.5 ms (2^19),
+// split Fq2-753 34.9 -> 31.3 ms (2^17), Fq3-298 29.9 -> 25.2 ms (2^20), Fq2-298 7.85 -> 7.44 ms (2^20).
 template <class G>
-struct MsmAccWaves { static constexpr int value = SplitOf<G>::type::F::Base::INLINE_ARITH ? 2 : 1; };
+struct MsmAccWaves {
+  typedef typename SplitOf<G>::type::F FA;
+  static constexpr int value = (FA::Base::INLINE_ARITH && FA::DEG == 1) ? 2 : 1;
+};
 template <class G>
 __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kernel(const uint32_t* __restrict__ bases, const MsmEntrySource src,
                                                             const uint32_t* __restrict__ off, uint32_t nkeys,
