@@ -603,7 +603,9 @@ struct Fp3 {
   PCD_HD Fp3 dbl() const { return {c0.dbl(), c1.dbl(), c2.dbl()}; }
   // schoolbook with lazy reduction, one Montgomery reduction per coefficient:
   //   c0 = a0 b0 + nr (a1 b2 + a2 b1),  c1 = a0 b1 + a1 b0 + nr a2 b2,  c2 = a0 b2 + a1 b1 + a2 b0
-  __host__ __device__ __noinline__ static void mul(Fp3& o, const Fp3& a, const Fp3& b) {
+  __host__ __device__ __noinline__ static void mul(Fp3& o, const Fp3& a, const Fp3& b) { mul_impl(o, a, b); }
+  __host__ __device__ __noinline__ static void sqr_(Fp3& o, const Fp3& a) { sqr_impl(o, a); }
+  PCD_HD static void mul_impl(Fp3& o, const Fp3& a, const Fp3& b) {
     F na1 = a.c1.mul_small(NR), na2 = a.c2.mul_small(NR);
     F r0 = F::dot3(a.c0, b.c0, na1, b.c2, na2, b.c1);
     F r1 = F::dot3(a.c0, b.c1, a.c1, b.c0, na2, b.c2);
@@ -613,7 +615,7 @@ struct Fp3 {
     o.c2 = r2;
   }
   //   c0 = a0^2 + 2 nr a1 a2,  c1 = 2 a0 a1 + nr a2^2,  c2 = a1^2 + 2 a0 a2
-  __host__ __device__ __noinline__ static void sqr_(Fp3& o, const Fp3& a) {
+  PCD_HD static void sqr_impl(Fp3& o, const Fp3& a) {
     F d0 = a.c0.dbl(), na2 = a.c2.mul_small(NR), dna1 = a.c1.mul_small(2 * NR);
     F r0 = F::dot2(a.c0, a.c0, dna1, a.c2);
     F r1 = F::dot2(d0, a.c1, na2, a.c2);
@@ -622,8 +624,11 @@ struct Fp3 {
     o.c1 = r1;
     o.c2 = r2;
   }
-  PCD_HD Fp3 operator*(const Fp3& b) const { Fp3 o; mul(o, *this, b); return o; }
-  PCD_HD Fp3 sqr() const { Fp3 o; sqr_(o, *this); return o; }
+#ifndef PCD_FQ3_INLINE
+#define PCD_FQ3_INLINE 0
+#endif
+  PCD_HD Fp3 operator*(const Fp3& b) const { Fp3 o; if constexpr (F::INLINE_ARITH && PCD_FQ3_INLINE) mul_impl(o, *this, b); else mul(o, *this, b); return o; }
+  PCD_HD Fp3 sqr() const { Fp3 o; if constexpr (F::INLINE_ARITH && PCD_FQ3_INLINE) sqr_impl(o, *this); else sqr_(o, *this); return o; }
   PCD_HD Fp3 mul_small(unsigned k) const { return {c0.mul_small(k), c1.mul_small(k), c2.mul_small(k)}; }
   PCD_HD Fp3 mul_base(const F& k) const { return {c0 * k, c1 * k, c2 * k}; }
   PCD_HD Fp3 inv() const {

@@ -39,6 +39,11 @@ extern "C" {
     pub fn pcdhip_groth16_prove(ctx: *mut pcdhip_ctx, pk: *const pcdhip_g16_pk, a: *const pcdhip_csr, b: *const pcdhip_csr, c: *const pcdhip_csr,
                                 z: *const u64, r: *const u64, s: *const u64, proof: *mut u64, inf: *mut u8) -> c_int;
     pub fn pcdhip_groth16_set_assembly(ctx: *mut pcdhip_ctx, mode: c_int) -> c_int;
+    // page-locked host memory for the assignment (optional), device-resident multi-GPU exchange
+    pub fn pcdhip_host_alloc(bytes: usize, out: *mut *mut std::os::raw::c_void) -> c_int;
+    pub fn pcdhip_host_free(p: *mut std::os::raw::c_void);
+    pub fn pcdhip_points_sum(ctx: *mut pcdhip_ctx, curve: c_int, group: c_int, xyz: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn pcdhip_points_sum_dev(ctx: *mut pcdhip_ctx, curve: c_int, group: c_int, xyz_device: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
     // key generation: generate_parameters after synthesis / FixedBaseMSM::multi_scalar_mul + batch normalisation
     pub fn pcdhip_groth16_setup(ctx: *mut pcdhip_ctx, curve: c_int, a: *const pcdhip_csr, b: *const pcdhip_csr, c: *const pcdhip_csr,
                                 num_vars: usize, num_inputs: usize, g1_xy: *const u64, g2_xy: *const u64, toxic: *const u64,
