@@ -624,11 +624,9 @@ struct Fp3 {
     o.c1 = r1;
     o.c2 = r2;
   }
-#ifndef PCD_FQ3_INLINE
-#define PCD_FQ3_INLINE 0
-#endif
-  PCD_HD Fp3 operator*(const Fp3& b) const { Fp3 o; if constexpr (F::INLINE_ARITH && PCD_FQ3_INLINE) mul_impl(o, *this, b); else mul(o, *this, b); return o; }
-  PCD_HD Fp3 sqr() const { Fp3 o; if constexpr (F::INLINE_ARITH && PCD_FQ3_INLINE) sqr_impl(o, *this); else sqr_(o, *this); return o; }
+  // (always through the non-inlined copies: with the products inlined the MNT6 G2 point kernels take > 15 min to compile)
+  PCD_HD Fp3 operator*(const Fp3& b) const { Fp3 o; mul(o, *this, b); return o; }
+  PCD_HD Fp3 sqr() const { Fp3 o; sqr_(o, *this); return o; }
   PCD_HD Fp3 mul_small(unsigned k) const { return {c0.mul_small(k), c1.mul_small(k), c2.mul_small(k)}; }
   PCD_HD Fp3 mul_base(const F& k) const { return {c0 * k, c1 * k, c2 * k}; }
   PCD_HD Fp3 inv() const {
