@@ -188,7 +188,11 @@ int pcdhip_init(int device_id, pcdhip_ctx** out) {
   pcdhip_ctx* ctx = new (std::nothrow) pcdhip_ctx();
   if (!ctx) return PCDHIP_E_OOM;
   ctx->device = device_id;
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+  // the context's own stream gets the highest priority: inside a proof it carries the witness map, whose small kernels
+  // must not queue behind the MSMs of the other streams (the h MSM waits for it)
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) != hipSuccess ||
       hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
     delete ctx;
     return PCDHIP_E_HIP;
@@ -306,7 +310,7 @@ int pcdhip_bases_upload(pcdhip_ctx* ctx, int curve_id, int group_id, const uint6
   if (ctx->precompute != 0 && n >= 64) {
     const bool full = ctx->precompute < 0;
     const int c = ctx->msm_c ? ctx->msm_c : msm_pick_window(n, ge.scalar_bits, full ? 1 : 0);
-    const int W = (ge.scalar_bits + c - 1) / c;
+    const int W = msm_num_windows(ge.scalar_bits, c);
     b->c = c;
     b->groups = full ? W : std::min(W, ctx->precompute);
   }
@@ -329,7 +333,7 @@ int pcdhip_bases_upload(pcdhip_ctx* ctx, int curve_id, int group_id, const uint6
   }
   if (e == hipSuccess) e = ge.points_in(ctx->stream, (const uint32_t*)stage, (uint32_t)n, b->dptr);
   if (e == hipSuccess && b->groups > 1) {
-    const int W = (ge.scalar_bits + b->c - 1) / b->c;
+    const int W = msm_num_windows(ge.scalar_bits, b->c);
     const int Wg = (W + b->groups - 1) / b->groups;
     e = ge.precompute(ctx->stream, b->dptr, (uint32_t)n, b->groups, b->c * Wg);
   }

@@ -54,18 +54,21 @@ struct MsmPlan {
   uint32_t chunk = 0;  // sorted entries per lane in msm_accumulate
 };
 
+// windows of a signed-digit decomposition (see "digits" below): ceil((bits + 1) / c), room for the last carry
+PCD_HD constexpr int msm_num_windows(int scalar_bits, int c) { return (scalar_bits + c) / c; }
+
 // minimise  W*n mixed adds (11 M) + Wg * 2^(c+1) full adds (16 M) over c, where Wg = bucket windows:
 // Wg = W without precomputed bases, Wg = ceil(W / groups) with them (full_precompute: Wg = 1).
 inline int msm_pick_window(size_t n, int scalar_bits, int full_precompute) {
   double best = 1e300;
   int bc = 8;
   for (int c = 6; c <= 22; c++) {
-    int W = (scalar_bits + c - 1) / c;
+    int W = msm_num_windows(scalar_bits, c);
     int Wg = full_precompute ? 1 : W;
-    double cost = (double)W * (double)n * 11.0 + (double)Wg * (double)(2u << c) * 16.0 * 1.3;
+    double cost = (double)W * (double)n * 11.0 + (double)Wg * (double)(1u << c) * 16.0 * 1.3;  // 2^(c-1) buckets per window
     // a short top window concentrates n entries on 2^top buckets: their histogram / scatter atomics serialise
     // (measured: ~35 ns per entry per hot bucket, i.e. ~1400 modmul-times)
-    int top = scalar_bits - (W - 1) * c;
+    int top = scalar_bits + 1 - (W - 1) * c;
     cost += (double)n / (double)(1u << (top > 20 ? 20 : top)) * 1400.0;
     if (cost < best) { best = cost; bc = c; }
   }
@@ -73,6 +76,18 @@ inline int msm_pick_window(size_t n, int scalar_bits, int full_precompute) {
 }
 
 // ------------------------------------------------------------------------------------------------ digits
+// Signed digits: k = sum_w d_w 2^(c w) with d_w in [-2^(c-1), 2^(c-1)]: half as many buckets per window (bucket |d|, the
+// point negated when d < 0), i.e. one more bit per window for the same bucket array.  W = ceil((bits + 1) / c) windows leave
+// room for the last carry.  An entry = base index | sign << 31.
+constexpr uint32_t MSM_NEG = 0x80000000u;
+// raw digit + carry in -> |d| (0 .. 2^(c-1)), sign flag (MSM_NEG or 0), carry out
+PCD_DEV uint32_t msm_signed(uint32_t raw, int c, uint32_t& carry, uint32_t& neg) {
+  uint32_t d = raw + carry;
+  const bool n = d > (1u << (c - 1));
+  carry = n ? 1u : 0u;
+  neg = n ? MSM_NEG : 0u;
+  return n ? (1u << c) - d : d;
+}
 template <int NS>
 PCD_DEV uint32_t msm_digit(const uint32_t* s, int w, int c) {
   int bit = w * c;
@@ -130,12 +145,13 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
   }
   if (!live || is_one) return;
   int g = 0, j = 0;
+  uint32_t carry = 0, neg;
   for (int w = 0; w < W; w++) {
-    uint32_t d = msm_digit<NS>(s, w, c);
+    uint32_t d = msm_signed(msm_digit<NS>(s, w, c), c, carry, neg);
     if (d != 0) {
       uint32_t key = ((uint32_t)j << c) | d;
       uint32_t pos = atomicAdd(&cnt[key], 1u);
-      uint32_t idx = (uint32_t)g * n_total + base_offset + i;
+      uint32_t idx = ((uint32_t)g * n_total + base_offset + i) | neg;
       if (MODE == MODE_SCATTER) sorted_idx[off[key] + pos] = idx;
       if (MODE == MODE_BIN) {
         if (pos < cap) slots[(size_t)key * cap + pos] = idx;
@@ -157,6 +173,10 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
 //   pass 2  msm_bin_sort_kernel: one workgroup per bin: LDS counting sort of its entries by the low key bits; writes
 //           the final base-index list and the per-key offsets (bins are in key order, so no global scan is needed)
 // Global atomics drop from n W to ~2 n W / TILE_ENTRIES_PER_BIN; everything else is LDS atomics and streaming.
+#ifndef PCD_SORT_UNROLL
+#define PCD_SORT_UNROLL 4
+#endif
+constexpr int MSM_SORT_UNROLL = PCD_SORT_UNROLL;  // entries per lane in flight in the per-bin counting sort
 constexpr int MSM_BIN_SHIFT = 9;          // 512 keys per bin
 constexpr int MSM_TILE = 2048;            // scalars per workgroup in passes 0 / 1
 constexpr uint32_t MSM_MAX_BINS = 8192;   // LDS histogram of a workgroup: 32 KiB
@@ -196,8 +216,9 @@ __global__ void __launch_bounds__(256) msm_coarse_kernel(const uint32_t* __restr
     }
     if (!live || is_one) continue;
     int j = 0;
+    uint32_t carry = 0, neg;
     for (int w = 0; w < W; w++) {
-      uint32_t d = msm_digit<NS>(s, w, c);
+      uint32_t d = msm_signed(msm_digit<NS>(s, w, c), c, carry, neg);
       if (d != 0) atomicAdd(&lbin[((((uint32_t)j << c) | d)) >> MSM_BIN_SHIFT], 1u);
       if (++j == Wg) j = 0;
     }
@@ -223,12 +244,13 @@ __global__ void __launch_bounds__(256) msm_coarse_kernel(const uint32_t* __restr
     for (int q = 0; q < NS; q++) { s[q] = scalars[(size_t)i * NS + q]; if (q) hi |= s[q]; }
     if (hi == 0 && s[0] <= 1) continue;  // zero or one
     int g = 0, j = 0;
+    uint32_t carry = 0, neg;
     for (int w = 0; w < W; w++) {
-      uint32_t d = msm_digit<NS>(s, w, c);
+      uint32_t d = msm_signed(msm_digit<NS>(s, w, c), c, carry, neg);
       if (d != 0) {
         uint32_t key = ((uint32_t)j << c) | d;
         uint32_t pos = atomicAdd(&lbin[key >> MSM_BIN_SHIFT], 1u);
-        entries[pos] = ((uint64_t)key << 32) | (uint64_t)((uint32_t)g * n_total + base_offset + i);
+        entries[pos] = ((uint64_t)key << 32) | (uint64_t)(((uint32_t)g * n_total + base_offset + i) | neg);
       }
       if (++j == Wg) { j = 0; g++; }
     }
@@ -273,12 +295,12 @@ static __global__ void __launch_bounds__(256) msm_bin_sort_kernel(const uint64_t
   for (uint32_t k = threadIdx.x; k < KB; k += blockDim.x) hist[k] = 0;
   __syncthreads();
   // (four entries per lane in flight: the loop is a chain of global load -> LDS atomic -> scattered store latencies)
-  for (uint32_t p0 = lo + threadIdx.x; p0 < hi; p0 += 4 * blockDim.x) {
-    uint32_t kk[4];
+  for (uint32_t p0 = lo + threadIdx.x; p0 < hi; p0 += MSM_SORT_UNROLL * blockDim.x) {
+    uint32_t kk[MSM_SORT_UNROLL];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { uint32_t p = p0 + u * blockDim.x; kk[u] = p < hi ? (uint32_t)(entries[p] >> 32) & (KB - 1) : KB; }
+    for (int u = 0; u < MSM_SORT_UNROLL; u++) { uint32_t p = p0 + u * blockDim.x; kk[u] = p < hi ? (uint32_t)(entries[p] >> 32) & (KB - 1) : KB; }
 #pragma unroll
-    for (int u = 0; u < 4; u++) if (kk[u] < KB) atomicAdd(&hist[kk[u]], 1u);
+    for (int u = 0; u < MSM_SORT_UNROLL; u++) if (kk[u] < KB) atomicAdd(&hist[kk[u]], 1u);
   }
   __syncthreads();
   // exclusive scan of the 512 counters: two per lane, wave scan, then the four wave totals
@@ -296,15 +318,15 @@ static __global__ void __launch_bounds__(256) msm_bin_sort_kernel(const uint64_t
   off[(size_t)b * KB + 2 * t] = ex;
   off[(size_t)b * KB + 2 * t + 1] = ex + c0;
   __syncthreads();
-  for (uint32_t p0 = lo + threadIdx.x; p0 < hi; p0 += 4 * blockDim.x) {
-    uint64_t e[4];
-    uint32_t pos[4];
+  for (uint32_t p0 = lo + threadIdx.x; p0 < hi; p0 += MSM_SORT_UNROLL * blockDim.x) {
+    uint64_t e[MSM_SORT_UNROLL];
+    uint32_t pos[MSM_SORT_UNROLL];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { uint32_t p = p0 + u * blockDim.x; e[u] = p < hi ? entries[p] : ~0ull; }
+    for (int u = 0; u < MSM_SORT_UNROLL; u++) { uint32_t p = p0 + u * blockDim.x; e[u] = p < hi ? entries[p] : ~0ull; }
 #pragma unroll
-    for (int u = 0; u < 4; u++) if (e[u] != ~0ull) pos[u] = atomicAdd(&hist[(uint32_t)(e[u] >> 32) & (KB - 1)], 1u);
+    for (int u = 0; u < MSM_SORT_UNROLL; u++) if (e[u] != ~0ull) pos[u] = atomicAdd(&hist[(uint32_t)(e[u] >> 32) & (KB - 1)], 1u);
 #pragma unroll
-    for (int u = 0; u < 4; u++) if (e[u] != ~0ull) sorted_idx[pos[u]] = (uint32_t)e[u];
+    for (int u = 0; u < MSM_SORT_UNROLL; u++) if (e[u] != ~0ull) sorted_idx[pos[u]] = (uint32_t)e[u];
   }
 }
 
@@ -372,8 +394,11 @@ struct MsmCursor {  // walks the buckets of consecutive list positions
     key_start = off[key];
     key_end = off[key + 1];
   }
-  PCD_DEV void advance_to(const uint32_t* __restrict__ off, uint32_t p) {
-    while (p >= key_end) { key++; key_start = key_end; key_end = off[key + 1]; }
+  // (a few linear steps -- neighbouring buckets are the common case -- then a binary search: with signed digits the upper half
+  //  of a window's key range is empty, and the lane that crosses it must not walk 2^(c-1) empty keys one load at a time)
+  PCD_DEV void advance_to(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t p) {
+    for (int step = 0; step < 4 && p >= key_end; step++) { key++; key_start = key_end; key_end = off[key + 1]; }
+    if (p >= key_end) seek(off, nkeys, p);
   }
 };
 PCD_DEV uint32_t msm_entry(const MsmEntrySource& src, bool compact, const MsmCursor& cur, uint32_t p) {
@@ -432,23 +457,30 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
   // around every one of them (same-box A/B on MI355X: G1-753 31.4 -> 27.5 ms at 2^19, split Fq2-753 37.6 -> 33.3 ms at 2^17,
   // Fq3-753 73 -> 47 ms at 2^16 without the prefetch).
   constexpr bool PREFETCH = F::Base::INLINE_ARITH;
+  auto fetch = [&](const MsmCursor& cu, uint32_t pos) {  // the entry's point, negated for a negative digit
+    const uint32_t e = msm_entry(src, compact, cu, pos);
+    Aff<F> q = Aff<F>::load(bases + (size_t)(e & ~MSM_NEG) * Aff<F>::WORDS);
+    const F ny = q.y.neg();
+    if (e & MSM_NEG) q.y = ny;
+    return q;
+  };
   Aff<F> nxt;
-  if (PREFETCH) nxt = Aff<F>::load(bases + (size_t)msm_entry(src, compact, cur, start) * Aff<F>::WORDS);
+  if (PREFETCH) nxt = fetch(cur, start);
   for (uint32_t p = start; p < end; p++) {
     if (p >= cur.key_end) {  // run of `key` is complete
       if (open_start) { acc.flush(piece_first + (size_t)t * Jac<F>::WORDS); open_start = false; }
       else acc.flush(buckets + (size_t)cur.key * Jac<F>::WORDS);
-      cur.advance_to(off, p);
+      cur.advance_to(off, nkeys, p);
     }
     if (PREFETCH) {
       Aff<F> pt = nxt;
       if (p + 1 < end) {
-        nxt_cur.advance_to(off, p + 1);
-        nxt = Aff<F>::load(bases + (size_t)msm_entry(src, compact, nxt_cur, p + 1) * Aff<F>::WORDS);
+        nxt_cur.advance_to(off, nkeys, p + 1);
+        nxt = fetch(nxt_cur, p + 1);
       }
       acc.add(pt);
     } else {
-      acc.add(Aff<F>::load(bases + (size_t)msm_entry(src, compact, cur, p) * Aff<F>::WORDS));
+      acc.add(fetch(cur, p));
     }
   }
   bool open_end = cur.key_end > end;
@@ -759,12 +791,12 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   MsmPlan pl;
   pl.n = n;
   pl.c = bv.groups > 1 ? bv.c : (c_override ? c_override : msm_pick_window(n, G::FR::BITS, 0));
-  pl.W = (G::FR::BITS + pl.c - 1) / pl.c;
+  pl.W = msm_num_windows(G::FR::BITS, pl.c);
   const int Wg = (pl.W + bv.groups - 1) / bv.groups;  // bucket windows
   pl.nkeys = (uint32_t)Wg << pl.c;
   pl.chunk = chunk_override ? chunk_override : 32;
   const uint64_t maxM = (uint64_t)n * pl.W;
-  if (maxM >= 0xFFFFFFF0ull || (uint64_t)bv.n_total * bv.groups >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+  if (maxM >= 0xFFFFFFF0ull || (uint64_t)bv.n_total * bv.groups >= 0x7FFFFFF0ull) return hipErrorInvalidValue;  // bit 31 of an entry: sign
 
   EventSet<9> ev;
   if (tm) PCD_HIP_TRY(ev.create());
@@ -797,8 +829,8 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   // 4-byte writes scattered over a 200 MB slot array against a 63 MB compact list), so the two-pass counting sort
   // stays the default (pcdhip_msm_set_sort).
   const int wins = (pl.W + Wg - 1) / Wg;  // scalar windows that share one bucket window
-  const int top_bits = G::FR::BITS - (pl.W - 1) * pl.c;
-  double mu = (double)n * wins / (double)(1u << pl.c) + (top_bits < pl.c ? (double)n / (double)(1u << top_bits) : 0.0);
+  const int top_bits = G::FR::BITS + 1 - (pl.W - 1) * pl.c;
+  double mu = (double)n * wins / (double)(1u << (pl.c - 1)) + (top_bits < pl.c ? (double)n / (double)(1u << top_bits) : 0.0);
   uint32_t cap = (uint32_t)(mu + 6.0 * sqrt(mu) + 8.0);
   cap = (cap + 7u) & ~7u;
   const bool use_slots = single_pass && (double)pl.nkeys * cap * 4.0 <= 1.5e9;
@@ -920,7 +952,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   PCD_HIP_TRY(mark(5));
   // 6. tail levels
   {
-    const uint32_t B = (1u << pl.c) - 1;
+    const uint32_t B = 1u << (pl.c - 1);  // buckets |d| = 1 .. 2^(c-1) of a window (signed digits)
     size_t cap_pts = ((size_t)1 << pl.c);  // generous per-window capacity for A'/C'
     PCD_HIP_TRY(ws.ensure(WS_A0, (size_t)Wg * cap_pts * PB / 2 + PB * Wg * 4));
     PCD_HIP_TRY(ws.ensure(WS_A1, (size_t)Wg * cap_pts * PB / 2 + PB * Wg * 4));
