@@ -227,6 +227,16 @@ int pcdhip_groth16_verify(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g
                           const uint64_t* delta_g2, const uint64_t* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs,
                           const uint64_t* public_inputs_canonical, const uint64_t* proof, const uint8_t* proof_inf, int* ok);
 
+/* the native verifications of a merge node (`ECCyclePCD::verify`, mod.rs:239, once per prior
+ * message) in one call: every Miller loop of the n_proofs checks runs in ONE launch (4 n_proofs lanes), the products and
+ * final exponentiations in another (one lane per proof).  Same verification key for all; public inputs:
+ * n_proofs x (num_inputs - 1) canonical scalars; proofs: n_proofs x (A || B || C); proofs_inf: n_proofs x 3 flags or NULL.
+ * ok[i] = 1 / 0 per proof -- deterministic, the same answers as n_proofs calls of pcdhip_groth16_verify. */
+int pcdhip_groth16_verify_batch(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, const uint64_t* beta_g2,
+                                const uint64_t* gamma_g2, const uint64_t* delta_g2, const uint64_t* gamma_abc_g1,
+                                const uint8_t* gamma_abc_inf, size_t num_inputs, size_t n_proofs,
+                                const uint64_t* public_inputs_canonical, const uint64_t* proofs, const uint8_t* proofs_inf, int* ok);
+
 /* ---- timing helpers (HIP events on the context's stream, for bench.py) ------------------------- */
 int pcdhip_timer_start(pcdhip_ctx* ctx);
 int pcdhip_timer_stop(pcdhip_ctx* ctx, float* out_ms);

@@ -48,7 +48,7 @@ EXPORTS = [
     "pcdhip_set_precompute", "pcdhip_msm_set_sort", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
     "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
-    "pcdhip_multi_pairing", "pcdhip_groth16_verify", "pcdhip_timer_start", "pcdhip_timer_stop",
+    "pcdhip_multi_pairing", "pcdhip_groth16_verify", "pcdhip_groth16_verify_batch", "pcdhip_timer_start", "pcdhip_timer_stop",
 ]
 
 
@@ -327,6 +327,22 @@ class Context:
                                                 _p(_u64(delta_g2)), _p(abc), _p(gi), C.c_size_t(abc.shape[0]), _p(pi),
                                                 _p(_u64(proof)), _p(pinf), C.byref(ok)))
         return ok.value == 1
+
+    def groth16_verify_batch(self, curve, alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1, public_inputs_canonical, proofs,
+                             gamma_abc_inf=None, proofs_inf=None):
+        """n Groth16 verifications under one key (the inputs of a merge node) with all Miller loops in one launch -> bool array."""
+        abc = _u64(gamma_abc_g1).reshape(-1, point_limbs(curve, G1))
+        ni = abc.shape[0]
+        pr = _u64(proofs).reshape(-1, 2 * point_limbs(curve, G1) + point_limbs(curve, G2))
+        k = pr.shape[0]
+        pi = _u64(public_inputs_canonical).reshape(k, (ni - 1) * FIELD_LIMBS[CURVE_FR[curve]]) if ni > 1 else None
+        ok = (C.c_int * max(k, 1))()
+        gi = np.ascontiguousarray(gamma_abc_inf, dtype=np.uint8) if gamma_abc_inf is not None else None
+        pinf = np.ascontiguousarray(proofs_inf, dtype=np.uint8) if proofs_inf is not None else None
+        self._check(lib().pcdhip_groth16_verify_batch(self._ctx, curve, _p(_u64(alpha_g1)), _p(_u64(beta_g2)), _p(_u64(gamma_g2)),
+                                                      _p(_u64(delta_g2)), _p(abc), _p(gi), C.c_size_t(ni), C.c_size_t(k), _p(pi), _p(pr),
+                                                      _p(pinf), ok))
+        return np.array([ok[i] == 1 for i in range(k)])
 
     # ---- timing
     def timer_start(self):

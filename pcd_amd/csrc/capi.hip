@@ -1060,14 +1060,16 @@ int pcdhip_groth16_setup(pcdhip_ctx* ctx, int curve_id, const pcdhip_csr* A, con
 }
 
 // ------------------------------------------------------------------------------------------------ pairing
-int pcdhip_multi_pairing(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy,
-                         const uint8_t* g2_inf, size_t n_pairs, uint64_t* gt_out) {
-  if (!ctx || !valid_curve(curve_id) || (n_pairs && (!g1_xy || !g2_xy)) || !gt_out || n_pairs >= (1u << 24)) return PCDHIP_E_ARG;
+// groups x per pairs -> groups GT elements
+static int pairing_groups(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy,
+                          const uint8_t* g2_inf, size_t groups, size_t per, uint64_t* gt_out) {
+  const size_t n_pairs = groups * per;
+  if (!ctx || !valid_curve(curve_id) || (n_pairs && (!g1_xy || !g2_xy)) || !gt_out || n_pairs >= (1u << 24) || (groups && !per)) return PCDHIP_E_ARG;
   BIND();
   const PairingEntry& pe = pairing_entry(curve_id);
   const size_t w1 = (size_t)pcdhip_point_limbs(curve_id, 1) * 8, w2 = (size_t)pcdhip_point_limbs(curve_id, 2) * 8;
   const size_t gb = (size_t)pe.gt_words * 4, gi = (size_t)pe.gt_internal_words * 4;
-  TRY(ctx->aux_ws.ensure(AUX_MISC, n_pairs * (w1 + w2 + gi) + gb + 256));
+  TRY(ctx->aux_ws.ensure(AUX_MISC, n_pairs * (w1 + w2 + gi) + std::max<size_t>(groups, 1) * gb + 256));
   char* d = (char*)ctx->aux_ws.buf[AUX_MISC];
   uint32_t* g1d = (uint32_t*)d;
   uint32_t* g2d = (uint32_t*)(d + n_pairs * w1);
@@ -1081,9 +1083,84 @@ int pcdhip_multi_pairing(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, c
       if (g2_inf && g2_inf[i]) TRY(hipMemsetAsync((char*)g2d + i * w2, 0, w2, ctx->stream));
     }
   }
-  TRY(pe.multi_pairing(ctx->stream, g1d, g2d, (uint32_t)n_pairs, scr, out));
-  TRY(hipMemcpyAsync(gt_out, out, gb, hipMemcpyDeviceToHost, ctx->stream));
+  TRY(pe.multi_pairing(ctx->stream, g1d, g2d, (uint32_t)groups, (uint32_t)per, scr, out));
+  TRY(hipMemcpyAsync(gt_out, out, groups * gb, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
+  return PCDHIP_OK;
+}
+int pcdhip_multi_pairing(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy,
+                         const uint8_t* g2_inf, size_t n_pairs, uint64_t* gt_out) {
+  // (one group holding every pair; with no pair at all the empty product still goes through the final exponentiation)
+  if (n_pairs == 0) {
+    if (!ctx || !valid_curve(curve_id) || !gt_out) return PCDHIP_E_ARG;
+    BIND();
+    const PairingEntry& pe = pairing_entry(curve_id);
+    TRY(ctx->aux_ws.ensure(AUX_MISC, (size_t)pe.gt_words * 4 + 256));
+    uint32_t* out = (uint32_t*)ctx->aux_ws.buf[AUX_MISC];
+    TRY(pe.multi_pairing(ctx->stream, out, out, 1, 0, out, out));
+    TRY(hipMemcpyAsync(gt_out, out, (size_t)pe.gt_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(hipStreamSynchronize(ctx->stream));
+    return PCDHIP_OK;
+  }
+  return pairing_groups(ctx, curve_id, g1_xy, g1_inf, g2_xy, g2_inf, 1, n_pairs, gt_out);
+}
+
+int pcdhip_groth16_verify_batch(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, const uint64_t* beta_g2, const uint64_t* gamma_g2,
+                                const uint64_t* delta_g2, const uint64_t* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs,
+                                size_t n_proofs, const uint64_t* public_inputs_canonical, const uint64_t* proofs, const uint8_t* proofs_inf,
+                                int* ok) {
+  if (!ctx || !valid_curve(curve_id) || !alpha_g1 || !beta_g2 || !gamma_g2 || !delta_g2 || !gamma_abc_g1 || num_inputs < 1 ||
+      (num_inputs > 1 && n_proofs && !public_inputs_canonical) || (n_proofs && (!proofs || !ok)) || n_proofs >= (1u << 20))
+    return PCDHIP_E_ARG;
+  if (n_proofs == 0) return PCDHIP_OK;
+  BIND();
+  const size_t l1 = (size_t)pcdhip_point_limbs(curve_id, 1), l2 = (size_t)pcdhip_point_limbs(curve_id, 2);
+  const int fr = kCurveFr[curve_id];
+  const size_t sl = (size_t)kFieldLimbs[fr], pl = 2 * l1 + l2;
+  const size_t k = n_proofs;
+  // acc_i = gamma_abc[0] + sum_j x_ij gamma_abc[j]: small MSMs over the same bases (scalars 1, x_i1, ...)
+  const int saved = ctx->precompute;
+  ctx->precompute = 0;
+  pcdhip_bases* gb = nullptr;
+  int rc = pcdhip_bases_upload(ctx, curve_id, 1, gamma_abc_g1, gamma_abc_inf, num_inputs, &gb);
+  ctx->precompute = saved;
+  if (rc) return rc;
+  std::vector<uint64_t> acc_j(k * (l1 / 2 * 3)), acc_a(k * l1), scal(num_inputs * sl);
+  std::vector<uint8_t> acc_inf(k, 0);
+  for (size_t i = 0; i < k && !rc; i++) {
+    std::fill(scal.begin(), scal.end(), 0);
+    scal[0] = 1;
+    if (num_inputs > 1) memcpy(&scal[sl], public_inputs_canonical + i * (num_inputs - 1) * sl, (num_inputs - 1) * sl * 8);
+    rc = pcdhip_msm(ctx, gb, 0, scal.data(), num_inputs, &acc_j[i * (l1 / 2 * 3)]);
+  }
+  pcdhip_bases_free(ctx, gb);
+  if (rc) return rc;
+  rc = pcdhip_to_affine(ctx, curve_id, 1, acc_j.data(), k, acc_a.data(), acc_inf.data());
+  if (rc) return rc;
+  // e(A_i, B_i) == e(alpha, beta) e(acc_i, gamma) e(C_i, delta): every Miller loop of the batch in one launch, one lane
+  // per proof for the products and final exponentiations
+  const PairingEntry& pe = pairing_entry(curve_id);
+  const size_t gw = (size_t)pe.gt_words / 2;
+  std::vector<uint64_t> lhs(k * gw), rhs(k * gw), g1s(3 * k * l1), g2s(3 * k * l2), a1(k * l1), b2(k * l2);
+  std::vector<uint8_t> inf1(3 * k, 0), infA(k, 0), infB(k, 0);
+  for (size_t i = 0; i < k; i++) {
+    const uint64_t* pr = proofs + i * pl;
+    memcpy(&a1[i * l1], pr, l1 * 8);
+    memcpy(&b2[i * l2], pr + l1, l2 * 8);
+    memcpy(&g1s[(3 * i) * l1], alpha_g1, l1 * 8);
+    memcpy(&g1s[(3 * i + 1) * l1], &acc_a[i * l1], l1 * 8);
+    memcpy(&g1s[(3 * i + 2) * l1], pr + l1 + l2, l1 * 8);
+    memcpy(&g2s[(3 * i) * l2], beta_g2, l2 * 8);
+    memcpy(&g2s[(3 * i + 1) * l2], gamma_g2, l2 * 8);
+    memcpy(&g2s[(3 * i + 2) * l2], delta_g2, l2 * 8);
+    inf1[3 * i + 1] = acc_inf[i];
+    if (proofs_inf) { infA[i] = proofs_inf[3 * i]; infB[i] = proofs_inf[3 * i + 1]; inf1[3 * i + 2] = proofs_inf[3 * i + 2]; }
+  }
+  rc = pairing_groups(ctx, curve_id, a1.data(), infA.data(), b2.data(), infB.data(), k, 1, lhs.data());
+  if (rc) return rc;
+  rc = pairing_groups(ctx, curve_id, g1s.data(), inf1.data(), g2s.data(), nullptr, k, 3, rhs.data());
+  if (rc) return rc;
+  for (size_t i = 0; i < k; i++) ok[i] = memcmp(&lhs[i * gw], &rhs[i * gw], gw * 8) == 0 ? 1 : 0;
   return PCDHIP_OK;
 }
 

@@ -158,9 +158,9 @@ const CurveEntry& curve_entry(int curve_id);
 struct PairingEntry {
   int gt_words;           // u32 words of one GT element (Fq4 / Fq6) at the C-ABI
   int gt_internal_words;  // ... in the device image (scratch sizing)
-  // gt_out = final_exp(prod_i miller(P_i, Q_i)); scratch: n GT elements
-  hipError_t (*multi_pairing)(hipStream_t, const uint32_t* g1_dev, const uint32_t* g2_dev, uint32_t n, uint32_t* scratch,
-                              uint32_t* gt_out);
+  // gt_out[g] = final_exp(prod_{i < per} miller(P_{g per + i}, Q_{g per + i})) for g < groups; scratch: groups * per GT elements
+  hipError_t (*multi_pairing)(hipStream_t, const uint32_t* g1_dev, const uint32_t* g2_dev, uint32_t groups, uint32_t per,
+                              uint32_t* scratch, uint32_t* gt_out);
 };
 const PairingEntry& pairing_entry(int curve_id);
 

@@ -32,19 +32,24 @@ __global__ void __launch_bounds__(64) miller_kernel(const uint32_t* __restrict__
   Fqk f = PE::miller_loop(Aff<Fq>::from_abi(g1 + (size_t)i * A1A), Aff<E>::from_abi(g2 + (size_t)i * A2A));
   f.store(out + (size_t)i * GW);
 }
-// product of the n Miller values, then one final exponentiation
-__global__ void __launch_bounds__(64) final_exp_kernel(const uint32_t* __restrict__ fs, uint32_t n, uint32_t* __restrict__ out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// one lane per group of `per` consecutive Miller values: their product, then one final exponentiation
+__global__ void __launch_bounds__(64) final_exp_kernel(const uint32_t* __restrict__ fs, uint32_t groups, uint32_t per,
+                                                       uint32_t* __restrict__ out) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= groups) return;
   typename PE::Frob t;
   frob_init<Fq, PE::K, PCT::NR>(t);
   Fqk f = Fqk::one();
-  for (uint32_t i = 0; i < n; i++) f = f * Fqk::load(fs + (size_t)i * GW);
-  PE::final_exponentiation(f, t).to_abi(out);
+  for (uint32_t i = 0; i < per; i++) f = f * Fqk::load(fs + ((size_t)g * per + i) * GW);
+  PE::final_exponentiation(f, t).to_abi(out + (size_t)g * GWA);
 }
 
-hipError_t multi_pairing(hipStream_t st, const uint32_t* g1_dev, const uint32_t* g2_dev, uint32_t n, uint32_t* scratch, uint32_t* gt_out) {
+// gt_out[g] = final_exp(prod_{i < per} miller(P_{g per + i}, Q_{g per + i})), g < groups
+hipError_t multi_pairing(hipStream_t st, const uint32_t* g1_dev, const uint32_t* g2_dev, uint32_t groups, uint32_t per, uint32_t* scratch,
+                         uint32_t* gt_out) {
+  const uint32_t n = groups * per;
   if (n) hipLaunchKernelGGL(miller_kernel, dim3((n + 63) / 64), dim3(64), 0, st, g1_dev, g2_dev, n, scratch);
-  hipLaunchKernelGGL(final_exp_kernel, dim3(1), dim3(64), 0, st, scratch, n, gt_out);
+  if (groups) hipLaunchKernelGGL(final_exp_kernel, dim3((groups + 63) / 64), dim3(64), 0, st, scratch, groups, per, gt_out);
   return hipGetLastError();
 }
 

@@ -39,6 +39,10 @@ extern "C" {
     pub fn pcdhip_groth16_prove(ctx: *mut pcdhip_ctx, pk: *const pcdhip_g16_pk, a: *const pcdhip_csr, b: *const pcdhip_csr, c: *const pcdhip_csr,
                                 z: *const u64, r: *const u64, s: *const u64, proof: *mut u64, inf: *mut u8) -> c_int;
     pub fn pcdhip_groth16_set_assembly(ctx: *mut pcdhip_ctx, mode: c_int) -> c_int;
+    // the verifications of a merge node (ECCyclePCD::verify over every prior message) in one call
+    pub fn pcdhip_groth16_verify_batch(ctx: *mut pcdhip_ctx, curve: c_int, alpha_g1: *const u64, beta_g2: *const u64, gamma_g2: *const u64,
+                                       delta_g2: *const u64, gamma_abc_g1: *const u64, gamma_abc_inf: *const u8, num_inputs: usize,
+                                       n_proofs: usize, public_inputs: *const u64, proofs: *const u64, proofs_inf: *const u8, ok: *mut c_int) -> c_int;
     // page-locked host memory for the assignment (optional), device-resident multi-GPU exchange
     pub fn pcdhip_host_alloc(bytes: usize, out: *mut *mut std::os::raw::c_void) -> c_int;
     pub fn pcdhip_host_free(p: *mut std::os::raw::c_void);

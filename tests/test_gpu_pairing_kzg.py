@@ -56,6 +56,41 @@ def test_groth16_verify_on_gpu(co, gpu_ctx, cid, nc):
     assert not gpu_ctx.groth16_verify(*args, pub, bad_proof)
 
 
+@pytest.mark.parametrize("cid,nc", [(0, 300), (1, 200), (2, 40)])
+def test_groth16_verify_batch(co, gpu_ctx, cid, nc):
+    """The inputs of a merge node verified in one call (one launch for all Miller loops): per-proof answers equal the
+    single verification and the oracle's, including a wrong public input, a wrong proof point and an empty batch."""
+    import time
+    fr = co.CURVE_FR[cid]
+    r = co.synthetic_r1cs(fr, nc, 3, seed=61)
+    keys = co.groth16_setup(cid, r, co.gen_field(fr, 5, seed=62), nthreads=16)
+    pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
+    k = 8
+    pub = co.fp_op(fr, "to_canonical", np.ascontiguousarray(r.z[1:r.num_inputs]))
+    proofs, pubs = [], []
+    for i in range(k):
+        rs = co.gen_field(fr, 2, seed=70 + i)
+        proof, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])     # k different proofs of the same statement
+        assert not inf.any()
+        proofs.append(proof); pubs.append(pub.copy())
+    pk.free()
+    pubs[2][0, 0] ^= 1                                               # wrong public input
+    w1 = co.point_words(cid, 1)
+    proofs[5] = proofs[5].copy(); proofs[5][:w1] = keys.alpha_g1     # a valid point, wrong proof
+    args = (cid, keys.alpha_g1, keys.beta_g2, keys.gamma_g2, keys.delta_g2, keys.gamma_abc_g1)
+    t0 = time.perf_counter()
+    got = gpu_ctx.groth16_verify_batch(*args, np.stack(pubs), np.stack(proofs))
+    t_batch = time.perf_counter() - t0
+    want = np.array([i not in (2, 5) for i in range(k)])
+    assert np.array_equal(got, want)
+    t0 = time.perf_counter()
+    single = np.array([gpu_ctx.groth16_verify(*args, pubs[i], proofs[i]) for i in range(k)])
+    t_single = time.perf_counter() - t0
+    assert np.array_equal(single, want)
+    print(f"curve {cid}: {k} verifications batched {t_batch * 1e3:.1f} ms, one by one {t_single * 1e3:.1f} ms")
+    assert gpu_ctx.groth16_verify_batch(*args, np.stack(pubs)[:0], np.stack(proofs)[:0]).shape == (0,)
+
+
 def test_kzg_prefix_commitments(co, gpu_ctx):
     """Marlin/KZG10 shape: one resident `powers_of_g`, commitments are MSMs over prefixes of it (coefficients with
     leading zeros skipped by the caller: offset), plus a hiding MSM over `powers_of_gamma_g`."""
