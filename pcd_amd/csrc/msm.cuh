@@ -794,7 +794,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   pl.W = msm_num_windows(G::FR::BITS, pl.c);
   const int Wg = (pl.W + bv.groups - 1) / bv.groups;  // bucket windows
   pl.nkeys = (uint32_t)Wg << pl.c;
-  pl.chunk = chunk_override ? chunk_override : 32;
+  pl.chunk = chunk_override ? chunk_override : 40;  // sorted entries per lane (median-of-8 A/B on MI355X at 2^18 / 2^20, G1 and G2: 40 beats 32 by 3-5 %, 48 ties, 64 loses)
   const uint64_t maxM = (uint64_t)n * pl.W;
   if (maxM >= 0xFFFFFFF0ull || (uint64_t)bv.n_total * bv.groups >= 0x7FFFFFF0ull) return hipErrorInvalidValue;  // bit 31 of an entry: sign
 
