@@ -44,6 +44,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: everything else that libraries print there while we run (RCCL's
+    # version banner at communicator creation, for one) is sent to stderr by pointing fd 1 at fd 2 until the result is ready
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from pcd_amd import capi
@@ -166,7 +172,10 @@ def main():
         }
         if step_info:
             out["pcd_step"] = step_info
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.destroy_process_group()
 
