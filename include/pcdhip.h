@@ -12,7 +12,7 @@
  * Encodings (exactly the in-memory image of the upstream types, so the Rust side is a memcpy):
  *   field element   L little-endian uint64_t limbs (L = 5 for the 298-bit fields, 12 for the
  *                   753-bit fields), Montgomery form with R = 2^(64 L)       [ark-ff Fp320/Fp768]
- *   scalar (MSM)    L limbs, canonical (non-Montgomery)                      [`into_repr()`]
+ *   scalar (MSM)    L limbs, canonical (non-Montgomery, reduced: < r)        [`into_repr()`]
  *   Fq2 / Fq3       consecutive base-field elements c0, c1 (, c2)
  *   affine point    x || y, infinity in a separate byte array (nullable = no point at infinity)
  *   Jacobian point  X || Y || Z, Z = 0 means infinity                        [GroupProjective]
