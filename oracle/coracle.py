@@ -260,6 +260,31 @@ class Keys:
         return s
 
 
+def synthetic_keys(curve, r, seed):
+    """Groth16 key made of seeded on-curve points, sized for the domain `GeneralEvaluationDomain::new` picks (radix-2 or
+    mixed radix).  A real trusted setup at 2^20 takes minutes on the CPU and the prover arithmetic does not depend on the
+    key being consistent; proofs made with such a key are compared bit for bit with this oracle's, not verified."""
+    m, ni = r.num_vars, r.num_inputs
+    n = domain_size(r.field, r.num_constraints + ni)
+    g1 = gen_points(curve, 1, 2 * m + (n - 1) + (m - ni) + 3, seed=seed)
+    g2 = gen_points(curve, 2, m + 2, seed=seed + 1)
+    z8 = lambda k: np.zeros(k, dtype=np.uint8)
+    o = [0]
+
+    def take(k):
+        v = np.ascontiguousarray(g1[o[0]:o[0] + k])
+        o[0] += k
+        return v
+    A = dict(a_query=take(m), b_g1_query=take(m), h_query=take(n - 1), l_query=take(m - ni))
+    A.update(alpha_g1=take(1)[0], beta_g1=take(1)[0], delta_g1=take(1)[0])
+    A.update(b_g2_query=np.ascontiguousarray(g2[:m]), beta_g2=np.ascontiguousarray(g2[m]), delta_g2=np.ascontiguousarray(g2[m + 1]),
+             gamma_g2=np.ascontiguousarray(g2[m + 1]), gamma_abc_g1=np.ascontiguousarray(g1[:ni]), gamma_abc_inf=z8(ni),
+             a_inf=z8(m), b_g1_inf=z8(m), b_g2_inf=z8(m), h_inf=z8(n - 1), l_inf=z8(m - ni))
+    keys = Keys(curve, r, A)
+    keys.domain_size = n
+    return keys
+
+
 def groth16_setup(curve, r, toxic_mont, nthreads=1):
     """toxic_mont: (5, L) Montgomery limbs of (alpha, beta, gamma, delta, tau)."""
     w1, w2 = point_words(curve, 1), point_words(curve, 2)

@@ -1,5 +1,5 @@
 // extern "C" surface of libpcdhip.so (include/pcdhip.h).  Host orchestration only: every arithmetic
-// step is a HIP kernel from msm.cuh / fft.cuh / inst_*.hip.  There is no CPU fallback anywhere in this
+// step is a HIP kernel from msm.hip.h / fft.hip.h / inst_*.hip.  There is no CPU fallback anywhere in this
 // library -- if no GPU is usable, pcdhip_init fails with PCDHIP_E_NO_DEVICE and nothing else can be called.
 #include <string.h>
 
@@ -57,8 +57,16 @@ bool valid_curve(int c) { return c >= 0 && c < 4; }
 bool valid_field(int f) { return f >= 0 && f < 4; }
 bool valid_group(int g) { return g == 1 || g == 2; }
 
+// nothing may throw across the C ABI: bodies that use std containers run inside guarded()
+template <class Fn>
+int guarded(Fn&& body) {
+  try { return body(); }
+  catch (const std::bad_alloc&) { return PCDHIP_E_OOM; }
+  catch (...) { return PCDHIP_E_HIP; }
+}
+
 int fail(pcdhip_ctx* ctx, hipError_t e) {
-  if (ctx) ctx->last_hip_error = hipGetErrorString(e);
+  if (ctx) { try { ctx->last_hip_error = hipGetErrorString(e); } catch (...) {} }
   if (e == hipErrorOutOfMemory) return PCDHIP_E_OOM;
   if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return PCDHIP_E_NO_DEVICE;
   if (e == hipErrorInvalidValue) return PCDHIP_E_ARG;
@@ -107,6 +115,22 @@ int pick_domain(int field_id, size_t min_size, Dom* d) {
   return best ? PCDHIP_OK : PCDHIP_E_SIZE_UNSUPPORTED;
 }
 
+// affine points flagged as the point at infinity become literal zeros (0, 0) -- the device encoding of the identity
+// (not on any of the eight curves: b != 0); `flags` = one byte per point, already on the device
+__global__ void __launch_bounds__(256) zero_flagged_kernel(uint32_t* __restrict__ pts, const uint8_t* __restrict__ flags, size_t n_words,
+                                                            uint32_t words_per_point) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_words && flags[i / words_per_point]) pts[i] = 0;
+}
+hipError_t zero_flagged(hipStream_t st, uint32_t* pts_dev, uint8_t* flags_dev, const uint8_t* flags_host, size_t n, size_t point_bytes) {
+  if (!flags_host || !n) return hipSuccess;
+  hipError_t e = hipMemcpyAsync(flags_dev, flags_host, n, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return e;
+  const size_t nw = n * (point_bytes / 4);
+  hipLaunchKernelGGL(zero_flagged_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, pts_dev, flags_dev, nw, (uint32_t)(point_bytes / 4));
+  return hipGetLastError();
+}
+
 int get_tables(pcdhip_ctx* ctx, int field_id, int log_n, const FftTables** out);
 int get_mixed_tables(pcdhip_ctx* ctx, int field_id, const Dom& d, const FftTables** out) {
   uint64_t key = (1ull << 63) | ((uint64_t)field_id << 32) | d.n;
@@ -114,7 +138,7 @@ int get_mixed_tables(pcdhip_ctx* ctx, int field_id, const Dom& d, const FftTable
   if (it == ctx->fft_tables.end()) {
     FftTables t;
     TRY(field_entry(field_id).mixed_make_tables(ctx->stream, d.n, d.m, &t));
-    it = ctx->fft_tables.emplace(key, t).first;
+    try { it = ctx->fft_tables.emplace(key, t).first; } catch (...) { return PCDHIP_E_OOM; }
   }
   *out = &it->second;
   return PCDHIP_OK;
@@ -141,7 +165,7 @@ int get_tables(pcdhip_ctx* ctx, int field_id, int log_n, const FftTables** out) 
   if (it == ctx->fft_tables.end()) {
     FftTables t;
     TRY(field_entry(field_id).fft_make_tables(ctx->stream, log_n, &t));
-    it = ctx->fft_tables.emplace(key, t).first;
+    try { it = ctx->fft_tables.emplace(key, t).first; } catch (...) { return PCDHIP_E_OOM; }
   }
   *out = &it->second;
   return PCDHIP_OK;
@@ -324,13 +348,10 @@ int pcdhip_bases_upload(pcdhip_ctx* ctx, int curve_id, int group_id, const uint6
   if (e != hipSuccess) { delete b; return fail(ctx, e); }
   if (b->groups == 1) b->c = 0;
   // stage the C-ABI image, rewrite flagged points to (0, 0) (not on any of the curves: b != 0), convert
-  e = ctx->aux_ws.ensure(AUX_MISC, std::max<size_t>(n, 1) * abi_b);
+  e = ctx->aux_ws.ensure(AUX_MISC, std::max<size_t>(n, 1) * (abi_b + 1) + 64);
   char* stage = (char*)ctx->aux_ws.buf[AUX_MISC];
   if (e == hipSuccess) e = hipMemcpyAsync(stage, xy, n * abi_b, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && inf) {
-    for (size_t i = 0; i < n && e == hipSuccess; i++)
-      if (inf[i]) e = hipMemsetAsync(stage + i * abi_b, 0, abi_b, ctx->stream);
-  }
+  if (e == hipSuccess) e = zero_flagged(ctx->stream, (uint32_t*)stage, (uint8_t*)stage + n * abi_b, inf, n, abi_b);
   if (e == hipSuccess) e = ge.points_in(ctx->stream, (const uint32_t*)stage, (uint32_t)n, b->dptr);
   if (e == hipSuccess && b->groups > 1) {
     const int W = msm_num_windows(ge.scalar_bits, b->c);
@@ -394,8 +415,10 @@ static int msm_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset,
   if (out_on_device) { TRY(ge.jac_out(ctx->stream, out_dev, 1, (uint32_t*)out_xyz)); return PCDHIP_OK; }  // asynchronous
   TRY(ge.jac_out(ctx->stream, out_dev, 1, out_abi));
   TRY(hipMemcpyAsync(out_xyz, out_abi, jac_abi_b, hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t too_wide = 0;  // a scalar that is not a reduced canonical value (>= 2^bits): the digits would silently drop its top
+  if (ctx->msm_ws.last_err_dev) TRY(hipMemcpyAsync(&too_wide, ctx->msm_ws.last_err_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
-  return PCDHIP_OK;
+  return too_wide ? PCDHIP_E_ARG : PCDHIP_OK;
 }
 
 int pcdhip_msm_dev(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset,
@@ -550,11 +573,22 @@ size_t csr_bytes(const pcdhip_csr* m, const FieldEntry& fe, size_t off[3]) {
   off[2] = off[1] + nnz * fe.words * 4;
   return off[2] + (nnz * 4 + 7) / 8 * 8;
 }
-int upload_csr_to(pcdhip_ctx* ctx, const pcdhip_csr* m, const FieldEntry& fe, char* d, DevCsr* out) {
-  if (!m || !m->row_ptr || (m->num_rows >> 31)) return PCDHIP_E_ARG;
+// host-side shape check of a caller's CSR matrix: row_ptr starts at 0 and never decreases, every column index is below
+// `num_cols` (the kernels index the assignment with it) -- PCDHIP_E_ARG instead of an out-of-bounds device read
+int validate_csr(const pcdhip_csr* m, size_t num_cols) {
+  if (!m || !m->row_ptr || (m->num_rows >> 31) || m->row_ptr[0] != 0) return PCDHIP_E_ARG;
+  for (uint64_t r = 0; r < m->num_rows; r++) if (m->row_ptr[r + 1] < m->row_ptr[r]) return PCDHIP_E_ARG;
   const uint64_t nnz = m->row_ptr[m->num_rows];
-  if (nnz && (!m->col || !m->coeff)) return PCDHIP_E_ARG;
   if (nnz >> 31) return PCDHIP_E_ARG;
+  if (nnz && (!m->col || !m->coeff)) return PCDHIP_E_ARG;
+  uint32_t worst = 0;
+  for (uint64_t k = 0; k < nnz; k++) worst = std::max(worst, m->col[k]);
+  return (nnz && worst >= num_cols) ? PCDHIP_E_ARG : PCDHIP_OK;
+}
+int upload_csr_to(pcdhip_ctx* ctx, const pcdhip_csr* m, const FieldEntry& fe, size_t num_cols, char* d, DevCsr* out) {
+  int vrc = validate_csr(m, num_cols);
+  if (vrc) return vrc;
+  const uint64_t nnz = m->row_ptr[m->num_rows];
   size_t off[3];
   csr_bytes(m, fe, off);
   TRY(hipMemcpyAsync(d + off[0], m->row_ptr, (m->num_rows + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -571,11 +605,11 @@ int upload_csr_to(pcdhip_ctx* ctx, const pcdhip_csr* m, const FieldEntry& fe, ch
   out->rows = (uint32_t)m->num_rows;
   return PCDHIP_OK;
 }
-int upload_csr(pcdhip_ctx* ctx, int slot, const pcdhip_csr* m, const FieldEntry& fe, DevCsr* out) {
+int upload_csr(pcdhip_ctx* ctx, int slot, const pcdhip_csr* m, const FieldEntry& fe, size_t num_cols, DevCsr* out) {
   if (!m || !m->row_ptr) return PCDHIP_E_ARG;
   size_t off[3];
   TRY(ctx->aux_ws.ensure(slot, csr_bytes(m, fe, off) + 64));
-  return upload_csr_to(ctx, m, fe, (char*)ctx->aux_ws.buf[slot], out);
+  return upload_csr_to(ctx, m, fe, num_cols, (char*)ctx->aux_ws.buf[slot], out);
 }
 
 // h (d.n elements, device image) left in aux slot AUX_A; z_dev: m elements on device; mats: A, B, C on device
@@ -616,10 +650,11 @@ int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const u
   return PCDHIP_OK;
 }
 
-int upload_three(pcdhip_ctx* ctx, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C, const FieldEntry& fe, DevCsr out[3]) {
+int upload_three(pcdhip_ctx* ctx, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C, const FieldEntry& fe, size_t num_vars,
+                 DevCsr out[3]) {
   const pcdhip_csr* ms[3] = {A, B, C};
   const int slots[3] = {AUX_CSR_RP, AUX_CSR_COL, AUX_CSR_COEF};  // one aux slot per matrix
-  for (int k = 0; k < 3; k++) { int rc = upload_csr(ctx, slots[k], ms[k], fe, &out[k]); if (rc) return rc; }
+  for (int k = 0; k < 3; k++) { int rc = upload_csr(ctx, slots[k], ms[k], fe, num_vars, &out[k]); if (rc) return rc; }
   return PCDHIP_OK;
 }
 }  // namespace
@@ -636,7 +671,7 @@ int pcdhip_groth16_witness_map(pcdhip_ctx* ctx, int field_id, const pcdhip_csr* 
   TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_Z_CANON], (uint32_t*)ctx->aux_ws.buf[AUX_Z], (uint32_t)num_vars, 0));
   Dom dom;
   DevCsr mats[3];
-  int rc = upload_three(ctx, A, B, C, fe, mats);
+  int rc = upload_three(ctx, A, B, C, fe, num_vars, mats);
   if (rc) return rc;
   rc = witness_map_dev(ctx, field_id, mats, (const uint32_t*)ctx->aux_ws.buf[AUX_Z], num_inputs, &dom);
   if (rc) return rc;
@@ -650,6 +685,7 @@ int pcdhip_groth16_witness_map(pcdhip_ctx* ctx, int field_id, const pcdhip_csr* 
 
 // ------------------------------------------------------------------------------------------------ Groth16
 int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g16_pk** out) {
+  return guarded([&]() -> int {
   if (!ctx || !h || !out || !valid_curve((int)h->curve_id)) return PCDHIP_E_ARG;
   if (!h->alpha_g1 || !h->beta_g1 || !h->delta_g1 || !h->beta_g2 || !h->delta_g2 || !h->a_query || !h->b_g1_query ||
       !h->b_g2_query || (!h->h_query && h->h_len) || (!h->l_query && h->l_len))
@@ -695,6 +731,7 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
   if (rc) { pcdhip_g16_pk_free(ctx, pk); return rc; }
   *out = pk;
   return PCDHIP_OK;
+  });
 }
 int pcdhip_g16_pk_set_r1cs(pcdhip_ctx* ctx, pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C) {
   if (!ctx || !pk || !A || !B || !C) return PCDHIP_E_ARG;
@@ -709,7 +746,7 @@ int pcdhip_g16_pk_set_r1cs(pcdhip_ctx* ctx, pcdhip_g16_pk* pk, const pcdhip_csr*
   TRY(hipMalloc(&pk->r1cs_dev, total + 64));
   for (int k = 0; k < 3; k++) {
     DevCsr dc;
-    int rc = upload_csr_to(ctx, ms[k], fe, (char*)pk->r1cs_dev + base[k], &dc);
+    int rc = upload_csr_to(ctx, ms[k], fe, pk->num_vars, (char*)pk->r1cs_dev + base[k], &dc);
     if (rc) return rc;
     pk->rp[k] = dc.rp; pk->coeff[k] = dc.coeff; pk->col[k] = dc.col;
   }
@@ -838,7 +875,7 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   };
   for (int k = 0; k + 1 < nj; k++) { rc = launch(k, ctx->g16_ready); if (rc) return rc; }
   // ---- K1: h, on the context's stream, while the MSMs above run
-  if (A && B && C) { TRY(hipStreamSynchronize(st)); rc = upload_three(ctx, A, B, C, fe, mats); if (rc) return rc; }  // (staging slot AUX_SCAL is reused)
+  if (A && B && C) { TRY(hipStreamSynchronize(st)); rc = upload_three(ctx, A, B, C, fe, m, mats); if (rc) return rc; }  // (staging slot AUX_SCAL is reused)
   else for (int k = 0; k < 3; k++) mats[k] = {pk->rp[k], pk->col[k], pk->coeff[k], pk->rows};
   Dom dom_used;
   rc = witness_map_dev(ctx, fr, mats, z_dev, ni, &dom_used);
@@ -953,6 +990,7 @@ int transpose_csr(const pcdhip_csr* m, size_t cols, size_t limbs, HostCsrT* t) {
 
 int pcdhip_groth16_setup(pcdhip_ctx* ctx, int curve_id, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C, size_t num_vars,
                          size_t num_inputs, const uint64_t* g1_xy, const uint64_t* g2_xy, const uint64_t* toxic, pcdhip_g16_setup_out* out) {
+  return guarded([&]() -> int {
   if (!ctx || !valid_curve(curve_id) || !A || !B || !C || !g1_xy || !g2_xy || !toxic || !out) return PCDHIP_E_ARG;
   if (num_inputs < 1 || num_inputs > num_vars || (num_vars >> 31) || A->num_rows != B->num_rows || A->num_rows != C->num_rows) return PCDHIP_E_ARG;
   if (!out->alpha_g1 || !out->beta_g1 || !out->delta_g1 || !out->beta_g2 || !out->gamma_g2 || !out->delta_g2 || !out->a_query ||
@@ -1009,7 +1047,7 @@ int pcdhip_groth16_setup(pcdhip_ctx* ctx, int curve_id, const pcdhip_csr* A, con
     rc = transpose_csr(ms[k], m, limbs, &tr);
     if (rc) return rc;
     DevCsr dm;
-    rc = upload_csr(ctx, AUX_CSR_RP, &tr.view, fe, &dm);
+    rc = upload_csr(ctx, AUX_CSR_RP, &tr.view, fe, nc, &dm);
     if (rc) return rc;
     TRY(fe.spmv(st, dm.rp, dm.col, dm.coeff, dm.rows, u, 0, 0, (uint32_t)m, vecs[k]));
     TRY(hipStreamSynchronize(st));  // `tr` and the staging slot are reused by the next matrix
@@ -1057,6 +1095,7 @@ int pcdhip_groth16_setup(pcdhip_ctx* ctx, int curve_id, const pcdhip_csr* A, con
   TRY(hipStreamSynchronize(st));
   out->domain_size = n;
   return PCDHIP_OK;
+  });
 }
 
 // ------------------------------------------------------------------------------------------------ pairing
@@ -1069,19 +1108,19 @@ static int pairing_groups(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, 
   const PairingEntry& pe = pairing_entry(curve_id);
   const size_t w1 = (size_t)pcdhip_point_limbs(curve_id, 1) * 8, w2 = (size_t)pcdhip_point_limbs(curve_id, 2) * 8;
   const size_t gb = (size_t)pe.gt_words * 4, gi = (size_t)pe.gt_internal_words * 4;
-  TRY(ctx->aux_ws.ensure(AUX_MISC, n_pairs * (w1 + w2 + gi) + std::max<size_t>(groups, 1) * gb + 256));
+  const size_t gt_off = n_pairs * (w1 + w2 + gi), flag_off = gt_off + std::max<size_t>(groups, 1) * gb;
+  TRY(ctx->aux_ws.ensure(AUX_MISC, flag_off + 2 * n_pairs + 256));
   char* d = (char*)ctx->aux_ws.buf[AUX_MISC];
   uint32_t* g1d = (uint32_t*)d;
   uint32_t* g2d = (uint32_t*)(d + n_pairs * w1);
   uint32_t* scr = (uint32_t*)(d + n_pairs * (w1 + w2));
-  uint32_t* out = (uint32_t*)(d + n_pairs * (w1 + w2 + gi));
+  uint32_t* out = (uint32_t*)(d + gt_off);
   if (n_pairs) {
     TRY(hipMemcpyAsync(g1d, g1_xy, n_pairs * w1, hipMemcpyHostToDevice, ctx->stream));
     TRY(hipMemcpyAsync(g2d, g2_xy, n_pairs * w2, hipMemcpyHostToDevice, ctx->stream));
-    for (size_t i = 0; i < n_pairs; i++) {  // flagged infinities -> (0,0)
-      if (g1_inf && g1_inf[i]) TRY(hipMemsetAsync((char*)g1d + i * w1, 0, w1, ctx->stream));
-      if (g2_inf && g2_inf[i]) TRY(hipMemsetAsync((char*)g2d + i * w2, 0, w2, ctx->stream));
-    }
+    // flagged infinities -> (0, 0)
+    TRY(zero_flagged(ctx->stream, g1d, (uint8_t*)d + flag_off, g1_inf, n_pairs, w1));
+    TRY(zero_flagged(ctx->stream, g2d, (uint8_t*)d + flag_off + n_pairs, g2_inf, n_pairs, w2));
   }
   TRY(pe.multi_pairing(ctx->stream, g1d, g2d, (uint32_t)groups, (uint32_t)per, scr, out));
   TRY(hipMemcpyAsync(gt_out, out, groups * gb, hipMemcpyDeviceToHost, ctx->stream));
@@ -1109,6 +1148,7 @@ int pcdhip_groth16_verify_batch(pcdhip_ctx* ctx, int curve_id, const uint64_t* a
                                 const uint64_t* delta_g2, const uint64_t* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs,
                                 size_t n_proofs, const uint64_t* public_inputs_canonical, const uint64_t* proofs, const uint8_t* proofs_inf,
                                 int* ok) {
+  return guarded([&]() -> int {
   if (!ctx || !valid_curve(curve_id) || !alpha_g1 || !beta_g2 || !gamma_g2 || !delta_g2 || !gamma_abc_g1 || num_inputs < 1 ||
       (num_inputs > 1 && n_proofs && !public_inputs_canonical) || (n_proofs && (!proofs || !ok)) || n_proofs >= (1u << 20))
     return PCDHIP_E_ARG;
@@ -1162,11 +1202,13 @@ int pcdhip_groth16_verify_batch(pcdhip_ctx* ctx, int curve_id, const uint64_t* a
   if (rc) return rc;
   for (size_t i = 0; i < k; i++) ok[i] = memcmp(&lhs[i * gw], &rhs[i * gw], gw * 8) == 0 ? 1 : 0;
   return PCDHIP_OK;
+  });
 }
 
 int pcdhip_groth16_verify(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, const uint64_t* beta_g2, const uint64_t* gamma_g2,
                           const uint64_t* delta_g2, const uint64_t* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs,
                           const uint64_t* public_inputs_canonical, const uint64_t* proof, const uint8_t* proof_inf, int* ok) {
+  return guarded([&]() -> int {
   if (!ctx || !valid_curve(curve_id) || !alpha_g1 || !beta_g2 || !gamma_g2 || !delta_g2 || !gamma_abc_g1 || num_inputs < 1 ||
       (num_inputs > 1 && !public_inputs_canonical) || !proof || !ok)
     return PCDHIP_E_ARG;
@@ -1206,6 +1248,7 @@ int pcdhip_groth16_verify(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g
   if (rc) return rc;
   *ok = (lhs == rhs) ? 1 : 0;
   return PCDHIP_OK;
+  });
 }
 
 int pcdhip_groth16_last_timings(pcdhip_ctx* ctx, float out_ms[8]) {

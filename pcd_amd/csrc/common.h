@@ -10,7 +10,7 @@
 #include <vector>
 
 #include "../../include/pcdhip.h"
-#include "msm.cuh"
+#include "msm.hip.h"
 
 namespace pcd {
 
@@ -96,7 +96,7 @@ struct GroupEntry {
   hipError_t (*jac_out)(hipStream_t, const uint32_t* internal_dev, uint32_t n, uint32_t* abi_dev);   // Jacobian, internal -> ABI
   PointsSumFn points_sum;  // ABI in, ABI out
   ToAffineFn to_affine;    // ABI in, ABI out
-  // out[i] = k_i * base (fixed_base.cuh): base / out in the C-ABI affine image, scalars canonical words; scratch sizes in
+  // out[i] = k_i * base (fixed_base.hip.h): base / out in the C-ABI affine image, scalars canonical words; scratch sizes in
   // u32 words: fb_table_words (window table + per-window powers), 3/2 * point_words per scalar for the Jacobian results
   size_t fb_table_words;
   hipError_t (*fixed_base)(hipStream_t, const uint32_t* base_abi, const uint32_t* scalars, uint32_t n, uint32_t* table_scratch,

@@ -8,9 +8,9 @@
 //
 // Affine infinity is encoded as literal zeros (0, 0) on device: (0,0) is not on any of the eight curves
 // (b != 0), and pcdhip_bases_upload rewrites flagged points to it.  Coordinates live in the device-internal
-// field image (fp.cuh); from_abi / to_abi convert at the C-ABI.
+// field image (fp.hip.h); from_abi / to_abi convert at the C-ABI.
 #pragma once
-#include "fp.cuh"
+#include "fp.hip.h"
 
 namespace pcd {
 
@@ -41,7 +41,7 @@ struct Aff {
 
 // ------------------------------------------------------------------------------------------------ group configs
 // G: coordinate field F, scalar-field parameters FR, and multiplication by the curve coefficient a.
-// INL selects the inlined / compact variant of the field arithmetic (fp.cuh); the memory image is the same.
+// INL selects the inlined / compact variant of the field arithmetic (fp.hip.h); the memory image is the same.
 template <class FQ, class FRP, unsigned A, int CURVE, bool INL = (FQ::N <= 11)>
 struct G1Cfg {
   typedef Fp<FQ, INL> F;
@@ -67,7 +67,7 @@ struct G2Cfg3 {  // twist over Fq3: a' = (0, 0, a) = a u^2;  x u^2 = (nr c1, nr 
   PCD_HD static F mul_by_a(const F& x) { return {x.c1.mul_small(A * NR), x.c2.mul_small(A * NR), x.c0.mul_small(A)}; }
 };
 
-// lane-split form of the Fq2 twist (fp.cuh Fp2S): used by the bucket accumulation of the 753-bit G2
+// lane-split form of the Fq2 twist (fp.hip.h Fp2S): used by the bucket accumulation of the 753-bit G2
 template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
 struct G2Cfg2S {
   typedef Fp2S<Fp<FQ, false>, NR> F;
@@ -176,7 +176,7 @@ struct EC {
     }
     return r;
   }
-  // ---- mixed addition with lazily reduced coordinates (G1 of the 298-bit curves: F = Fp with the Lz helpers of fp.cuh) ----
+  // ---- mixed addition with lazily reduced coordinates (G1 of the 298-bit curves: F = Fp with the Lz helpers of fp.hip.h) ----
   // The bucket accumulation is a long chain acc <- acc + P_i; here the accumulator keeps X and Y unreduced between steps:
   //   X  carry-propagated limbs, value < 16p      Y  = 2 D, limbs < 2^29, value < 4p      Z  in [0, 2p) as usual
   // and every addition / subtraction of madd-2007-bl is limb-wise (no carry chain, no reduction); the products absorb it.

@@ -14,7 +14,7 @@
 #pragma once
 #include <vector>
 
-#include "fp.cuh"
+#include "fp.hip.h"
 
 namespace pcd {
 

@@ -10,7 +10,7 @@
 // unused); one lane per scalar adds its nwin table entries with mixed additions; a second kernel normalises FB_BATCH
 // Jacobian results per lane with one inversion (Montgomery's trick) and writes the C-ABI affine image + flags.
 #pragma once
-#include "ec.cuh"
+#include "ec.hip.h"
 
 namespace pcd {
 

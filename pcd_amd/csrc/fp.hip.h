@@ -200,7 +200,7 @@ struct Fp {
   // ---- lazily reduced arithmetic (298-bit fields only: R'/p > 2^10 leaves room) -----------------------------------------------
   // Lz = an integer >= 0 held in SIGNED 28-bit-radix limbs that are not carry-propagated: additions and subtractions are
   // limb-wise, without any carry chain or reduction mod p.  Only the products reduce: for values a < ca p, b < cb p with
-  // ca cb <= 1024 the Montgomery product (a b + m p) / R' is < 2p with normalised limbs.  The callers (ec.cuh madd_lz) keep
+  // ca cb <= 1024 the Montgomery product (a b + m p) / R' is < 2p with normalised limbs.  The callers (ec.hip.h madd_lz) keep
   // track of the value bounds (the multiple of p) and of the limb magnitudes (|a_i| |b_j| summed over a column < 2^63).
   struct Lz { int32_t v[N]; };
   // host-side harness only (tests/hostcheck, -DPCD_LZ_CHECK): every column sum is recomputed in 128 bits and compared

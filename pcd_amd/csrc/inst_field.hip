@@ -2,7 +2,7 @@
 #include "common.h"
 #include <string.h>
 
-#include "fft.cuh"
+#include "fft.hip.h"
 
 namespace pcd {
 
@@ -74,7 +74,7 @@ hipError_t make_tables(hipStream_t st, int log_n, FftTables* t) {
   return hipStreamSynchronize(st);
 }
 
-// transform x in place (tmp = ping-pong partner).  inverse: w^-1 and 1/n;  coset: see fft.cuh header.
+// transform x in place (tmp = ping-pong partner).  inverse: w^-1 and 1/n;  coset: see fft.hip.h header.
 hipError_t run(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t* tmp, int log_n, int inverse, int coset,
                float* pass_ms, int* npasses) {
   std::vector<FftPass> plan = fft_plan(log_n);

@@ -1,7 +1,7 @@
 // One object per group (compile with -DPCD_GROUP_IDX=0..7, idx = 2 * curve_id + (group_id - 1)):
 // MSM driver + small point utilities instantiated for that group.
 #include "common.h"
-#include "fixed_base.cuh"
+#include "fixed_base.hip.h"
 
 namespace pcd {
 

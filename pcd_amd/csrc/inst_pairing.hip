@@ -1,6 +1,6 @@
-// One object per curve (compile with -DPCD_CURVE_IDX=0..3): pairing kernels (pairing.cuh).
+// One object per curve (compile with -DPCD_CURVE_IDX=0..3): pairing kernels (pairing.hip.h).
 #include "common.h"
-#include "pairing.cuh"
+#include "pairing.hip.h"
 
 namespace pcd {
 

@@ -28,7 +28,7 @@
 #include <type_traits>
 #include <vector>
 
-#include "ec.cuh"
+#include "ec.hip.h"
 
 namespace pcd {
 
@@ -88,6 +88,18 @@ PCD_DEV uint32_t msm_signed(uint32_t raw, int c, uint32_t& carry, uint32_t& neg)
   neg = n ? MSM_NEG : 0u;
   return n ? (1u << c) - d : d;
 }
+// a scalar must be a reduced canonical value (< r < 2^bits): the signed recoding leaves room for one carry only, so anything
+// wider would silently drop its top bits.  Offenders raise a device flag that the host-result entry points turn into PCDHIP_E_ARG.
+template <int NS>
+PCD_DEV bool msm_scalar_too_wide(const uint32_t* s, int bits) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    if (32 * k >= bits) o |= s[k];
+    else if (32 * (k + 1) > bits) o |= s[k] >> (bits - 32 * k);
+  }
+  return o != 0;
+}
 template <int NS>
 PCD_DEV uint32_t msm_digit(const uint32_t* s, int w, int c) {
   int bit = w * c;
@@ -115,7 +127,8 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
                                                          uint32_t n_total, uint32_t base_offset, uint32_t nkeys,
                                                          uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
                                                          uint32_t* __restrict__ sorted_idx, uint32_t* __restrict__ slots, uint32_t cap,
-                                                         uint32_t* __restrict__ ones_idx, uint32_t* __restrict__ flag, int skip_ones) {
+                                                         uint32_t* __restrict__ ones_idx, uint32_t* __restrict__ flag, int skip_ones,
+                                                         int scalar_bits, uint32_t* __restrict__ err) {
   if (MODE == MODE_SCATTER && flag && *flag == 0) return;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   bool live = i < n;
@@ -126,6 +139,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
 #pragma unroll
     for (int k = 0; k < NS; k++) { s[k] = scalars[(size_t)i * NS + k]; if (k) hi |= s[k]; }
     is_one = (hi == 0 && s[0] == 1);
+    if (MODE != MODE_SCATTER && err && msm_scalar_too_wide<NS>(s, scalar_bits)) *err = 1u;
   }
   // scalars equal to one: one atomic per wave on the pseudo bucket
   unsigned long long m = __ballot(live && is_one);
@@ -186,7 +200,7 @@ __global__ void __launch_bounds__(256) msm_coarse_kernel(const uint32_t* __restr
                                                          uint32_t n_total, uint32_t base_offset, uint32_t nbins,
                                                          uint32_t* __restrict__ gbin /* WRITE: cursors (start at the bin bases) */,
                                                          uint64_t* __restrict__ entries, uint32_t* __restrict__ ones_count,
-                                                         uint32_t* __restrict__ ones_idx) {
+                                                         uint32_t* __restrict__ ones_idx, int scalar_bits, uint32_t* __restrict__ err) {
   extern __shared__ uint32_t lbin[];  // nbins counters, then (WRITE) reused as cursors
   for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) lbin[b] = 0;
   __syncthreads();
@@ -202,6 +216,7 @@ __global__ void __launch_bounds__(256) msm_coarse_kernel(const uint32_t* __restr
 #pragma unroll
       for (int q = 0; q < NS; q++) { s[q] = scalars[(size_t)i * NS + q]; if (q) hi |= s[q]; }
       is_one = (hi == 0 && s[0] == 1);
+      if (!WRITE && msm_scalar_too_wide<NS>(s, scalar_bits)) *err = 1u;
     }
     if (!WRITE) {  // the ones are listed once, in pass 0
       unsigned long long m = __ballot(live && is_one);
@@ -733,6 +748,7 @@ struct MsmWorkspace {
   // device buffers, grown on demand and reused across calls (no allocation on the hot path once warm)
   void* buf[20] = {nullptr};
   size_t cap[20] = {0};
+  const uint32_t* last_err_dev = nullptr;  // device word raised by the last MSM's digit pass when a scalar was not reduced (null: not checked)
   hipError_t ensure(int slot, size_t bytes) {
     if (cap[slot] >= bytes) return hipSuccess;
     if (buf[slot]) { hipError_t e = hipFree(buf[slot]); if (e != hipSuccess) return e; buf[slot] = nullptr; cap[slot] = 0; }
@@ -787,7 +803,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   constexpr int NS = G::FR::N32;  // canonical scalar words
   constexpr int PW = Jac<F>::WORDS;
   constexpr size_t PB = (size_t)PW * 4;
-  if (n == 0) { Jac<F> inf = Jac<F>::infinity(); return hipMemcpyAsync(out_dev, &inf, PB, hipMemcpyHostToDevice, st); }
+  if (n == 0) { ws.last_err_dev = nullptr; Jac<F> inf = Jac<F>::infinity(); return hipMemcpyAsync(out_dev, &inf, PB, hipMemcpyHostToDevice, st); }
   MsmPlan pl;
   pl.n = n;
   pl.c = bv.groups > 1 ? bv.c : (c_override ? c_override : msm_pick_window(n, G::FR::BITS, 0));
@@ -823,6 +839,9 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   uint32_t* buckets = (uint32_t*)ws.buf[WS_BUCKETS];
   uint32_t* ones_idx = (uint32_t*)ws.buf[WS_ONES];
   uint32_t* flag = ones_idx + n;  // cap-overflow flag of the single-pass binning
+  uint32_t* err = flag + 1;       // a scalar >= 2^bits was seen (msm_scalar_too_wide)
+  ws.last_err_dev = consume ? nullptr : err;
+  constexpr int SBITS = G::FR::BITS;
   // Optional single-pass binning: every bucket owns `cap` slots (mean load + 6 sigma + 8), one atomic pass instead of
   // histogram + scatter, on-device fallback to the compact list when a bucket overflows.  Measured on MI355X at
   // n = 2^20: it wins for witness-like scalars (0.37 vs 0.52 ms of sorting) and loses for uniform ones (1.64 vs 1.45 ms:
@@ -852,9 +871,9 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   } else if (use_slots) {
     PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)tkeys * 4, st));
     // 1. one pass: slots + exact histogram
-    PCD_HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
+    PCD_HIP_TRY(hipMemsetAsync(flag, 0, 8, st));
     hipLaunchKernelGGL((msm_digits_kernel<NS, MODE_BIN>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, pl.nkeys, cnt,
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr, slots, cap, ones_idx, flag, 0);
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, slots, cap, ones_idx, flag, 0, SBITS, err);
     PCD_HIP_TRY(mark(1));
     // 2. scan
     hipLaunchKernelGGL(scan_block_sums, dim3(scan_blocks), dim3(1024), 0, st, cnt, tkeys, scan_per_block, bsum);
@@ -865,7 +884,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     uint32_t* cur = (uint32_t*)ws.buf[WS_CUR];
     PCD_HIP_TRY(hipMemsetAsync(cur, 0, (size_t)tkeys * 4, st));
     hipLaunchKernelGGL((msm_digits_kernel<NS, MODE_SCATTER>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, pl.nkeys, cur,
-                       off, sorted, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, flag, 1);
+                       off, sorted, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, flag, 1, SBITS, err);
     PCD_HIP_TRY(mark(3));
     src = {sorted, slots, ones_idx, flag, cap, ones_key};
   } else if (use_partition) {
@@ -878,29 +897,30 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     uint32_t* bin_base = (uint32_t*)ws.buf[WS_CUR];
     uint32_t* cursor = bin_base + nbins + 2;
     uint32_t* ones_count = flag;  // (the binning flag word is unused on this path)
-    PCD_HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
+    PCD_HIP_TRY(hipMemsetAsync(flag, 0, 8, st));
     hipLaunchKernelGGL((msm_coarse_kernel<NS, false>), dim3(tiles), dim3(256), (size_t)nbins * 4, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total,
-                       bv.offset, nbins, cnt, (uint64_t*)nullptr, ones_count, ones_idx);
+                       bv.offset, nbins, cnt, (uint64_t*)nullptr, ones_count, ones_idx, SBITS, err);
     PCD_HIP_TRY(mark(1));
     hipLaunchKernelGGL(msm_bin_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, nbins, bin_base, cursor, ones_count, off, pl.nkeys);
     PCD_HIP_TRY(mark(2));
     hipLaunchKernelGGL((msm_coarse_kernel<NS, true>), dim3(tiles), dim3(256), (size_t)nbins * 4, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total,
-                       bv.offset, nbins, cursor, entries, ones_count, ones_idx);
+                       bv.offset, nbins, cursor, entries, ones_count, ones_idx, SBITS, err);
     hipLaunchKernelGGL(msm_bin_sort_kernel, dim3(nbins), dim3(256), 0, st, entries, bin_base, sorted, off);
     PCD_HIP_TRY(mark(3));
     src = {sorted, nullptr, ones_idx, nullptr, 0u, ones_key};
   } else {
     PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)tkeys * 4, st));
+    PCD_HIP_TRY(hipMemsetAsync(flag, 0, 8, st));
     // 1. histogram  2. scan  3. scatter (cursor = cnt reset to zero)
     hipLaunchKernelGGL((msm_digits_kernel<NS, MODE_HIST>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, pl.nkeys, cnt,
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, 0);
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, 0, SBITS, err);
     PCD_HIP_TRY(mark(1));
     hipLaunchKernelGGL(scan_block_sums, dim3(scan_blocks), dim3(1024), 0, st, cnt, tkeys, scan_per_block, bsum);
     hipLaunchKernelGGL(scan_apply, dim3(scan_blocks), dim3(1024), 0, st, cnt, tkeys, scan_per_block, bsum, scan_blocks, off);
     PCD_HIP_TRY(mark(2));
     PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)tkeys * 4, st));
     hipLaunchKernelGGL((msm_digits_kernel<NS, MODE_SCATTER>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, pl.nkeys, cnt,
-                       off, sorted, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, 0);
+                       off, sorted, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, 0, SBITS, err);
     PCD_HIP_TRY(mark(3));
     src = {sorted, nullptr, nullptr, nullptr, 0u, ones_key};
   }

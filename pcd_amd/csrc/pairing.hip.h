@@ -9,7 +9,7 @@
 // (q^(k/2) - 1)[(q + 1)] then q + w0.  One lane per (P, Q) pair: the G2 steps are fused with the line
 // evaluations instead of being precomputed; independent pairs fill a wave.
 #pragma once
-#include "ec.cuh"
+#include "ec.hip.h"
 
 namespace pcd {
 

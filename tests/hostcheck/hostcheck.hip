@@ -1,7 +1,7 @@
 // TEST HARNESS ONLY (never part of libpcdhip.so): compiles the __host__ __device__ field / curve
 // templates of pcd_amd/csrc for the HOST so that their formulas can be checked against the oracle in
 // this GPU-less container.  It exercises no kernel and is not a CPU fallback of anything.
-#include "../../pcd_amd/csrc/ec.cuh"
+#include "../../pcd_amd/csrc/ec.hip.h"
 using namespace pcd;
 
 template <class G>
@@ -87,7 +87,7 @@ extern "C" int hc_madd_chain(int curve, const uint32_t* bases, int n, uint32_t* 
   return 0;
 }
 
-#include "../../pcd_amd/csrc/pairing.cuh"
+#include "../../pcd_amd/csrc/pairing.hip.h"
 template <class PC>
 static void pairing_host(const uint32_t* g1, const uint32_t* g2, uint32_t* out) {
   typedef Pairing<PC> PE;

@@ -1,0 +1,112 @@
+"""BASELINE.json configs at their stated sizes, HIP path against the CPU oracle, through the C-ABI (bit-exact).
+
+  configs[1]  MNT4-298 / MNT6-298 Groth16 PCD step, 2^16-constraint predicate  -> composed proves: main domain 2^17, help 2^16
+              (the two SNARK::prove calls of /root/reference src/ec_cycle_pcd/mod.rs:171,179)
+  configs[2]  MNT4-753 / MNT6-753 step at 2^20: G1 MSM 2^20, G2 (Fq2) MSM 2^18, G2 (Fq3) MSM 2^16, and the composed proves
+              (main domain 2^20, help on the mixed-radix domain 5 * 2^14 its circuit size forces)
+  configs[3]  Marlin KZG multi-MSM at 2^20 over a resident 6 * 2^20-point powers vector (tests/mnt4_marlin.rs:72-75 reaches
+              KZG10::commit = prefix MSM + hiding MSM)
+
+The oracle legs take seconds to ~1 min on the GPU box's host cores; inputs are seeded."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THREADS = min(os.cpu_count() or 1, 64)
+
+
+def _msm_at_size(co, ctx, cid, grp, log_n, dist=0):
+    n = 1 << log_n
+    fr = co.CURVE_FR[cid]
+    pts = co.gen_points(cid, grp, n, seed=900 + 10 * cid + grp)
+    sc = co.gen_scalars(fr, n, seed=901 + 10 * cid + grp, dist=dist)
+    b = ctx.bases_upload(cid, grp, pts)
+    sb = ctx.buf_upload(fr, sc)
+    got = co.to_affine(cid, grp, ctx.msm(b, sb))
+    b.free(); sb.free()
+    want = co.to_affine(cid, grp, co.msm(cid, grp, pts, sc, nthreads=THREADS))
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (cid, grp, log_n)
+
+
+def test_msm_g1_mnt4_753_2p20(co, gpu_ctx):
+    _msm_at_size(co, gpu_ctx, 2, 1, 20)
+
+
+def test_msm_g2_fq2_mnt4_753_2p18(co, gpu_ctx):
+    _msm_at_size(co, gpu_ctx, 2, 2, 18)
+
+
+def test_msm_g2_fq3_mnt6_753_2p16(co, gpu_ctx):
+    _msm_at_size(co, gpu_ctx, 3, 2, 16)
+
+
+def test_msm_g2_mnt4_298_2p20_witness_like(co, gpu_ctx):
+    # the main proof's G2 MSM at config-1/2 scale with a witness-like scalar mix (zeros, ones: the pseudo bucket)
+    _msm_at_size(co, gpu_ctx, 0, 2, 20, dist=1)
+
+
+def test_msm_g2_fq3_mnt6_298_2p17(co, gpu_ctx):
+    _msm_at_size(co, gpu_ctx, 1, 2, 17)
+
+
+def _prove_at_size(co, ctx, curve, nc, seed):
+    from pcd_amd import capi
+    fr = co.CURVE_FR[curve]
+    r = co.synthetic_r1cs(fr, nc, 2, seed=seed)
+    keys = co.synthetic_keys(curve, r, seed=seed + 1)
+    rs = co.gen_field(fr, 2, seed=seed + 2)
+    pk = ctx.g16_pk_upload(keys.host_struct(), curve)
+    ctx.g16_pk_set_r1cs(pk, r)
+    try:
+        for mode in (2, 1):  # chained and folded assembly: the same proof
+            ctx.groth16_set_assembly(mode)
+            proof, inf = ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
+            if mode == 2:
+                want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)
+            assert np.array_equal(proof, want) and np.array_equal(inf, winf), (curve, nc, mode)
+    finally:
+        ctx.groth16_set_assembly(0)
+        pk.free()
+    return keys.domain_size
+
+
+def test_config1_pcd_step_298(co, gpu_ctx):
+    """configs[1]: 2^16-constraint predicate -> main proof on the 2^17 domain (MNT4-298), help proof on 2^16 (MNT6-298)."""
+    assert _prove_at_size(co, gpu_ctx, 0, (1 << 17) - 8, seed=1100) == 1 << 17
+    assert _prove_at_size(co, gpu_ctx, 1, (1 << 16) - 8, seed=1110) == 1 << 16
+
+
+def test_config2_pcd_step_753(co, gpu_ctx):
+    """configs[2]: main proof MNT4-753 on the 2^20 domain; help proof MNT6-753 whose scalar field has 2-adicity 15, so a
+    52 768-row circuit lands on the mixed-radix domain 5 * 2^14 (ark-poly GeneralEvaluationDomain)."""
+    assert _prove_at_size(co, gpu_ctx, 3, (1 << 15) + 20000, seed=1130) == 5 << 14
+    assert _prove_at_size(co, gpu_ctx, 2, (1 << 20) - 8, seed=1120) == 1 << 20
+
+
+def test_config3_kzg_commit_2p20(co, gpu_ctx):
+    """configs[3]: KZG10::commit over prefixes of ONE resident 6n-point powers vector, n = 2^20: a commitment of length n, one
+    of length 6n and one at an interior offset (shifted powers of a degree bound), each with its n-point hiding MSM."""
+    ctx = gpu_ctx
+    curve, fr, n = 0, co.CURVE_FR[0], 1 << 20
+    powers = co.gen_points(curve, 1, 6 * n, seed=41)
+    gamma = co.gen_points(curve, 1, n, seed=42)
+    polys = co.gen_scalars(fr, 6 * n, seed=43)
+    blind = co.gen_scalars(fr, n, seed=44)
+    P = ctx.bases_upload(curve, 1, powers)
+    G = ctx.bases_upload(curve, 1, gamma)
+    S = ctx.buf_upload(fr, polys)
+    B = ctx.buf_upload(fr, blind)
+    try:
+        wanth = co.msm(curve, 1, gamma, blind, nthreads=THREADS)
+        for off, length in ((0, n), (0, 6 * n), (5 * n - 3, n)):
+            c = ctx.msm(P, S, offset=off, n=length)
+            h = ctx.msm(G, B, offset=0, n=n)
+            got = co.to_affine(curve, 1, ctx.points_sum(curve, 1, np.stack([c, h])))
+            want = co.msm(curve, 1, powers[off:off + length], polys[:length], nthreads=THREADS)
+            want = co.to_affine(curve, 1, co.jac_add(curve, 1, want, wanth))
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (off, length)
+    finally:
+        P.free(); G.free(); S.free(); B.free()

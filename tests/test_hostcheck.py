@@ -18,7 +18,7 @@ HC = os.path.join(ROOT, "tests", "hostcheck")
 def hc():
     so = os.path.join(HC, "libhostcheck.so")
     srcs = [os.path.join(HC, "hostcheck.hip")] + [os.path.join(ROOT, "pcd_amd", "csrc", f) for f in
-                                                  ("fp.cuh", "ec.cuh", "pairing.cuh", "params_gen.h", "params28_gen.h")]
+                                                  ("fp.hip.h", "ec.hip.h", "pairing.hip.h", "params_gen.h", "params28_gen.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared", "-DPCD_LZ_CHECK",
                                os.path.join(HC, "hostcheck.hip"), "-o", so], stderr=subprocess.DEVNULL)
