@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- headline measurement of the PCD prover hot path on MI355X.
 
-Metric (BASELINE.json): MSM Mscalar-mul/s on MNT4-298 G1 at n = 2^20 (proving key resident), plus the
-PCD-step prover-arithmetic time (main Groth16 proof over MNT4-298 at n = 2^20 + help proof over MNT6-298
-at n = 2^16) reported in the same JSON line as `pcd_step`.
+Metric (BASELINE.json): MSM Mscalar-mul/s on MNT4-298 G1 at n = 2^20 (proving key resident), plus the PCD-step
+prover-arithmetic time, reported in the same JSON line:
+  pcd_step      main Groth16 proof over MNT4-298 (domain 2^20) + help proof over MNT6-298 (2^16)
+  pcd_step_753  BASELINE configs[2] / north_star target: main proof over MNT4-753 (domain 2^20) + help proof over MNT6-753
+                (mixed-radix domain 5 * 2^14), with the roofline of its dominant kernel (G1-753 bucket accumulation)
+Every prove is timed as the median of 5 and its proof bytes are compared with the CPU oracle before a number is printed.
 
-One "step" = one variable-base MSM of 2^20 (scalar, base) pairs per GPU with bases AND scalars already
-resident in HBM (pcdhip_msm_dev); the 120-byte Jacobian result returns to the host.  With N GPUs the MSM has
-N * 2^20 pairs sharded by point range (weak scaling); the only exchange is an all-gather of one Jacobian point
-per rank over RCCL followed by a local EC-add kernel.
+One "step" = one variable-base MSM with bases AND scalars already resident in HBM (pcdhip_msm_dev); the Jacobian result
+returns to the host.  With N GPUs (one process per GPU, RCCL) the pairs are sharded by point range and the only exchange is an
+all-gather of one Jacobian point per rank + a local EC-add kernel:
+  default   weak scaling: 2^20 pairs PER GPU (`scaling: weak`); the line also carries `strong` -- the same exchange with a
+            fixed TOTAL of 2^20 and of 2^22 pairs split over the N ranks
+  --strong  the fixed-total run (2^--log-n pairs, default 2^20) is the headline value (`scaling: strong`)
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--strong]
 """
 import argparse
 import json
@@ -29,9 +34,19 @@ CURVE, GROUP, LOG_N = 0, 1, 20        # MNT4-298 G1, n = 2^20
 SEED = 0x5043443031                   # "PCD01"
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MAD_PEAK = 3.42e13                    # v_mad_u64_u32 lane-ops/s measured on MI355X (profiles/r01_k0_int_rates.txt)
-MODMUL_PER_PAIR = 220                 # 298-bit, n = 2^20, upstream c = 15 / W = 20
-MADS_PER_MODMUL = 210                 # 2 L^2 + L for L = 10 32-bit limbs
-BYTES_PER_PAIR = 120                  # canonical scalar (40 B) + affine base (80 B)
+# SURVEY.md 8d contract work per pair at n = 2^20 (upstream window rule c = 15: W = 20 / 51 windows x 11 modmul, CIOS
+# modmul = 2 L^2 + L 32-bit mads with L = 10 / 24)
+CONTRACT = {0: (220, 210, 120), 2: (561, 1176, 288)}   # curve -> (modmul per pair, mads per modmul, bytes per pair)
+
+
+def madd_mads(curve):
+    """32-bit multiply-adds one mixed addition of the G1 accumulate kernel EXECUTES (28-bit limbs: product 2 N^2, square
+    N (N + 1) / 2 + N^2, fused two-term product 3 N^2; N = 11 / 27):
+      298-bit  lazily reduced madd (ec.hip.h madd_lz): 3 squares + 6 products + 1 fused two-term product
+      753-bit  madd-2007-bl: 4 squares + 7 products"""
+    n = 11 if curve < 2 else 27
+    mul, sqr, dot2 = 2 * n * n, n * (n + 1) // 2 + n * n, 3 * n * n
+    return 3 * sqr + 6 * mul + dot2 if curve < 2 else 4 * sqr + 7 * mul
 
 
 def main():
@@ -40,7 +55,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dist", type=int, default=0, help="scalar distribution: 0 uniform (headline), 1 witness-like")
-    ap.add_argument("--no-step", action="store_true", help="skip the PCD-step (Groth16 main+help) section")
+    ap.add_argument("--strong", action="store_true", help="headline = fixed TOTAL of 2^log-n pairs split over the ranks")
+    ap.add_argument("--log-n", type=int, default=LOG_N, help="with --strong: log2 of the total pair count (20 or 22)")
+    ap.add_argument("--no-step", action="store_true", help="skip the PCD-step sections (Groth16 main + help, 298- and 753-bit)")
+    ap.add_argument("--no-753", action="store_true", help="skip the 753-bit PCD step (about two minutes of input generation and CPU checking)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
@@ -78,11 +96,6 @@ def main():
     sc = co.gen_scalars(fr, n, seed=SEED + 1000 + rank, dist=args.dist)
 
     ctx = capi.Context(local_rank)
-    t0 = time.time()
-    bases = ctx.bases_upload(CURVE, GROUP, pts)       # includes the one-time window-shifted precomputation
-    upload_s = time.time() - t0
-    sbuf = ctx.buf_upload(fr, sc)
-    ctx.msm_profile(True)
 
     def barrier():
         if use_dist:
@@ -95,83 +108,141 @@ def main():
         from pcd_amd.dist import DeviceExchange
         exchange = DeviceExchange(ctx, CURVE, GROUP, device)   # partial -> RCCL all-gather -> EC sum, all on the device
 
-    def step():
-        return exchange.msm(bases, sbuf) if use_dist else ctx.msm(bases, sbuf)
+    def timed_msm(bases, sbuf, steps, warmup):
+        """(wall seconds of `steps` MSMs, max over ranks; last result).  Profiling events are OFF inside the timed region."""
+        ctx.msm_profile(False)
+        step = (lambda: exchange.msm(bases, sbuf)) if use_dist else (lambda: ctx.msm(bases, sbuf))
+        res = None
+        for _ in range(warmup):
+            res = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, res
 
-    for _ in range(args.warmup):
-        res = step()
-    barrier()
-    acc_ms, tot_ms = [], []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-        tm = ctx.msm_last_timings()
-        acc_ms.append(tm["accumulate"])
-        tot_ms.append(tm["total"])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def stage_times(bases, sbuf, reps=5):
+        """per-stage device time (HIP events on the stream the kernels run on), mean over `reps` MSMs -- outside the timed region"""
+        ctx.msm_profile(True)
+        acc = []
+        for _ in range(reps):
+            ctx.msm(bases, sbuf)
+            acc.append(ctx.msm_last_timings())
+        ctx.msm_profile(False)
+        return {k: float(np.mean([a[k] for a in acc])) for k in acc[0]}
+
+    def strong_run(log_total, steps, warmup):
+        """fixed TOTAL of 2^log_total pairs, rank r holding the point range [r n / N, (r + 1) n / N) of the key"""
+        per = (1 << log_total) // world
+        p = pts[:per] if per <= n else co.gen_points(CURVE, GROUP, per, seed=SEED + 77 + rank)
+        s = sc[:per] if per <= n else co.gen_scalars(fr, per, seed=SEED + 1077 + rank, dist=args.dist)
+        b = ctx.bases_upload(CURVE, GROUP, p)
+        sb = ctx.buf_upload(fr, s)
+        el, _ = timed_msm(b, sb, steps, warmup)
+        plan = ctx.bases_info(b)
+        b.free(); sb.free()
+        return {"total_pairs": 1 << log_total, "pairs_per_gpu": per, "ms_per_step": round(el / steps * 1e3, 4),
+                "value": round((per * world) * steps / el / 1e6, 3), "unit": "Mscalar-mul/s", "window_bits": plan[0], "windows": plan[1]}
+
+    headline_strong = args.strong
+    if headline_strong:
+        per = (1 << args.log_n) // world
+        if per > n:
+            pts = co.gen_points(CURVE, GROUP, per, seed=SEED + rank)
+            sc = co.gen_scalars(fr, per, seed=SEED + 1000 + rank, dist=args.dist)
+        pts, sc, n_local = pts[:per], sc[:per], per
+    else:
+        n_local = n
+    t0 = time.time()
+    bases = ctx.bases_upload(CURVE, GROUP, pts)       # includes the one-time window-shifted precomputation
+    upload_s = time.time() - t0
+    sbuf = ctx.buf_upload(fr, sc)
+    elapsed, res = timed_msm(bases, sbuf, args.steps, args.warmup)
+    stages = stage_times(bases, sbuf)
+    c_bits, W, copies = ctx.bases_info(bases)
 
     # ---- correctness of what was timed (outside the timed region): rank-local partial vs the CPU oracle
     cpu = None
     if rank == 0 and not args.no_cpu:
-        W = (298 + 14) // 15
-        threads = max(1, min(os.cpu_count() or 1, W))   # upstream parallelises over windows only
+        Wup = (298 + 14) // 15
+        threads = max(1, min(os.cpu_count() or 1, Wup))   # upstream parallelises over windows only
         t0 = time.perf_counter()
         want = co.msm(CURVE, GROUP, pts, sc, nthreads=threads)
         cpu_s = time.perf_counter() - t0
-        if world == 1:
-            ok = np.array_equal(co.to_affine(CURVE, GROUP, res)[0], co.to_affine(CURVE, GROUP, want)[0])
-        else:
-            ok = np.array_equal(co.to_affine(CURVE, GROUP, ctx.msm(bases, sbuf))[0], co.to_affine(CURVE, GROUP, want)[0])
-        if not ok:
+        got = res if world == 1 else ctx.msm(bases, sbuf)
+        if not np.array_equal(co.to_affine(CURVE, GROUP, got)[0], co.to_affine(CURVE, GROUP, want)[0]):
             raise SystemExit("GPU MSM result differs from the CPU oracle: refusing to report a number")
-        cpu = {"value": round(n / cpu_s / 1e6, 4), "unit": "Mscalar-mul/s", "cores": threads, "kind": "port",
-               "sample": f"one full MNT4-298 G1 MSM, n=2^{LOG_N}, same inputs, C++ restatement of ark-ec Pippenger "
+        cpu = {"value": round(n_local / cpu_s / 1e6, 4), "unit": "Mscalar-mul/s", "cores": threads, "kind": "port",
+               "sample": f"one full MNT4-298 G1 MSM, n={n_local}, same inputs, C++ restatement of ark-ec Pippenger "
                          f"(threads over windows, c=15), {cpu_s:.2f} s; host has {os.cpu_count()} cores"}
 
+    strong = None
+    if not headline_strong:
+        k = max(5, args.steps // 2)
+        strong = {f"2^{lt}": strong_run(lt, k, 2) for lt in (20, 22)}
+
     # ---- PCD step (prover arithmetic of main + help Groth16 proofs), N = 1 only
-    step_info = None
+    step_info = step_753 = None
     if rank == 0 and world == 1 and not args.no_step:
-        step_info = pcd_step(ctx, co)
+        bases.free(); sbuf.free()
+        step_info = pcd_step(ctx, co, (("main_mnt4_298", 0, (1 << 20) - 8), ("help_mnt6_298", 1, (1 << 16) - 8)), 32)
+        if not args.no_753:
+            step_753 = pcd_step(ctx, co, (("main_mnt4_753", 2, (1 << 20) - 8), ("help_mnt6_753", 3, (1 << 15) + 20000)), 64, roofline_curve=2)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * n * args.steps / elapsed / 1e6
-        acc = float(np.mean(acc_ms))
-        ach_gbs = n * BYTES_PER_PAIR / (acc * 1e-3) / 1e9
+        value = world * n_local * args.steps / elapsed / 1e6
+        acc = stages["accumulate"]
+        mm, mpm, bpp = CONTRACT[CURVE]
+        ach_gbs = n_local * bpp / (acc * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_msm_accumulate.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        mads = n * MODMUL_PER_PAIR * MADS_PER_MODMUL
+        executed = n_local * W * madd_mads(CURVE)
+        contract = n_local * mm * mpm
         out = {
             "metric": "msm_mscalar_mul_per_s", "value": round(value, 3), "unit": "Mscalar-mul/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (11 x 28-bit unsaturated Montgomery limbs, v_mad_u64_u32 with 64-bit column accumulators)",
+            "scaling": "strong" if headline_strong else "weak", "vs_baseline": None,
+            "dtype": "u32 (11 x 28-bit unsaturated Montgomery limbs, v_mad_u64_u32 with 64-bit column accumulators)",
             "data": "synthetic",
-            "config": {"workload": f"MNT4-298 G1 variable-base MSM, n=2^{LOG_N} pairs per GPU, proving-key bases and scalars "
-                                   f"resident in HBM, scalar distribution {'uniform' if args.dist == 0 else 'witness-like'}",
-                       "curve": "MNT4-298", "group": "G1", "log_n": LOG_N, "sharding": f"point-range x{world}",
-                       "precompute": "one window-shifted copy of the bases per scalar window (one-time, at key upload)",
-                       "upload_precompute_s": round(upload_s, 3)},
+            "config": {"workload": (f"MNT4-298 G1 variable-base MSM, n={n_local} pairs per GPU ({'fixed total 2^%d split over the ranks' % args.log_n if headline_strong else '2^20 per GPU'}), "
+                                    f"proving-key bases and scalars resident in HBM, scalar distribution {'uniform' if args.dist == 0 else 'witness-like'}"),
+                       "curve": "MNT4-298", "group": "G1", "log_n": args.log_n if headline_strong else LOG_N, "sharding": f"point-range x{world}",
+                       "precompute": f"{copies} window-shifted copies of the bases (one per scalar window; one-time, at key upload)",
+                       "window_bits": c_bits, "windows": W, "upload_precompute_s": round(upload_s, 3)},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "msm_accumulate_kernel", "kernel_ms": round(acc, 4),
                          "note": "algorithmic bytes = n x (40 B scalar + 80 B affine base); this kernel is integer-VALU-bound, "
                                  "not HBM-bound: see roofline_int"},
-            "roofline_int": {"bound": "valu_int32_mad", "achieved": round(mads / (acc * 1e-3) / 1e12, 3),
-                             "peak": round(MAD_PEAK / 1e12, 2), "unit": "T mad/s", "frac": round(mads / (acc * 1e-3) / MAD_PEAK, 4),
-                             "note": "algorithmic mads = n x 220 modmul/pair x 210 (32x32->64 mads per 298-bit CIOS modmul), "
-                                     "SURVEY.md 8d; peak = measured v_mad_u64_u32 issue rate (profiles/r01_k0_int_rates.txt)"},
-            "msm_stage_ms": {k: round(float(v), 4) for k, v in ctx.msm_last_timings().items()},
+            "roofline_int": {"bound": "valu_int32_mad", "achieved": round(executed / (acc * 1e-3) / 1e12, 3),
+                             "peak": round(MAD_PEAK / 1e12, 2), "unit": "T mad/s", "frac": round(executed / (acc * 1e-3) / MAD_PEAK, 4),
+                             "executed_mads_per_pair": W * madd_mads(CURVE),
+                             "note": f"EXECUTED multiply-adds of the plan that ran: n x W={W} mixed additions (signed digits, c={c_bits}) x "
+                                     f"{madd_mads(CURVE)} mads per lazily reduced madd; peak = measured v_mad_u64_u32 issue rate "
+                                     "(profiles/r01_k0_int_rates.txt).  This is the hardware fraction.",
+                             "upstream_work_rate": {"value": round(contract / (acc * 1e-3) / MAD_PEAK, 4),
+                                                    "note": "SURVEY.md 8d contract work (n x 220 modmul x 210 mads: upstream's c=15 / W=20, CIOS) per kernel "
+                                                            "second over the same peak -- a speed in units of the upstream algorithm's work, "
+                                                            "not a utilisation (signed digits and wider windows do less work per pair)"}},
+            "msm_stage_ms": {k: round(float(v), 4) for k, v in stages.items()},
+            "whole_step_int_frac": round(executed / (ms_per_step * 1e-3) / MAD_PEAK, 4),   # per GPU: executed mads of the accumulate stage over the WHOLE step's time
             "cpu_baseline": cpu,
         }
+        if strong:
+            out["strong"] = strong
         if step_info:
             out["pcd_step"] = step_info
+        if step_753:
+            out["pcd_step_753"] = step_753
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
@@ -180,72 +251,93 @@ def main():
         dist.destroy_process_group()
 
 
-def synthetic_keys(co, curve, r, seed):
-    """Proving key made of seeded on-curve points (a real trusted setup at 2^20 takes minutes on the CPU and
-    the prover arithmetic does not depend on the key being consistent)."""
-    m, ni, n = r.num_vars, r.num_inputs, 1 << r.domain_log
-    w1, w2 = co.point_words(curve, 1), co.point_words(curve, 2)
-    g1 = co.gen_points(curve, 1, 2 * m + (n - 1) + (m - ni) + 3, seed=seed)
-    g2 = co.gen_points(curve, 2, m + 2, seed=seed + 1)
-    z8 = lambda k: np.zeros(k, dtype=np.uint8)
-    o = 0
-    def take(k):
-        nonlocal o
-        v = np.ascontiguousarray(g1[o:o + k]); o += k
-        return v
-    A = dict(a_query=take(m), b_g1_query=take(m), h_query=take(n - 1), l_query=take(m - ni))
-    A.update(alpha_g1=take(1)[0], beta_g1=take(1)[0], delta_g1=take(1)[0])
-    A.update(b_g2_query=np.ascontiguousarray(g2[:m]), beta_g2=np.ascontiguousarray(g2[m]), delta_g2=np.ascontiguousarray(g2[m + 1]),
-             gamma_g2=np.ascontiguousarray(g2[m + 1]), gamma_abc_g1=np.ascontiguousarray(g1[:ni]), gamma_abc_inf=z8(ni),
-             a_inf=z8(m), b_g1_inf=z8(m), b_g2_inf=z8(m), h_inf=z8(n - 1), l_inf=z8(m - ni))
-    return co.Keys(curve, r, A)
-
-
-def pcd_step(ctx, co):
-    """Prover arithmetic of one PCD step: main proof (MNT4-298, domain 2^20) + help proof (MNT6-298, domain
-    2^16: its scalar field has 2-adicity 17); the assignment is uniformly random field elements -- the worst case for
-    the MSMs (a real witness is full of 0 / 1 values, which cost nothing / go to the pseudo bucket: `--dist 1`);
-    keys resident; bit-exact vs the oracle."""
-    from pcd_amd import capi
-    info = {"unit": "ms", "what": "witness map + the proof's MSMs (h, l, A, B1 on G1; B on G2) + assembly (s*A, r*B1 chained behind their MSMs or folded into two more MSMs, chosen by size), per proof; the MSMs over the assignment overlap the witness map; R1CS synthesis (Rust host) excluded"}
-    total_gpu, total_cpu = 0.0, 0.0
-    for name, curve, log_n in (("main_mnt4_298", 0, 20), ("help_mnt6_298", 1, 16)):
-        fr = co.CURVE_FR[curve]
-        nc = (1 << log_n) - 8
-        r = co.synthetic_r1cs(fr, nc, 2, seed=SEED + curve)
-        keys = synthetic_keys(co, curve, r, seed=SEED + 10 + curve)
-        rs = co.gen_field(fr, 2, seed=SEED + 20)
-        pk = ctx.g16_pk_upload(keys.host_struct(), curve)
-        ctx.g16_pk_set_r1cs(pk, r)                              # matrices are fixed per circuit: resident like the key
-        r.z = capi.pinned_like(r.z)                             # the assignment is handed over in page-locked host memory
-        ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)   # warm-up (FFT tables, workspaces)
+def median_prove(ctx, pk, r, rs, reps=5):
+    """(median wall ms of `reps` proves, proof, device timings of the median-adjacent last run)"""
+    walls = []
+    proof = None
+    for _ in range(reps):
         t0 = time.perf_counter()
         proof, inf = ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
-        wall = (time.perf_counter() - t0) * 1e3
-        tm = ctx.groth16_last_timings()
-        ctx.groth16_set_assembly(1)                             # the two explicit assembly forms, for the record (the default picks one)
-        ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
-        t0 = time.perf_counter()
-        proof_f, _ = ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
-        wall_folded = (time.perf_counter() - t0) * 1e3
-        ctx.groth16_set_assembly(2)
-        ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
-        t0 = time.perf_counter()
-        proof_c, _ = ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
-        wall_chained = (time.perf_counter() - t0) * 1e3
+        walls.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(walls)), proof, ctx.groth16_last_timings(), walls
+
+
+def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None):
+    """Prover arithmetic of one PCD step: main proof + help proof (the help scalar fields have 2-adicity 17 / 15: radix-2 up
+    to 2^16 rows at 298 bits, the mixed-radix domain 5 * 2^14 for the 753-bit help circuit); the assignment is uniformly random
+    field elements -- the worst case for the MSMs (a real witness is full of 0 / 1 values, which cost nothing / go to the pseudo
+    bucket: `--dist 1`); keys and matrices resident, z in page-locked host memory; every timing is the median of 5 proves;
+    proof bytes equal to the oracle's or no number is printed."""
+    from pcd_amd import capi
+    info = {"unit": "ms", "timing": "median of 5 proves per assembly form",
+            "what": "witness map + the proof's MSMs (h, l, A, B1 on G1; B on G2) + assembly (s*A, r*B1 chained behind their MSMs or folded "
+                    "into two more MSMs, chosen by size), per proof; the MSMs over the assignment overlap the witness map; R1CS synthesis "
+                    "(Rust host) excluded"}
+    total_gpu, total_cpu = 0.0, 0.0
+    for name, curve, nc in proofs:
+        fr = co.CURVE_FR[curve]
+        t0 = time.time()
+        r = co.synthetic_r1cs(fr, nc, 2, seed=SEED + curve)
+        keys = co.synthetic_keys(curve, r, seed=SEED + 10 + curve)
+        rs = co.gen_field(fr, 2, seed=SEED + 20)
+        gen_s = time.time() - t0
+        t0 = time.time()
+        pk = ctx.g16_pk_upload(keys.host_struct(), curve)
+        ctx.g16_pk_set_r1cs(pk, r)                              # matrices are fixed per circuit: resident like the key
+        up_s = time.time() - t0
+        r.z = capi.pinned_like(r.z)                             # the assignment is handed over in page-locked host memory
+        ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)   # warm-up (FFT tables, workspaces)
+        wall, proof, tm, walls = median_prove(ctx, pk, r, rs)
+        forms = {}
+        for mode, label in ((1, "folded"), (2, "chained")):    # the two explicit assembly forms, for the record (the default picks one)
+            ctx.groth16_set_assembly(mode)
+            ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
+            forms[label] = median_prove(ctx, pk, r, rs)
         ctx.groth16_set_assembly(0)
-        threads = min(os.cpu_count() or 1, 32)
+        threads = min(os.cpu_count() or 1, max_threads)
         t0 = time.perf_counter()
         want, _ = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=threads)
         cpu_ms = (time.perf_counter() - t0) * 1e3
-        if not np.array_equal(proof, want) or not np.array_equal(proof_f, want) or not np.array_equal(proof_c, want):
+        if not all(np.array_equal(p, want) for p in (proof, forms["folded"][1], forms["chained"][1])):
             raise SystemExit(f"GPU Groth16 proof ({name}) differs from the CPU oracle")
-        info[name] = {"gpu_wall_ms": round(wall, 2), "gpu_wall_ms_folded_assembly": round(wall_folded, 2),
-                      "gpu_wall_ms_chained_assembly": round(wall_chained, 2), "gpu_device_ms": {k: round(float(v), 3) for k, v in tm.items()},
-                      "cpu_port_ms": round(cpu_ms, 1), "cpu_threads": threads, "log_n": log_n}
+        info[name] = {"gpu_wall_ms": round(wall, 2), "gpu_wall_ms_min_max": [round(min(walls), 2), round(max(walls), 2)],
+                      "gpu_wall_ms_folded_assembly": round(forms["folded"][0], 2),
+                      "gpu_wall_ms_chained_assembly": round(forms["chained"][0], 2),
+                      "gpu_device_ms": {k: round(float(v), 3) for k, v in tm.items()},
+                      "cpu_port_ms": round(cpu_ms, 1), "cpu_threads": threads, "domain": int(keys.domain_size),
+                      "key_upload_precompute_s": round(up_s, 2), "input_gen_s": round(gen_s, 2)}
         total_gpu += wall
         total_cpu += cpu_ms
-        pk.free()
+        if roofline_curve == curve:
+            # the dominant kernel of the step: G1 bucket accumulation of the main proof (four of its five MSMs); measured on one
+            # standalone MSM over the key's own h query with the stage events on
+            pk.free()
+            pk = None
+            n = 1 << 20
+            hq = np.ascontiguousarray(keys.h_query[:n - 1])
+            b = ctx.bases_upload(curve, 1, hq)
+            sb = ctx.buf_upload(fr, co.gen_scalars(fr, n - 1, seed=SEED + 30))
+            ctx.msm_profile(True)
+            accs, tots = [], []
+            for _ in range(4):
+                ctx.msm(b, sb)
+                t = ctx.msm_last_timings()
+                accs.append(t["accumulate"]); tots.append(t["total"])
+            ctx.msm_profile(False)
+            c_bits, W, copies = ctx.bases_info(b)
+            b.free(); sb.free()
+            acc = float(np.median(accs[1:]))
+            executed = (n - 1) * W * madd_mads(curve)
+            mm, mpm, bpp = CONTRACT[curve]
+            info["roofline_int"] = {"kernel": "msm_accumulate_kernel (G1, MNT4-753)", "kernel_ms": round(acc, 3), "msm_total_ms": round(float(np.median(tots[1:])), 3),
+                                    "bound": "valu_int32_mad", "achieved": round(executed / (acc * 1e-3) / 1e12, 3), "peak": round(MAD_PEAK / 1e12, 2),
+                                    "unit": "T mad/s", "frac": round(executed / (acc * 1e-3) / MAD_PEAK, 4), "window_bits": c_bits, "windows": W,
+                                    "executed_mads_per_pair": W * madd_mads(curve),
+                                    "upstream_work_rate": round((n - 1) * mm * mpm / (acc * 1e-3) / MAD_PEAK, 4),
+                                    "hbm_algorithmic_GBs": round((n - 1) * bpp / (acc * 1e-3) / 1e9, 2)}
+        if pk is not None:
+            pk.free()
+        del keys, r
     info["pcd_step_prover_ms"] = round(total_gpu, 2)
     info["cpu_port_ms"] = round(total_cpu, 1)
     info["speedup_vs_cpu_port"] = round(total_cpu / total_gpu, 2)

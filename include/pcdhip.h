@@ -94,6 +94,15 @@ int pcdhip_msm_dev(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, co
  *    0           none (W bucket windows + Horner combine, as upstream);   k >= 2  k copies.
  * Falls back to fewer copies when device memory does not suffice. */
 int pcdhip_set_precompute(pcdhip_ctx* ctx, int mode);
+/* The plan an MSM of n pairs over these bases runs with (n = 0: the whole vector): signed-digit window bits c, scalar
+ * windows W = ceil((bits + 1) / c), and how many window-shifted copies of the vector are resident (1 = none).  bench.py
+ * prices the accumulate kernel's executed multiply-adds from it. */
+int pcdhip_bases_info(const pcdhip_bases* bases, size_t n, int* window_bits, int* windows, int* copies);
+/* Order the context's stream against a caller-owned HIP stream without a host wait (the RCCL stream of the exchange step,
+ * SURVEY.md 8e): direction 0 -- work queued on the context's stream from now on waits for everything already queued on
+ * `other_stream`; direction 1 -- `other_stream` waits for the context's stream.  `other_stream` is a hipStream_t (NULL =
+ * the legacy default stream) of the same device and HIP runtime. */
+int pcdhip_stream_wait(pcdhip_ctx* ctx, void* other_stream, int direction);
 /* Tuning / introspection: window bits (0 = automatic), sorted entries per lane (0 = default). */
 int pcdhip_msm_config(pcdhip_ctx* ctx, int window_bits, int chunk);
 /* Sorting strategy of the (bucket, base) entries: 0 (default) MSD partition through LDS (per-workgroup bin

@@ -44,7 +44,7 @@ EXPORTS = [
     "pcdhip_strerror", "pcdhip_device_count", "pcdhip_init", "pcdhip_destroy", "pcdhip_sync", "pcdhip_host_alloc", "pcdhip_host_free", "pcdhip_last_hip_error",
     "pcdhip_field_limbs", "pcdhip_curve_base_field", "pcdhip_curve_scalar_field", "pcdhip_point_limbs",
     "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
-    "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config",
+    "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config", "pcdhip_bases_info", "pcdhip_stream_wait",
     "pcdhip_set_precompute", "pcdhip_msm_set_sort", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
     "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
@@ -154,6 +154,16 @@ class Context:
         out = np.zeros(3 * point_limbs(curve, group) // 2, dtype=np.uint64)
         self._check(lib().pcdhip_points_sum_dev(self._ctx, curve, group, C.c_void_p(xyz_device_ptr), C.c_size_t(n), _p(out)))
         return out
+
+    def bases_info(self, bases, n=0):
+        """(window bits c, scalar windows W, resident window-shifted copies) of an MSM of n pairs over `bases`."""
+        c, w, k = C.c_int(), C.c_int(), C.c_int()
+        self._check(lib().pcdhip_bases_info(bases._h, C.c_size_t(n), C.byref(c), C.byref(w), C.byref(k)))
+        return c.value, w.value, k.value
+
+    def stream_wait(self, other_stream, direction):
+        """direction 0: this context's stream waits for `other_stream` (a raw hipStream_t); 1: the other way round."""
+        self._check(lib().pcdhip_stream_wait(self._ctx, C.c_void_p(other_stream), int(direction)))
 
     def msm_config(self, window_bits=0, chunk=0):
         self._check(lib().pcdhip_msm_config(self._ctx, window_bits, chunk))

@@ -243,6 +243,7 @@ void pcdhip_destroy(pcdhip_ctx* ctx) {
     (void)hipFree(kv.second.tw_fwd); (void)hipFree(kv.second.tw_inv);
     (void)hipFree(kv.second.coset); (void)hipFree(kv.second.coset_inv_scaled);
   }
+  if (ctx->xstream_ev) (void)hipEventDestroy(ctx->xstream_ev);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   (void)hipStreamDestroy(ctx->stream);
@@ -373,6 +374,24 @@ void pcdhip_bases_free(pcdhip_ctx* ctx, pcdhip_bases* bases) {
   if (ctx) (void)hipSetDevice(ctx->device);
   (void)hipFree(bases->dptr);
   delete bases;
+}
+int pcdhip_bases_info(const pcdhip_bases* bases, size_t n, int* window_bits, int* windows, int* copies) {
+  if (!bases || !window_bits || !windows || !copies) return PCDHIP_E_ARG;
+  const GroupEntry& ge = group_entry(bases->curve_id, bases->group_id);
+  const int c = bases->groups > 1 ? bases->c : msm_pick_window(n ? n : bases->n, ge.scalar_bits, 0);
+  *window_bits = c;
+  *windows = msm_num_windows(ge.scalar_bits, c);
+  *copies = bases->groups;
+  return PCDHIP_OK;
+}
+int pcdhip_stream_wait(pcdhip_ctx* ctx, void* other_stream, int direction) {
+  if (!ctx || direction < 0 || direction > 1) return PCDHIP_E_ARG;
+  BIND();
+  if (!ctx->xstream_ev) TRY(hipEventCreateWithFlags(&ctx->xstream_ev, hipEventDisableTiming));
+  hipStream_t other = (hipStream_t)other_stream;
+  TRY(hipEventRecord(ctx->xstream_ev, direction == 0 ? other : ctx->stream));
+  TRY(hipStreamWaitEvent(direction == 0 ? ctx->stream : other, ctx->xstream_ev, 0));
+  return PCDHIP_OK;
 }
 int pcdhip_msm_config(pcdhip_ctx* ctx, int window_bits, int chunk) {
   if (!ctx || window_bits < 0 || window_bits > 24 || chunk < 0) return PCDHIP_E_ARG;

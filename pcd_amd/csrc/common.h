@@ -73,6 +73,7 @@ struct pcdhip_ctx {
   float g16_ms[8] = {0};
   int g16_assembly = 0;  // s*A and r*B_1: 0 automatic, 1 folded into two extra MSMs, 2 chained one-lane products
   hipEvent_t t0 = nullptr, t1 = nullptr;
+  hipEvent_t xstream_ev = nullptr;  // pcdhip_stream_wait: ordering against a caller-owned stream (e.g. the RCCL stream)
   std::string last_hip_error;
 };
 

@@ -68,18 +68,36 @@ struct G2Cfg3 {  // twist over Fq3: a' = (0, 0, a) = a u^2;  x u^2 = (nr c1, nr 
 };
 
 // lane-split form of the Fq2 twist (fp.hip.h Fp2S): used by the bucket accumulation of the 753-bit G2
-template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE, bool INL = false>
 struct G2Cfg2S {
-  typedef Fp2S<Fp<FQ, false>, NR> F;
+  typedef Fp2S<Fp<FQ, INL>, NR> F;
   typedef FRP FR;
   static constexpr int CURVE_ID = CURVE;
   static constexpr int GROUP = 2;
   PCD_DEV static F mul_by_a(const F& x) { return x.mul_small(A * NR); }
 };
-// SplitOf<G>: the group configuration a throughput kernel should compute in, and how many lanes share one point (2^SHIFT)
-template <class G> struct SplitOf { typedef G type; static constexpr int SHIFT = 0; };
+// lane-split form of the Fq3 twist (fp.hip.h Fp3S): bucket accumulation of the MNT6 G2 groups, three lanes per point
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE, bool INL = (FQ::N <= 11)>
+struct G2Cfg3S {
+  typedef Fp3S<Fp<FQ, INL>, NR> F;
+  typedef FRP FR;
+  static constexpr int CURVE_ID = CURVE;
+  static constexpr int GROUP = 2;
+  PCD_DEV static F mul_by_a(const F& x) { return x.mul_by_au2(A); }
+};
+// SplitOf<G>: the group configuration a throughput kernel should compute in, and how many adjacent lanes share one point
+#ifndef PCD_SPLIT_FQ2_298
+#define PCD_SPLIT_FQ2_298 0  // the 298-bit Fq2 twist unsplit (inlined arithmetic, one wave per SIMD) or split over lane pairs
+#endif
+template <class G> struct SplitOf { typedef G type; static constexpr int LANES = 1; };
 template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
-struct SplitOf<G2Cfg2<FQ, FRP, A, NR, CURVE, false>> { typedef G2Cfg2S<FQ, FRP, A, NR, CURVE> type; static constexpr int SHIFT = 1; };
+struct SplitOf<G2Cfg2<FQ, FRP, A, NR, CURVE, false>> { typedef G2Cfg2S<FQ, FRP, A, NR, CURVE, false> type; static constexpr int LANES = 2; };
+#if PCD_SPLIT_FQ2_298
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+struct SplitOf<G2Cfg2<FQ, FRP, A, NR, CURVE, true>> { typedef G2Cfg2S<FQ, FRP, A, NR, CURVE, true> type; static constexpr int LANES = 2; };
+#endif
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE, bool INL>
+struct SplitOf<G2Cfg3<FQ, FRP, A, NR, CURVE, INL>> { typedef G2Cfg3S<FQ, FRP, A, NR, CURVE, INL> type; static constexpr int LANES = 3; };
 
 typedef G1Cfg<F298A, F298B, PCD_MNT4_298_A_SMALL, 0> G1_MNT4_298;
 typedef G1Cfg<F298B, F298A, PCD_MNT6_298_A_SMALL, 1> G1_MNT6_298;

@@ -381,6 +381,10 @@ struct Fp {
     if (k == 2) return dbl();
     if (k == 3) return dbl() + *this;
     if (k == 4) return dbl().dbl();
+    return mul_small_var(k);
+  }
+  // the same without the shortcuts for tiny k: branch-free, so k may differ from lane to lane (lane-split extension fields)
+  PCD_HD Fp mul_small_var(unsigned k) const {
     uint32_t t[N];
     uint64_t c = 0;
 #pragma unroll
@@ -640,6 +644,80 @@ struct Fp3 {
   PCD_HD void store(uint32_t* p) const { c0.store(p); c1.store(p + F::WORDS); c2.store(p + 2 * F::WORDS); }
   PCD_HD static Fp3 from_abi(const uint32_t* w) { return {F::from_abi(w), F::from_abi(w + F::ABI_WORDS), F::from_abi(w + 2 * F::ABI_WORDS)}; }
   PCD_HD void to_abi(uint32_t* w) const { c0.to_abi(w); c1.to_abi(w + F::ABI_WORDS); c2.to_abi(w + 2 * F::ABI_WORDS); }
+};
+
+// The cubic extension with its three coefficients SPLIT OVER A TRIPLE OF ADJACENT LANES (lane index mod 3 = coefficient index;
+// a 64-lane wave holds 21 triples, lane 63 idles): every lane keeps ONE base-field element per Fq3 value, so a Jacobian
+// accumulator costs 3 N registers per lane instead of 9 N.  The unsplit form does not fit the register file (298-bit: 99 of the
+// accumulator alone plus a 66-register point; its products were function calls through scratch, ~20 % of the mad roofline).
+// Additions are coefficient-wise; a product fetches the partners' coefficients (4 N ds_bpermute) and each lane computes ONE output
+// coefficient with one fused three-term product:
+//   lane 0:  a0 b0 + (nr a1) b2 + (nr a2) b1      lane 1:  a1 b0 + a0 b1 + (nr a2) b2      lane 2:  a2 b0 + a1 b1 + a0 b2
+// Memory image unchanged (c0 || c1 || c2): load / store address the lane's own third.  Device only; the three lanes of a triple
+// must follow the same control flow (they work on the same point).
+template <class F, unsigned NR>
+struct Fp3S {
+  typedef typename F::Params Params;
+  typedef F Base;
+  static constexpr int DEG = 3;
+  static constexpr int WORDS = 3 * F::WORDS;
+  static constexpr int ABI_WORDS = 3 * F::ABI_WORDS;
+  static constexpr int LANES = 3;
+  F c;
+  PCD_DEV static unsigned role() { return (threadIdx.x & 63u) % 3u; }
+  PCD_DEV static int lane_next() { const unsigned l = threadIdx.x & 63u; return (int)l + (l % 3u == 2u ? -2 : 1); }   // holder of coefficient (role + 1) mod 3
+  PCD_DEV static int lane_next2() { const unsigned l = threadIdx.x & 63u; return (int)l + (l % 3u == 0u ? 2 : -1); }  // ... (role + 2) mod 3
+  PCD_DEV static F from_lane(const F& a, int lane) { F r;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) r.v[i] = (uint32_t)__shfl((int)a.v[i], lane, 64);
+    return r; }
+  PCD_DEV static F sel(bool t, const F& a, const F& b) { F r;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) r.v[i] = t ? a.v[i] : b.v[i];
+    return r; }
+  PCD_DEV static bool all3(bool b) {  // (no short circuit: all three lanes shuffle)
+    const int o1 = __shfl((int)b, lane_next(), 64), o2 = __shfl((int)b, lane_next2(), 64);
+    return b & (o1 != 0) & (o2 != 0);
+  }
+  PCD_DEV static Fp3S zero() { return {F::zero()}; }
+  PCD_DEV static Fp3S one() { F o = F::one(), z = F::zero(); return {sel(role() == 0, o, z)}; }
+  PCD_DEV bool is_raw_zero() const { return all3(c.is_raw_zero()); }
+  PCD_DEV bool is_zero() const { return all3(c.is_zero()); }
+  PCD_DEV bool operator==(const Fp3S& b) const { return (*this - b).is_zero(); }
+  PCD_DEV bool operator!=(const Fp3S& b) const { return !(*this == b); }
+  PCD_DEV Fp3S operator+(const Fp3S& b) const { return {c + b.c}; }
+  PCD_DEV Fp3S operator-(const Fp3S& b) const { return {c - b.c}; }
+  PCD_DEV Fp3S neg() const { return {c.neg()}; }
+  PCD_DEV Fp3S dbl() const { return {c.dbl()}; }
+  PCD_DEV Fp3S mul_small(unsigned k) const { return {c.mul_small(k)}; }
+  // With own = a_k, an = a_(k+1), an2 = a_(k+2) (indices mod 3) and the same for b, output coefficient k is
+  //   own * y1 + x2 * y2 + x3 * y3   with   (y1, y2, y3) = (b_k, b_(k+2), b_(k+1)) rotated by the role,
+  //   x2 = an (times nr on lanes 0, 1),  x3 = an2 (times nr on lane 0)
+  PCD_DEV Fp3S operator*(const Fp3S& b) const {
+    const int ln = lane_next(), ln2 = lane_next2();
+    const unsigned k = role();
+    const F an = from_lane(c, ln), an2 = from_lane(c, ln2), bn = from_lane(b.c, ln), bn2 = from_lane(b.c, ln2);
+    const F x2 = sel(k < 2, an.mul_small(NR), an), x3 = sel(k == 0, an2.mul_small(NR), an2);
+    const F y1 = sel(k == 0, b.c, sel(k == 1, bn2, bn));
+    const F y2 = sel(k == 0, bn2, sel(k == 1, bn, b.c));
+    const F y3 = sel(k == 0, bn, sel(k == 1, b.c, bn2));
+    return {F::dot3(c, y1, x2, y2, x3, y3)};
+  }
+  //   lane 0:  a0 a0 + (2 nr a1) a2      lane 1:  (2 a0) a1 + (nr a2) a2      lane 2:  a1 a1 + (2 a0) a2
+  PCD_DEV Fp3S sqr() const {
+    const int ln = lane_next(), ln2 = lane_next2();
+    const unsigned k = role();
+    const F an = from_lane(c, ln), an2 = from_lane(c, ln2);
+    const F x1 = sel(k == 0, c, sel(k == 1, an2.dbl(), an2));
+    const F y1 = sel(k == 2, an2, c);
+    const F x2 = an.mul_small_var(k == 0 ? 2 * NR : (k == 1 ? NR : 2));
+    const F y2 = sel(k == 0, an2, sel(k == 1, an, c));
+    return {F::dot2(x1, y1, x2, y2)};
+  }
+  // x * (a u^2) for the twist coefficient (0, 0, a):  (nr a c1, nr a c2, a c0) -- every lane takes its successor's coefficient
+  PCD_DEV Fp3S mul_by_au2(unsigned a) const { return {from_lane(c, lane_next()).mul_small_var(role() < 2 ? a * NR : a)}; }
+  PCD_DEV static Fp3S load(const uint32_t* p) { return {F::load(p + role() * F::WORDS)}; }
+  PCD_DEV void store(uint32_t* p) const { c.store(p + role() * F::WORDS); }
 };
 
 }  // namespace pcd

@@ -443,7 +443,10 @@ struct MsmRunLazy {
 template <class G>
 struct MsmAccWaves {
   typedef typename SplitOf<G>::type::F FA;
-  static constexpr int value = (FA::Base::INLINE_ARITH && FA::DEG == 1) ? 2 : 1;
+#ifndef PCD_ACC_WAVES_SPLIT
+#define PCD_ACC_WAVES_SPLIT 2
+#endif
+  static constexpr int value = !FA::Base::INLINE_ARITH ? 1 : FA::DEG == 1 ? 2 : SplitOf<G>::LANES > 1 ? PCD_ACC_WAVES_SPLIT : 1;
 };
 template <class G>
 __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kernel(const uint32_t* __restrict__ bases, const MsmEntrySource src,
@@ -455,7 +458,9 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
   typedef typename SplitOf<G>::type GA;
   typedef typename GA::F F;
   typedef EC<GA> E;
-  uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> SplitOf<G>::SHIFT;
+  constexpr uint32_t LANES = SplitOf<G>::LANES, PER_WAVE = 64 / LANES;  // chunks per 64-lane workgroup (three lanes per point: 21, lane 63 idles)
+  if (threadIdx.x >= PER_WAVE * LANES) return;
+  uint32_t t = blockIdx.x * PER_WAVE + threadIdx.x / LANES;
   const uint32_t M = off[nkeys];  // total sorted entries: read on the device, the host never waits for it
   uint64_t start64 = (uint64_t)t * chunk;
   if (start64 >= M) return;
@@ -952,8 +957,8 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   PCD_HIP_TRY(hipMemsetAsync(big_count, 0, 8, st));
   PCD_HIP_TRY(mark(8));  // the accumulate stage time is the kernel alone (mark 8 -> mark 4)
   {
-    const uint64_t acc_lanes = (uint64_t)nchunks << SplitOf<G>::SHIFT;
-    hipLaunchKernelGGL((msm_accumulate_kernel<G>), dim3((uint32_t)((acc_lanes + 63) / 64)), dim3(64), 0, st, bases_dev, src, off, tkeys,
+    constexpr uint32_t per_wave = 64 / SplitOf<G>::LANES;  // chunks per workgroup
+    hipLaunchKernelGGL((msm_accumulate_kernel<G>), dim3((nchunks + per_wave - 1) / per_wave), dim3(64), 0, st, bases_dev, src, off, tkeys,
                        pl.chunk, buckets, pfirst, plast);
   }
   PCD_HIP_TRY(mark(4));

@@ -52,8 +52,9 @@ class DeviceExchange:
     def msm(self, bases, scalars_buf):
         import torch
         import torch.distributed as dist
+        ts = torch.cuda.current_stream().cuda_stream      # raw hipStream_t the collective is enqueued on
         self.ctx.msm_partial_to_device(bases, scalars_buf, self.send.data_ptr())
-        self.ctx.sync()                                   # the library's stream -> torch's
+        self.ctx.stream_wait(ts, 1)                       # torch's stream waits for the partial (event, no host wait)
         dist.all_gather_into_tensor(self.recv, self.send)
-        torch.cuda.current_stream().synchronize()         # torch's stream -> the library's
+        self.ctx.stream_wait(ts, 0)                       # the library's stream waits for the gathered points
         return self.ctx.points_sum_device(self.curve, self.group, self.recv.data_ptr(), self.world)
