@@ -7,7 +7,8 @@ _ROOT = os.path.dirname(_HERE)
 
 
 def library_path():
-    return os.path.join(_HERE, "libpcdhip.so")
+    # PCDHIP_LIB: developer knob for A/B runs of experimental builds (tools/); the default is the in-tree library
+    return os.environ.get("PCDHIP_LIB") or os.path.join(_HERE, "libpcdhip.so")
 
 
 def build_library(jobs=None, verbose=False):

@@ -225,8 +225,41 @@ int pcdhip_init(int device_id, pcdhip_ctx** out) {
   return PCDHIP_OK;
 }
 
+int pcdhip_init_devices(const int* device_ids, int n_dev, pcdhip_ctx** out) {
+  if (!device_ids || n_dev < 1 || n_dev > 64 || !out) return PCDHIP_E_ARG;
+  int rc = pcdhip_init(device_ids[0], out);
+  if (rc || n_dev == 1) return rc;
+  pcdhip_ctx* ctx = *out;
+  *out = nullptr;
+  rc = guarded([&]() -> int {
+    ctx->peers.push_back(ctx);
+    for (int i = 1; i < n_dev; i++) {
+      pcdhip_ctx* p = nullptr;
+      int r = pcdhip_init(device_ids[i], &p);
+      if (r) return r;
+      ctx->peers.push_back(p);
+    }
+    // direct xGMI copies between the devices of the context where the platform allows them (the partial results and the
+    // slices of h travel device to device; without peer access the runtime stages them through the host)
+    for (pcdhip_ctx* a : ctx->peers)
+      for (pcdhip_ctx* b : ctx->peers) {
+        if (a->device == b->device) continue;
+        int can = 0;
+        if (hipSetDevice(a->device) != hipSuccess || hipDeviceCanAccessPeer(&can, a->device, b->device) != hipSuccess || !can) continue;
+        if (hipDeviceEnablePeerAccess(b->device, 0) != hipSuccess) (void)hipGetLastError();  // (already enabled: fine)
+      }
+    return PCDHIP_OK;
+  });
+  if (rc) { pcdhip_destroy(ctx); return rc; }
+  *out = ctx;
+  return PCDHIP_OK;
+}
+int pcdhip_ctx_devices(const pcdhip_ctx* ctx) { return !ctx ? PCDHIP_E_ARG : ctx->peers.empty() ? 1 : (int)ctx->peers.size(); }
+
 void pcdhip_destroy(pcdhip_ctx* ctx) {
   if (!ctx) return;
+  for (size_t g = 1; g < ctx->peers.size(); g++) pcdhip_destroy(ctx->peers[g]);
+  ctx->peers.clear();
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->msm_ws.release();
@@ -321,12 +354,44 @@ void pcdhip_buf_free(pcdhip_ctx* ctx, pcdhip_buf* buf) {
 }
 
 // ------------------------------------------------------------------------------------------------ MSM
+// contiguous range [lo, hi) of part g out of `parts` (sizes differ by at most one) -- the point-range sharding of SURVEY.md 8e
+static void shard_range(size_t n, size_t g, size_t parts, size_t* lo, size_t* hi) {
+  const size_t base = n / parts, rem = n % parts;
+  *lo = g * base + std::min(g, rem);
+  *hi = *lo + base + (g < rem ? 1 : 0);
+}
+static int bases_upload_single(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xy, const uint8_t* inf, size_t n, pcdhip_bases** out);
+
 int pcdhip_bases_upload(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xy, const uint8_t* inf, size_t n,
                         pcdhip_bases** out) {
   if (!ctx || !out || !valid_curve(curve_id) || !valid_group(group_id) || (!xy && n) || n >= (1ull << 31)) return PCDHIP_E_ARG;
+  if (ctx->peers.size() <= 1) return bases_upload_single(ctx, curve_id, group_id, xy, inf, n, out);
+  // multi-device context: one ordinary handle per device, each over its point range
+  *out = nullptr;
+  return guarded([&]() -> int {
+    pcdhip_bases* b = new pcdhip_bases();
+    b->curve_id = curve_id; b->group_id = group_id; b->n = n; b->dptr = nullptr; b->c = 0; b->groups = 1;
+    const size_t G = ctx->peers.size(), pl = (size_t)pcdhip_point_limbs(curve_id, group_id);
+    b->shard_lo.resize(G + 1);
+    for (size_t g = 0; g < G; g++) {
+      size_t lo, hi;
+      shard_range(n, g, G, &lo, &hi);
+      b->shard_lo[g] = lo; b->shard_lo[g + 1] = hi;
+      pcdhip_ctx* C = ctx->peers[g];
+      C->precompute = ctx->precompute; C->msm_c = ctx->msm_c;
+      pcdhip_bases* sh = nullptr;
+      int rc = bases_upload_single(C, curve_id, group_id, xy + lo * pl, inf ? inf + lo : nullptr, hi - lo, &sh);
+      if (rc) { pcdhip_bases_free(ctx, b); return rc; }
+      b->shards.push_back(sh);
+    }
+    *out = b;
+    return PCDHIP_OK;
+  });
+}
+static int bases_upload_single(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xy, const uint8_t* inf, size_t n, pcdhip_bases** out) {
   BIND();
   const GroupEntry& ge = group_entry(curve_id, group_id);
-  const size_t abi_b = (size_t)ge.point_abi_words * 4, int_b = (size_t)ge.point_words * 4;
+  const size_t abi_b = (size_t)ge.point_abi_words * 4, int_b = (size_t)ge.base_stride_words * 4;
   pcdhip_bases* b = new (std::nothrow) pcdhip_bases();
   if (!b) return PCDHIP_E_OOM;
   b->curve_id = curve_id; b->group_id = group_id; b->n = n; b->dptr = nullptr; b->c = 0; b->groups = 1;
@@ -371,12 +436,16 @@ int pcdhip_set_precompute(pcdhip_ctx* ctx, int mode) {
 }
 void pcdhip_bases_free(pcdhip_ctx* ctx, pcdhip_bases* bases) {
   if (!bases) return;
+  for (size_t g = 0; g < bases->shards.size(); g++)
+    pcdhip_bases_free(ctx && g < ctx->peers.size() ? ctx->peers[g] : ctx, bases->shards[g]);
+  bases->shards.clear();
   if (ctx) (void)hipSetDevice(ctx->device);
   (void)hipFree(bases->dptr);
   delete bases;
 }
 int pcdhip_bases_info(const pcdhip_bases* bases, size_t n, int* window_bits, int* windows, int* copies) {
   if (!bases || !window_bits || !windows || !copies) return PCDHIP_E_ARG;
+  if (!bases->shards.empty()) return pcdhip_bases_info(bases->shards[0], 0, window_bits, windows, copies);  // (the plan of device 0's shard)
   const GroupEntry& ge = group_entry(bases->curve_id, bases->group_id);
   const int c = bases->groups > 1 ? bases->c : msm_pick_window(n ? n : bases->n, ge.scalar_bits, 0);
   *window_bits = c;
@@ -440,9 +509,70 @@ static int msm_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset,
   return too_wide ? PCDHIP_E_ARG : PCDHIP_OK;
 }
 
+// MSM over bases sharded across the devices of the context: every device runs the whole pipeline on the part of [offset, offset + n)
+// that falls into its point range (scalars: the matching slice of the host vector), the partial results travel device to device
+// into device 0's gather buffer and one wave sums them there.  No host synchronisation before the result is read back.
+static int msm_sharded(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const uint64_t* scalars, size_t n, uint64_t* out_xyz) {
+  const size_t G = bases->shards.size();
+  if (ctx->peers.size() != G) return PCDHIP_E_ARG;
+  const GroupEntry& ge = group_entry(bases->curve_id, bases->group_id);
+  const size_t jb = (size_t)ge.point_abi_words / 2 * 3 * 4, ji = (size_t)ge.point_words / 2 * 3 * 4;
+  const size_t sl = (size_t)kFieldLimbs[kCurveFr[bases->curve_id]];
+  BIND();
+  TRY(ctx->aux_ws.ensure(AUX_MISC, (G + 1) * jb + 64 * ji + 64));
+  uint32_t* d = (uint32_t*)ctx->aux_ws.buf[AUX_MISC];  // result | gathered partials | tree scratch
+  uint32_t* gather = d + jb / 4;
+  uint32_t* scratch = d + (G + 1) * jb / 4;
+  uint32_t too_wide[64] = {0};
+  for (size_t g = 0; g < G; g++) {
+    const size_t lo = std::max(offset, bases->shard_lo[g]), hi = std::min(offset + n, bases->shard_lo[g + 1]);
+    pcdhip_ctx* C = ctx->peers[g];
+    if (hi <= lo) {  // nothing of this MSM on device g: its partial is the identity (Z = 0)
+      TRY(hipSetDevice(ctx->device));
+      TRY(hipMemsetAsync((char*)gather + g * jb, 0, jb, ctx->stream));
+      continue;
+    }
+    const pcdhip_bases* sh = bases->shards[g];
+    const size_t ng = hi - lo;
+    C->msm_sort = ctx->msm_sort;
+    {
+      pcdhip_ctx* ctx = C;  // (TRY / BIND report into the device's own context)
+      BIND();
+      const size_t sbytes = ng * sl * 8;
+      TRY(C->msm_ws.ensure(WS_SCAL, std::max<size_t>(sbytes, 8)));
+      TRY(C->msm_ws.ensure(WS_OUT, ji + jb + 64));
+      TRY(hipMemcpyAsync(C->msm_ws.buf[WS_SCAL], scalars + (lo - offset) * sl, sbytes, hipMemcpyHostToDevice, C->stream));
+      uint32_t* out_dev = (uint32_t*)C->msm_ws.buf[WS_OUT];
+      uint32_t* out_abi = out_dev + ji / 4;
+      TRY(ge.msm(C->msm_ws, C->stream, sh->view(lo - bases->shard_lo[g]), (const uint32_t*)C->msm_ws.buf[WS_SCAL], (uint32_t)ng, out_dev, C->msm_c,
+                 C->msm_chunk, C->msm_sort, nullptr, nullptr, MSM_SHARE_NONE));
+      TRY(ge.jac_out(C->stream, out_dev, 1, out_abi));
+      if (C->msm_ws.last_err_dev) TRY(hipMemcpyAsync(&too_wide[g], C->msm_ws.last_err_dev, 4, hipMemcpyDeviceToHost, C->stream));
+    }
+    const uint32_t* out_abi = (const uint32_t*)C->msm_ws.buf[WS_OUT] + ji / 4;
+    TRY(hipSetDevice(C->device));
+    TRY(hipMemcpyPeerAsync((char*)gather + g * jb, ctx->device, out_abi, C->device, jb, C->stream));
+    if (C != ctx) {
+      if (!C->xstream_ev) TRY(hipEventCreateWithFlags(&C->xstream_ev, hipEventDisableTiming));
+      TRY(hipEventRecord(C->xstream_ev, C->stream));
+      TRY(hipSetDevice(ctx->device));
+      TRY(hipStreamWaitEvent(ctx->stream, C->xstream_ev, 0));
+    }
+  }
+  BIND();
+  TRY(ge.points_sum(ctx->stream, gather, (uint32_t)G, scratch, d));
+  TRY(hipMemcpyAsync(out_xyz, d, jb, hipMemcpyDeviceToHost, ctx->stream));
+  for (size_t g = 1; g < G; g++) { TRY(hipSetDevice(ctx->peers[g]->device)); TRY(hipStreamSynchronize(ctx->peers[g]->stream)); }
+  BIND();
+  TRY(hipStreamSynchronize(ctx->stream));
+  for (size_t g = 0; g < G; g++) if (too_wide[g]) return PCDHIP_E_ARG;
+  return PCDHIP_OK;
+}
+
 int pcdhip_msm_dev(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset,
                    size_t n, uint64_t* out_xyz) {
   if (!ctx || !bases || !scalars || !out_xyz) return PCDHIP_E_ARG;
+  if (!bases->shards.empty()) return PCDHIP_E_ARG;  // sharded bases take host scalars (pcdhip_msm): a pcdhip_buf lives on one device
   if (offset + n > bases->n || scalar_offset + n > scalars->n || n >= (1ull << 31)) return PCDHIP_E_ARG;
   if (scalars->field_id != kCurveFr[bases->curve_id]) return PCDHIP_E_ARG;
   BIND();
@@ -452,7 +582,7 @@ int pcdhip_msm_dev(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, co
 
 int pcdhip_msm_dev_partial(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset,
                            size_t n, uint64_t* out_xyz_device) {
-  if (!ctx || !bases || !scalars || !out_xyz_device) return PCDHIP_E_ARG;
+  if (!ctx || !bases || !scalars || !out_xyz_device || !bases->shards.empty()) return PCDHIP_E_ARG;
   if (offset + n > bases->n || scalar_offset + n > scalars->n || n >= (1ull << 31)) return PCDHIP_E_ARG;
   if (scalars->field_id != kCurveFr[bases->curve_id]) return PCDHIP_E_ARG;
   BIND();
@@ -463,6 +593,7 @@ int pcdhip_msm_dev_partial(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t of
 int pcdhip_msm(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const uint64_t* scalars, size_t n, uint64_t* out_xyz) {
   if (!ctx || !bases || (!scalars && n) || !out_xyz) return PCDHIP_E_ARG;
   if (offset + n > bases->n || n >= (1ull << 31)) return PCDHIP_E_ARG;
+  if (!bases->shards.empty()) return msm_sharded(ctx, bases, offset, scalars, n, out_xyz);
   BIND();
   const size_t sbytes = n * kFieldLimbs[kCurveFr[bases->curve_id]] * 8;
   TRY(ctx->msm_ws.ensure(WS_SCAL, std::max<size_t>(sbytes, 8)));

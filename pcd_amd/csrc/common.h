@@ -33,23 +33,35 @@ struct pcdhip_bases {
   int c;           // window bits fixed at upload when groups > 1 (0 otherwise)
   int groups;      // 1 = plain bases
   pcd::MsmBasesView view(size_t offset) const { return {dptr, (uint32_t)n, (uint32_t)offset, c, groups}; }
+  // uploaded through a multi-device context: the vector is cut into contiguous point ranges, shard g (points
+  // [shard_lo[g], shard_lo[g + 1])) resident on the context's device g as an ordinary handle; dptr is null then
+  std::vector<pcdhip_bases*> shards;
+  std::vector<size_t> shard_lo;
 };
 namespace pcd {
 struct DevCsr { const uint64_t* rp; const uint32_t* col; const uint32_t* coeff; uint32_t rows; };
 }
 struct pcdhip_g16_pk {
   // constraint matrices kept resident by pcdhip_g16_pk_set_r1cs (fixed per circuit, like the key)
-  void* r1cs_dev;
-  const uint64_t* rp[3];
-  const uint32_t* col[3];
-  const uint32_t* coeff[3];
-  uint32_t rows;
-  int curve_id;
-  uint64_t num_vars, num_inputs, domain_size;
+  void* r1cs_dev = nullptr;
+  const uint64_t* rp[3] = {nullptr, nullptr, nullptr};
+  const uint32_t* col[3] = {nullptr, nullptr, nullptr};
+  const uint32_t* coeff[3] = {nullptr, nullptr, nullptr};
+  uint32_t rows = 0;
+  int curve_id = 0;
+  uint64_t num_vars = 0, num_inputs = 0, domain_size = 0;
   // a / b / l queries carry four trailing slots [delta_r, delta_s, delta_rs, vk point] (see inst_g16.hip)
-  pcdhip_bases *a_query, *b_g1_query, *b_g2_query, *h_query, *l_query;
+  pcdhip_bases *a_query = nullptr, *b_g1_query = nullptr, *b_g2_query = nullptr, *h_query = nullptr, *l_query = nullptr;
+  // multi-device key: shard g holds the entry range [lo[g], lo[g + 1]) of the a' / b' / l' queries (num_vars + 4 entries) and the
+  // range [hlo[g], hlo[g + 1]) of the h query on the context's device g; the parent's own query handles are null
+  std::vector<pcdhip_g16_pk*> shards;
+  std::vector<size_t> lo, hlo;
+  uint64_t h_len = 0;
 };
 struct pcdhip_ctx {
+  // multi-device context (pcdhip_init_devices with more than one id): peers[0] == this, peers[g] = the sub-context of device g;
+  // empty for an ordinary context
+  std::vector<pcdhip_ctx*> peers;
   int device;
   hipStream_t stream;
   pcd::MsmWorkspace msm_ws;
@@ -88,6 +100,7 @@ typedef hipError_t (*PointsSumFn)(hipStream_t, const uint32_t* jac_dev, uint32_t
 typedef hipError_t (*ToAffineFn)(hipStream_t, const uint32_t* jac_dev, uint32_t n, uint32_t* aff_dev);
 struct GroupEntry {
   int point_words;      // u32 words per affine point, device-internal image (Jacobian = 3/2 of it)
+  int base_stride_words;  // u32 words between consecutive points of a resident base array (>= point_words: records may be padded)
   int point_abi_words;  // u32 words per affine point at the C-ABI
   int scalar_words;     // u32 words per canonical scalar
   int scalar_bits;
@@ -96,6 +109,9 @@ struct GroupEntry {
   hipError_t (*points_in)(hipStream_t, const uint32_t* abi_dev, uint32_t n, uint32_t* internal_dev);  // affine, ABI -> internal
   hipError_t (*jac_out)(hipStream_t, const uint32_t* internal_dev, uint32_t n, uint32_t* abi_dev);   // Jacobian, internal -> ABI
   PointsSumFn points_sum;  // ABI in, ABI out
+  // out[s] = sum over g < parts of in[g * part_stride_words + s * (Jacobian words)], s < slots; device image in and out (the
+  // combine step of a proof sharded over devices: every slot is one MSM result, every part one device's partial)
+  hipError_t (*jac_sum_parts)(hipStream_t, const uint32_t* in, size_t part_stride_words, uint32_t parts, uint32_t slots, uint32_t* out);
   ToAffineFn to_affine;    // ABI in, ABI out
   // out[i] = k_i * base (fixed_base.hip.h): base / out in the C-ABI affine image, scalars canonical words; scratch sizes in
   // u32 words: fb_table_words (window table + per-window powers), 3/2 * point_words per scalar for the Jacobian results

@@ -66,7 +66,6 @@ struct Fp {
   static constexpr uint32_t MASK = 0x0FFFFFFFu;
   static constexpr bool INLINE_ARITH = INL;
   uint32_t v[N];
-
   PCD_HD static Fp zero() { Fp r; for (int i = 0; i < N; i++) r.v[i] = 0; return r; }
   PCD_HD static Fp one() { Fp r; for (int i = 0; i < N; i++) r.v[i] = P::one(i); return r; }
   PCD_HD static Fp r2() { Fp r; for (int i = 0; i < N; i++) r.v[i] = P::r2(i); return r; }

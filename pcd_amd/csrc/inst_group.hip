@@ -56,6 +56,20 @@ __global__ void __launch_bounds__(64) to_affine_kernel(const uint32_t* __restric
   a.to_abi(out_abi + (size_t)i * Aff<F>::ABI_WORDS);
 }
 
+__global__ void __launch_bounds__(64) jac_sum_parts_kernel(const uint32_t* __restrict__ in, size_t part_stride_words, uint32_t parts, uint32_t slots,
+                                                           uint32_t* __restrict__ out) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;  // one lane per slot
+  if (s >= slots) return;
+  Jac<F> acc = Jac<F>::load(in + (size_t)s * Jac<F>::WORDS);
+  for (uint32_t g = 1; g < parts; g++) acc = EC<GT>::add(acc, Jac<F>::load(in + (size_t)g * part_stride_words + (size_t)s * Jac<F>::WORDS));
+  acc.store(out + (size_t)s * Jac<F>::WORDS);
+}
+hipError_t jac_sum_parts_entry(hipStream_t st, const uint32_t* in, size_t part_stride_words, uint32_t parts, uint32_t slots, uint32_t* out) {
+  if (slots == 0) return hipSuccess;
+  hipLaunchKernelGGL(jac_sum_parts_kernel, dim3((slots + 63) / 64), dim3(64), 0, st, in, part_stride_words, parts, slots, out);
+  return hipGetLastError();
+}
+
 hipError_t msm_entry(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bases, const uint32_t* scalars, uint32_t n,
                      uint32_t* out_dev, int c, uint32_t chunk, int sort_mode, MsmTimings* tm, MsmSharedSort* share, int share_role) {
   return msm_run<GT>(ws, st, bases, scalars, n, out_dev, c, chunk, sort_mode, tm, share, share_role);
@@ -96,8 +110,8 @@ hipError_t fixed_base_entry(hipStream_t st, const uint32_t* base_abi, const uint
 #define PCD_CAT_(a, b) a##b
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const GroupEntry* PCD_CAT(pcd_group_entry_, PCD_GROUP_IDX)() {
-  static const GroupEntry e = {Aff<F>::WORDS, Aff<F>::ABI_WORDS, GT::FR::N32, GT::FR::BITS, msm_entry, precompute_entry,
-                               points_in_entry, jac_out_entry, points_sum_entry, to_affine_entry, FB_TABLE_WORDS, fixed_base_entry};
+  static const GroupEntry e = {Aff<F>::WORDS, MsmBaseStride<GT>::value, Aff<F>::ABI_WORDS, GT::FR::N32, GT::FR::BITS, msm_entry, precompute_entry,
+                               points_in_entry, jac_out_entry, points_sum_entry, jac_sum_parts_entry, to_affine_entry, FB_TABLE_WORDS, fixed_base_entry};
   return &e;
 }
 

@@ -404,15 +404,21 @@ struct MsmEntrySource {
 };
 struct MsmCursor {  // walks the buckets of consecutive list positions
   uint32_t key, key_start, key_end;
+  uint32_t next_end;  // off[key + 2], loaded one bucket AHEAD: a lane crosses a bucket edge every ~30 additions, some lane of a wave
+                      // nearly every iteration, and a dependent global load at that point would stall the whole wave each time
   PCD_DEV void seek(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t p) {
     key = msm_find_key(off, nkeys, p);
     key_start = off[key];
     key_end = off[key + 1];
+    next_end = key + 2 <= nkeys ? off[key + 2] : key_end;
   }
   // (a few linear steps -- neighbouring buckets are the common case -- then a binary search: with signed digits the upper half
   //  of a window's key range is empty, and the lane that crosses it must not walk 2^(c-1) empty keys one load at a time)
   PCD_DEV void advance_to(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t p) {
-    for (int step = 0; step < 4 && p >= key_end; step++) { key++; key_start = key_end; key_end = off[key + 1]; }
+    for (int step = 0; step < 4 && p >= key_end; step++) {
+      key++; key_start = key_end; key_end = next_end;
+      next_end = key + 2 <= nkeys ? off[key + 2] : key_end;
+    }
     if (p >= key_end) seek(off, nkeys, p);
   }
 };
@@ -421,6 +427,18 @@ PCD_DEV uint32_t msm_entry(const MsmEntrySource& src, bool compact, const MsmCur
   return compact ? src.sorted_idx[p] : src.slots[(size_t)cur.key * src.cap + (p - cur.key_start)];
 }
 
+// u32 words between consecutive base points in a `pcdhip_bases` array.  The affine image of a 298-bit G1 point is 88 B;
+// PCD_BASE_ALIGN pads the record to 128 B so that the gather of one point touches exactly one 128-B line (it straddles two for
+// most 88-B offsets: 4.4 GB of fetch traffic per 2^20 MSM against 1.4 GB of payload, profiles/r01_pmc_fetch_summary_final.csv).
+#ifndef PCD_BASE_ALIGN
+#define PCD_BASE_ALIGN 0
+#endif
+template <class G>
+struct MsmBaseStride {
+  static constexpr int W = Aff<typename G::F>::WORDS;
+  static constexpr int value = (PCD_BASE_ALIGN && W == 22) ? 32 : W;
+};
+
 template <class G>
 struct MsmRunPlain {
   typedef typename G::F F;
@@ -428,12 +446,46 @@ struct MsmRunPlain {
   PCD_DEV void add(const Aff<F>& q) { a = EC<G>::madd(a, q); }
   PCD_DEV void flush(uint32_t* dst) { a.store(dst); a = Jac<F>::infinity(); }
 };
+// The lazily reduced accumulator is flushed AS IT IS (X carry-propagated < 16p, Y limbs < 2^29, Z reduced; the identity as
+// Z = 0): the two reducing products of lz_to_jac would run inside the divergent flush branch that some lane of the wave takes in
+// nearly every iteration.  Whatever msm_accumulate wrote -- buckets and pieces -- is reduced by its reader (MsmStored::load: the
+// fix-up pass, one lane per bucket, coalesced and convergent).
 template <class G>
 struct MsmRunLazy {
   typedef typename G::F F;
   typename EC<G>::AccLz a = EC<G>::lz_infinity();
   PCD_DEV void add(const Aff<F>& q) { a = EC<G>::madd_lz(a, q); }
-  PCD_DEV void flush(uint32_t* dst) { EC<G>::lz_to_jac(a).store(dst); a = EC<G>::lz_infinity(); }
+  PCD_DEV void flush(uint32_t* dst) {
+    if (a.inf) { F::zero().store(dst + 2 * F::WORDS); return; }
+#pragma unroll
+    for (int i = 0; i < F::N; i++) { dst[i] = (uint32_t)a.X.v[i]; dst[F::WORDS + i] = (uint32_t)a.Y.v[i]; }
+    a.Z.store(dst + 2 * F::WORDS);
+    a = EC<G>::lz_infinity();
+  }
+};
+// a point written by msm_accumulate's flush, as a reduced Jacobian point
+template <class G, bool LAZY = LazyCapable<typename G::F>::value>
+struct MsmStored {
+  typedef typename G::F F;
+  PCD_DEV static Jac<F> load(const uint32_t* p) { return Jac<F>::load(p); }
+  static constexpr bool NEEDS_FIXUP = false;
+};
+template <class G>
+struct MsmStored<G, true> {
+  typedef typename G::F F;
+  PCD_DEV static Jac<F> load(const uint32_t* p) {
+    Jac<F> r;
+    r.Z = F::load(p + 2 * F::WORDS);
+    if (r.Z.is_zero()) return Jac<F>::infinity();
+    typename F::Lz x, y;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) { x.v[i] = (int32_t)p[i]; y.v[i] = (int32_t)p[F::WORDS + i]; }
+    const typename F::Lz one = F::one().lz();
+    r.X = F::lz_mul(x, one);
+    r.Y = F::lz_mul(y, one);
+    return r;
+  }
+  static constexpr bool NEEDS_FIXUP = true;  // buckets written whole by one chunk still need the reduction
 };
 
 // Waves per SIMD the register allocation of the accumulate kernel aims at: 2 for the 298-bit G1 (194 registers, no spills);
@@ -446,15 +498,21 @@ struct MsmAccWaves {
 #ifndef PCD_ACC_WAVES_SPLIT
 #define PCD_ACC_WAVES_SPLIT 2
 #endif
-  static constexpr int value = !FA::Base::INLINE_ARITH ? 1 : FA::DEG == 1 ? 2 : SplitOf<G>::LANES > 1 ? PCD_ACC_WAVES_SPLIT : 1;
+#ifndef PCD_ACC_WAVES_G1
+#define PCD_ACC_WAVES_G1 2
+#endif
+  static constexpr int value = !FA::Base::INLINE_ARITH ? 1 : FA::DEG == 1 ? PCD_ACC_WAVES_G1 : SplitOf<G>::LANES > 1 ? PCD_ACC_WAVES_SPLIT : 1;
 };
-template <class G>
+// COMPACT: the entries form one list (`sorted_idx`, the scalars equal to one possibly in their own list `ones_idx` behind it), so
+// entry p is found without knowing its bucket; otherwise (single-pass binning, pcdhip_msm_set_sort 1) entries sit in per-bucket slots
+// and are addressed through the cursor.
+template <class G, bool COMPACT>
 __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kernel(const uint32_t* __restrict__ bases, const MsmEntrySource src,
                                                             const uint32_t* __restrict__ off, uint32_t nkeys,
                                                             uint32_t chunk, uint32_t* __restrict__ buckets,
                                                             uint32_t* __restrict__ piece_first, uint32_t* __restrict__ piece_last) {
-  // GA: the configuration the arithmetic runs in -- G itself, or its lane-split form (753-bit Fq2: two adjacent lanes
-  // share one chunk, each holding one coefficient of every coordinate; memory images are the same)
+  // GA: the configuration the arithmetic runs in -- G itself, or its lane-split form (Fq2 over lane pairs, Fq3 over lane triples:
+  // the lanes of a group share one chunk, each holding one coefficient of every coordinate; memory images are the same)
   typedef typename SplitOf<G>::type GA;
   typedef typename GA::F F;
   typedef EC<GA> E;
@@ -465,10 +523,10 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
   uint64_t start64 = (uint64_t)t * chunk;
   if (start64 >= M) return;
   uint32_t start = (uint32_t)start64, end = (uint32_t)min((uint64_t)M, start64 + chunk);
-  const bool compact = !src.flag || *src.flag != 0;
-  MsmCursor cur, nxt_cur;
+  if (!COMPACT && src.flag && *src.flag != 0) return;  // a bucket overflowed its slots: the compact instantiation runs instead
+  if (COMPACT && src.flag && *src.flag == 0) return;
+  MsmCursor cur;
   cur.seek(off, nkeys, start);
-  nxt_cur = cur;
   bool open_start = cur.key_start < start;  // current run began in an earlier chunk
   // the running sum: Jacobian, or (G1 of the 298-bit curves) the lazily reduced accumulator of EC::madd_lz
   typename std::conditional<LazyCapable<F>::value, MsmRunLazy<GA>, MsmRunPlain<GA>>::type acc;
@@ -477,30 +535,51 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
   // around every one of them (same-box A/B on MI355X: G1-753 31.4 -> 27.5 ms at 2^19, split Fq2-753 37.6 -> 33.3 ms at 2^17,
   // Fq3-753 73 -> 47 ms at 2^16 without the prefetch).
   constexpr bool PREFETCH = F::Base::INLINE_ARITH;
-  auto fetch = [&](const MsmCursor& cu, uint32_t pos) {  // the entry's point, negated for a negative digit
-    const uint32_t e = msm_entry(src, compact, cu, pos);
-    Aff<F> q = Aff<F>::load(bases + (size_t)(e & ~MSM_NEG) * Aff<F>::WORDS);
+  const uint32_t ones_start = off[src.ones_key];  // list position of the first scalar equal to one
+  auto point_of = [&](uint32_t e) {  // the entry's point, negated for a negative digit
+    Aff<F> q = Aff<F>::load(bases + (size_t)(e & ~MSM_NEG) * MsmBaseStride<G>::value);
     const F ny = q.y.neg();
     if (e & MSM_NEG) q.y = ny;
     return q;
   };
-  Aff<F> nxt;
-  if (PREFETCH) nxt = fetch(cur, start);
-  for (uint32_t p = start; p < end; p++) {
-    if (p >= cur.key_end) {  // run of `key` is complete
-      if (open_start) { acc.flush(piece_first + (size_t)t * Jac<F>::WORDS); open_start = false; }
-      else acc.flush(buckets + (size_t)cur.key * Jac<F>::WORDS);
-      cur.advance_to(off, nkeys, p);
-    }
-    if (PREFETCH) {
-      Aff<F> pt = nxt;
-      if (p + 1 < end) {
-        nxt_cur.advance_to(off, nkeys, p + 1);
-        nxt = fetch(nxt_cur, p + 1);
+  if constexpr (COMPACT) {
+    auto entry_at = [&](uint32_t pos) { return (src.ones_idx && pos >= ones_start) ? src.ones_idx[pos - ones_start] : src.sorted_idx[pos]; };
+    Aff<F> nxt;
+    if (PREFETCH) nxt = point_of(entry_at(start));
+    for (uint32_t p = start; p < end; p++) {
+      if (p >= cur.key_end) {  // run of `key` is complete
+        if (open_start) { acc.flush(piece_first + (size_t)t * Jac<F>::WORDS); open_start = false; }
+        else acc.flush(buckets + (size_t)cur.key * Jac<F>::WORDS);
+        cur.advance_to(off, nkeys, p);
       }
-      acc.add(pt);
-    } else {
-      acc.add(fetch(cur, p));
+      if (PREFETCH) {
+        const Aff<F> pt = nxt;
+        if (p + 1 < end) nxt = point_of(entry_at(p + 1));
+        acc.add(pt);
+      } else {
+        acc.add(point_of(entry_at(p)));
+      }
+    }
+  } else {
+    MsmCursor nxt_cur = cur;
+    Aff<F> nxt;
+    if (PREFETCH) nxt = point_of(msm_entry(src, false, cur, start));
+    for (uint32_t p = start; p < end; p++) {
+      if (p >= cur.key_end) {
+        if (open_start) { acc.flush(piece_first + (size_t)t * Jac<F>::WORDS); open_start = false; }
+        else acc.flush(buckets + (size_t)cur.key * Jac<F>::WORDS);
+        cur.advance_to(off, nkeys, p);
+      }
+      if (PREFETCH) {
+        const Aff<F> pt = nxt;
+        if (p + 1 < end) {
+          nxt_cur.advance_to(off, nkeys, p + 1);
+          nxt = point_of(msm_entry(src, false, nxt_cur, p + 1));
+        }
+        acc.add(pt);
+      } else {
+        acc.add(point_of(msm_entry(src, false, cur, p)));
+      }
     }
   }
   bool open_end = cur.key_end > end;
@@ -539,7 +618,10 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
     return;
   }
   uint32_t t0 = lo / chunk, t1 = (hi - 1) / chunk;
-  if (t1 == t0) return;  // the whole run lies inside one chunk: msm_accumulate wrote the bucket itself
+  if (t1 == t0) {  // the whole run lies inside one chunk: msm_accumulate wrote the bucket itself (unreduced for the lazy groups)
+    if (MsmStored<G>::NEEDS_FIXUP) MsmStored<G>::load(buckets + (size_t)key * Jac<F>::WORDS).store(buckets + (size_t)key * Jac<F>::WORDS);
+    return;
+  }
   if (t1 - t0 + 1 > big_limit) {  // big bucket: its pieces are cut into segments of seg_len, one wave each
     uint32_t nseg = (t1 - t0 + seg_len) / seg_len;
     uint32_t slot = atomicAdd(&big_count[0], 1u);
@@ -551,9 +633,9 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
     }
     return;
   }
-  Jac<F> acc = Jac<F>::load(piece_last + (size_t)t0 * Jac<F>::WORDS);
-  for (uint32_t u = t0 + 1; u < t1; u++) acc = E::add(acc, Jac<F>::load(piece_last + (size_t)u * Jac<F>::WORDS));
-  acc = E::add(acc, Jac<F>::load(piece_first + (size_t)t1 * Jac<F>::WORDS));
+  Jac<F> acc = MsmStored<G>::load(piece_last + (size_t)t0 * Jac<F>::WORDS);
+  for (uint32_t u = t0 + 1; u < t1; u++) acc = E::add(acc, MsmStored<G>::load(piece_last + (size_t)u * Jac<F>::WORDS));
+  acc = E::add(acc, MsmStored<G>::load(piece_first + (size_t)t1 * Jac<F>::WORDS));
   acc.store(buckets + (size_t)key * Jac<F>::WORDS);
 }
 
@@ -590,7 +672,7 @@ __global__ void __launch_bounds__(64) msm_big_segments_kernel(const uint32_t* __
     Jac<F> acc = Jac<F>::infinity();
     for (uint32_t u = lo + threadIdx.x; u <= hi; u += 64) {
       const uint32_t* src = (u == tlast) ? piece_first : piece_last;
-      acc = E::add(acc, Jac<F>::load(src + (size_t)u * Jac<F>::WORDS));
+      acc = E::add(acc, MsmStored<G>::load(src + (size_t)u * Jac<F>::WORDS));
     }
     msm_wave_tree<G>(acc, my, partial + (size_t)sg * Jac<F>::WORDS);
   }
@@ -711,7 +793,7 @@ __global__ void __launch_bounds__(64) points_abi_to_internal_kernel(const uint32
   typedef typename G::F F;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Aff<F>::from_abi(abi + (size_t)i * Aff<F>::ABI_WORDS).store(out + (size_t)i * Aff<F>::WORDS);
+  Aff<F>::from_abi(abi + (size_t)i * Aff<F>::ABI_WORDS).store(out + (size_t)i * MsmBaseStride<G>::value);
 }
 template <class G>
 __global__ void __launch_bounds__(64) jac_internal_to_abi_kernel(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ abi) {
@@ -732,12 +814,13 @@ __global__ void __launch_bounds__(64) msm_precompute_kernel(uint32_t* __restrict
   typedef EC<G> E;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Aff<F> p = Aff<F>::load(pts + (size_t)i * Aff<F>::WORDS);
+  constexpr int STRIDE = MsmBaseStride<G>::value;
+  Aff<F> p = Aff<F>::load(pts + (size_t)i * STRIDE);
   Jac<F> q = p.is_inf() ? Jac<F>::infinity() : Jac<F>{p.x, p.y, F::one()};
   for (int g = 1; g < groups; g++) {
     for (int d = 0; d < shift; d++) q = E::dbl(q);
     Aff<F> a = E::to_affine(q);
-    a.store(pts + ((size_t)g * n + i) * Aff<F>::WORDS);
+    a.store(pts + ((size_t)g * n + i) * STRIDE);
     if (!q.is_inf()) q = Jac<F>{a.x, a.y, F::one()};  // keep Z = 1: cheaper doublings, same point
   }
 }
@@ -958,8 +1041,10 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   PCD_HIP_TRY(mark(8));  // the accumulate stage time is the kernel alone (mark 8 -> mark 4)
   {
     constexpr uint32_t per_wave = 64 / SplitOf<G>::LANES;  // chunks per workgroup
-    hipLaunchKernelGGL((msm_accumulate_kernel<G>), dim3((nchunks + per_wave - 1) / per_wave), dim3(64), 0, st, bases_dev, src, off, tkeys,
-                       pl.chunk, buckets, pfirst, plast);
+    const dim3 acc_grid((nchunks + per_wave - 1) / per_wave);
+    // (with per-bucket slots both instantiations are queued: the device's overflow flag decides which of them does the work)
+    if (src.slots) hipLaunchKernelGGL((msm_accumulate_kernel<G, false>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, buckets, pfirst, plast);
+    hipLaunchKernelGGL((msm_accumulate_kernel<G, true>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, buckets, pfirst, plast);
   }
   PCD_HIP_TRY(mark(4));
   // 5. pieces
