@@ -56,6 +56,17 @@ const char* pcdhip_strerror(int code);
 int pcdhip_device_count(void);
 /* One context = one device + one HIP stream + reusable workspaces. */
 int pcdhip_init(int device_id, pcdhip_ctx** out);
+/* a context over a device LIST (one host thread drives all of them).  n_dev = 1 is pcdhip_init.  With more devices
+ * the context shards by contiguous point range: pcdhip_bases_upload places range g of the vector on device g and
+ * pcdhip_msm (host scalars) runs one MSM per device, gathers the partial results on device 0 over xGMI (peer copies) and sums them
+ * there; pcdhip_g16_pk_upload shards every query the same way and pcdhip_groth16_prove runs the five MSMs of the proof on every
+ * device over its range (the witness map on device 0, slices of h handed device to device) -- BASELINE configs[4]'s merge node,
+ * "its MSMs use all GPUs".  Results are bit-identical to the single-device ones.  Independent PCD DAG branches need no such
+ * context: one ordinary context per (host thread, device), N threads x N contexts (pcd_amd/dag.py).  The same id may appear more
+ * than once (two logical shards on one device; the 1-GPU tests do that).  Device-resident scalars (pcdhip_msm_dev*) and the
+ * FFT / pairing / setup entry points address device 0 only; handles created through a multi-device context belong to it. */
+int pcdhip_init_devices(const int* device_ids, int n_dev, pcdhip_ctx** out);
+int pcdhip_ctx_devices(const pcdhip_ctx* ctx);  /* number of devices of the context */
 void pcdhip_destroy(pcdhip_ctx* ctx);
 int pcdhip_sync(pcdhip_ctx* ctx);
 /* Page-locked host memory for the buffers that cross PCIe on every proof (the assignment z: 42 MB at 2^20 x 298 bits):
@@ -236,15 +247,60 @@ int pcdhip_groth16_verify(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g
                           const uint64_t* delta_g2, const uint64_t* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs,
                           const uint64_t* public_inputs_canonical, const uint64_t* proof, const uint8_t* proof_inf, int* ok);
 
-/* the native verifications of a merge node (`ECCyclePCD::verify`, mod.rs:239, once per prior
- * message) in one call: every Miller loop of the n_proofs checks runs in ONE launch (4 n_proofs lanes), the products and
- * final exponentiations in another (one lane per proof).  Same verification key for all; public inputs:
+/* ---- `process_vk` and the verifications that use it --------------------------------------------------
+ * pcdhip_process_vk replaces ark-groth16 `prepare_verifying_key` (`SNARK::process_vk`, reference call sites
+ * src/ec_cycle_pcd/mod.rs:71,371,445,495,553): e(alpha, beta) is computed ONCE and kept, gamma and delta are negated, gamma_abc_g1
+ * becomes a resident base vector.  (The G2 line coefficients upstream also precomputes are not stored: the Miller-loop kernel fuses
+ * the G2 steps with the line evaluations, one lane per pair, and a coefficient stream would be three times its own state.) */
+typedef struct pcdhip_pvk pcdhip_pvk;
+int pcdhip_process_vk(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, const uint64_t* beta_g2, const uint64_t* gamma_g2,
+                      const uint64_t* delta_g2, const uint64_t* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs, pcdhip_pvk** out);
+void pcdhip_pvk_free(pcdhip_ctx* ctx, pcdhip_pvk* pvk);
+/* `Groth16::verify_with_processed_vk` for n_proofs proofs under one key (`ECCyclePCD::verify`, mod.rs:239, once per prior message
+ * of a merge node):  e(A, B) e(acc, -gamma) e(C, -delta) == e(alpha, beta)  -- three Miller loops and ONE final exponentiation per
+ * proof (upstream's form; four and two without the prepared key), every Miller loop of the batch in one launch (3 n_proofs lanes),
+ * the products and final exponentiations in another (one lane per proof).  Deterministic: ok[i] = 1 / 0 per proof.
+ * public inputs: n_proofs x (num_inputs - 1) canonical scalars; proofs: n_proofs x (A || B || C); proofs_inf: n_proofs x 3 or NULL. */
+int pcdhip_groth16_verify_prepared(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_t n_proofs, const uint64_t* public_inputs_canonical,
+                                   const uint64_t* proofs, const uint8_t* proofs_inf, int* ok);
+/* The same n_proofs checks folded into ONE product with a SHARED final exponentiation, by a random linear combination with the
+ * caller's challenges rho (n_proofs x 2 u64 limbs = 128 bits each, non-zero; the library draws no randomness):
+ *   prod_i e(rho_i A_i, B_i) e(sum rho_i acc_i, -gamma) e(sum rho_i C_i, -delta) e(-(sum rho_i) alpha, beta) == 1
+ * -- n_proofs + 3 Miller loops in one launch, one final exponentiation.  *all_ok = 1 iff the product is one: every proof valid,
+ * or an invalid batch that slipped through with probability 2^-128 over rho.  On 0, pcdhip_groth16_verify_prepared finds the culprit. */
+int pcdhip_groth16_verify_batch_rlc(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_t n_proofs, const uint64_t* public_inputs_canonical,
+                                    const uint64_t* proofs, const uint8_t* proofs_inf, const uint64_t* rho, int* all_ok);
+
+/* The native verifications of a merge node (`ECCyclePCD::verify`, mod.rs:239, once per prior
+ * message) in one call = pcdhip_process_vk + pcdhip_groth16_verify_prepared + pcdhip_pvk_free.  Same verification key for all; public inputs:
  * n_proofs x (num_inputs - 1) canonical scalars; proofs: n_proofs x (A || B || C); proofs_inf: n_proofs x 3 flags or NULL.
  * ok[i] = 1 / 0 per proof -- deterministic, the same answers as n_proofs calls of pcdhip_groth16_verify. */
 int pcdhip_groth16_verify_batch(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, const uint64_t* beta_g2,
                                 const uint64_t* gamma_g2, const uint64_t* delta_g2, const uint64_t* gamma_abc_g1,
                                 const uint8_t* gamma_abc_inf, size_t num_inputs, size_t n_proofs,
                                 const uint64_t* public_inputs_canonical, const uint64_t* proofs, const uint8_t* proofs_inf, int* ok);
+
+/* ---- wire format ---------------------------------------------------------------------------
+ * Replaces ark-serialize `CanonicalSerialize::{serialize, serialize_uncompressed}` / `CanonicalDeserialize` for
+ * `GroupAffine` (G1 and G2 of the four curves), ark-groth16 `Proof` (A || B || C) and `VerifyingKey` (alpha_g1, beta_g2, gamma_g2,
+ * delta_g2, u64 length + gamma_abc_g1): what a proof or key looks like when it leaves the process that made it.  Host-side
+ * (no GPU, no context).  Field elements: canonical little-endian integers in ceil(bits / 8) bytes (38 / 95), Fq2 / Fq3 as c0, c1
+ * (, c2); flags in the top bits of the last byte: 0x80 = y is the larger of (y, -y), 0x40 = infinity; compressed = x with flags,
+ * uncompressed = x, y with flags.  Points at this ABI are x || y Montgomery limbs + a flag byte, as everywhere in this header.
+ * Reading checks that coordinates are reduced and that the point lies on the curve (compressed: rebuilds y by a square root);
+ * PCDHIP_E_ARG otherwise.  Sizes are 0 for invalid ids. */
+size_t pcdhip_serialized_size(int curve_id, int group_id, int compressed);  /* bytes of one point */
+int pcdhip_serialize_points(int curve_id, int group_id, const uint64_t* xy_mont, const uint8_t* inf, size_t n, int compressed, uint8_t* out);
+int pcdhip_deserialize_points(int curve_id, int group_id, const uint8_t* in, size_t n, int compressed, uint64_t* xy_mont, uint8_t* inf);
+size_t pcdhip_proof_serialized_size(int curve_id, int compressed);
+int pcdhip_proof_serialize(int curve_id, const uint64_t* proof, const uint8_t* proof_inf, int compressed, uint8_t* out);
+int pcdhip_proof_deserialize(int curve_id, const uint8_t* in, int compressed, uint64_t* proof, uint8_t* proof_inf);
+size_t pcdhip_vk_serialized_size(int curve_id, size_t num_inputs, int compressed);
+int pcdhip_vk_serialize(int curve_id, const uint64_t* alpha_g1, const uint64_t* beta_g2, const uint64_t* gamma_g2, const uint64_t* delta_g2,
+                        const uint64_t* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs, int compressed, uint8_t* out);
+/* gamma_abc arrays hold up to max_inputs points; the count found is returned in num_inputs */
+int pcdhip_vk_deserialize(int curve_id, const uint8_t* in, size_t in_len, int compressed, uint64_t* alpha_g1, uint64_t* beta_g2, uint64_t* gamma_g2,
+                          uint64_t* delta_g2, uint64_t* gamma_abc_g1, uint8_t* gamma_abc_inf, size_t max_inputs, size_t* num_inputs);
 
 /* ---- timing helpers (HIP events on the context's stream, for bench.py) ------------------------- */
 int pcdhip_timer_start(pcdhip_ctx* ctx);

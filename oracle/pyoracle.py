@@ -622,3 +622,44 @@ def unpack_jacobian(curve, group, xyz):
     zi = F.inv(Z)
     zi2 = F.mul(zi, zi)
     return (F.mul(X, zi2), F.mul(Y, F.mul(zi2, zi)))
+
+
+# ----------------------------------------------------------------------------- wire format (ark-serialize CanonicalSerialize, restated)
+def _ser_elem(curve, e, flags=0):
+    nb = (curve.fq.bits + 7) // 8
+    out = bytearray()
+    for c in e:
+        out += int(c).to_bytes(nb, "little")
+    out[-1] |= flags
+    return bytes(out)
+
+
+def _y_is_larger(F, y):
+    ny = F.neg(y)
+    return tuple(reversed(y)) > tuple(reversed(ny))   # most significant coefficient first, integers per coefficient
+
+
+def serialize_point(curve, group, P, compressed=True):
+    """affine point (ext-tuples) or None -> bytes: flags 0x80 = y is the larger root, 0x40 = infinity, in the top bits of the last byte"""
+    F, _ = curve.group(group)
+    if P is None:
+        return _ser_elem(curve, F.zero(), 0x40) if compressed else _ser_elem(curve, F.zero()) + _ser_elem(curve, F.one(), 0x40)
+    x, y = P
+    if compressed:
+        return _ser_elem(curve, x, 0x80 if _y_is_larger(F, y) else 0)
+    return _ser_elem(curve, x) + _ser_elem(curve, y)
+
+
+def serialize_proof(curve, proof, compressed=True):
+    A, B, Cc = proof
+    return serialize_point(curve, 1, A, compressed) + serialize_point(curve, 2, B, compressed) + serialize_point(curve, 1, Cc, compressed)
+
+
+def serialize_vk(curve, alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1, compressed=True):
+    out = serialize_point(curve, 1, alpha_g1, compressed)
+    for Q in (beta_g2, gamma_g2, delta_g2):
+        out += serialize_point(curve, 2, Q, compressed)
+    out += len(gamma_abc_g1).to_bytes(8, "little")
+    for P in gamma_abc_g1:
+        out += serialize_point(curve, 1, P, compressed)
+    return out

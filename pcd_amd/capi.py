@@ -41,13 +41,16 @@ class G16PkHost(C.Structure):
 _LIB = None
 
 EXPORTS = [
-    "pcdhip_strerror", "pcdhip_device_count", "pcdhip_init", "pcdhip_destroy", "pcdhip_sync", "pcdhip_host_alloc", "pcdhip_host_free", "pcdhip_last_hip_error",
+    "pcdhip_strerror", "pcdhip_device_count", "pcdhip_init", "pcdhip_init_devices", "pcdhip_ctx_devices", "pcdhip_destroy", "pcdhip_sync", "pcdhip_host_alloc", "pcdhip_host_free", "pcdhip_last_hip_error",
     "pcdhip_field_limbs", "pcdhip_curve_base_field", "pcdhip_curve_scalar_field", "pcdhip_point_limbs",
     "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
     "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config", "pcdhip_bases_info", "pcdhip_stream_wait",
     "pcdhip_set_precompute", "pcdhip_msm_set_sort", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
     "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
+    "pcdhip_serialized_size", "pcdhip_serialize_points", "pcdhip_deserialize_points", "pcdhip_proof_serialized_size", "pcdhip_proof_serialize",
+    "pcdhip_proof_deserialize", "pcdhip_vk_serialized_size", "pcdhip_vk_serialize", "pcdhip_vk_deserialize",
+    "pcdhip_process_vk", "pcdhip_pvk_free", "pcdhip_groth16_verify_prepared", "pcdhip_groth16_verify_batch_rlc",
     "pcdhip_multi_pairing", "pcdhip_groth16_verify", "pcdhip_groth16_verify_batch", "pcdhip_timer_start", "pcdhip_timer_stop",
 ]
 
@@ -64,7 +67,9 @@ def lib():
         _LIB.pcdhip_last_hip_error.restype = C.c_char_p
         _LIB.pcdhip_destroy.restype = None
         _LIB.pcdhip_domain_size.restype = C.c_size_t
-        for name in ("pcdhip_buf_free", "pcdhip_bases_free", "pcdhip_g16_pk_free", "pcdhip_host_free"):
+        for name in ("pcdhip_serialized_size", "pcdhip_proof_serialized_size", "pcdhip_vk_serialized_size"):
+            getattr(_LIB, name).restype = C.c_size_t
+        for name in ("pcdhip_buf_free", "pcdhip_bases_free", "pcdhip_g16_pk_free", "pcdhip_host_free", "pcdhip_pvk_free"):
             getattr(_LIB, name).restype = None
     return _LIB
 
@@ -85,14 +90,21 @@ def point_limbs(curve, group):
 
 
 class Context:
-    """One device + one HIP stream (pcdhip_ctx)."""
+    """One device + one HIP stream (pcdhip_ctx); with `devices=[...]` a multi-device context (pcdhip_init_devices) that shards
+    bases, keys, MSMs and proofs by point range over the listed devices."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
         self._ctx = C.c_void_p()
-        rc = lib().pcdhip_init(int(device), C.byref(self._ctx))
+        if devices is not None:
+            ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+            rc = lib().pcdhip_init_devices(ids, len(devices), C.byref(self._ctx))
+            device = devices[0]
+        else:
+            rc = lib().pcdhip_init(int(device), C.byref(self._ctx))
         if rc != 0:
-            raise PcdHipError(f"pcdhip_init(device={device}) failed: {lib().pcdhip_strerror(rc).decode()}")
+            raise PcdHipError(f"pcdhip_init(device={device}, devices={devices}) failed: {lib().pcdhip_strerror(rc).decode()}")
         self.device = device
+        self.devices = list(devices) if devices is not None else [device]
 
     def close(self):
         if self._ctx:
@@ -354,6 +366,37 @@ class Context:
                                                       _p(pinf), ok))
         return np.array([ok[i] == 1 for i in range(k)])
 
+    def process_vk(self, curve, alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1, gamma_abc_inf=None):
+        """SNARK::process_vk: e(alpha, beta) cached, gamma / delta negated, gamma_abc resident."""
+        abc = _u64(gamma_abc_g1).reshape(-1, point_limbs(curve, G1))
+        gi = np.ascontiguousarray(gamma_abc_inf, dtype=np.uint8) if gamma_abc_inf is not None else None
+        h = C.c_void_p()
+        self._check(lib().pcdhip_process_vk(self._ctx, curve, _p(_u64(alpha_g1)), _p(_u64(beta_g2)), _p(_u64(gamma_g2)), _p(_u64(delta_g2)),
+                                            _p(abc), _p(gi), C.c_size_t(abc.shape[0]), C.byref(h)))
+        return Pvk(self, h, curve, abc.shape[0])
+
+    def _proof_batch(self, pvk, public_inputs_canonical, proofs, proofs_inf):
+        pr = _u64(proofs).reshape(-1, 2 * point_limbs(pvk.curve, G1) + point_limbs(pvk.curve, G2))
+        k = pr.shape[0]
+        pi = _u64(public_inputs_canonical).reshape(k, (pvk.num_inputs - 1) * FIELD_LIMBS[CURVE_FR[pvk.curve]]) if pvk.num_inputs > 1 else None
+        pinf = np.ascontiguousarray(proofs_inf, dtype=np.uint8) if proofs_inf is not None else None
+        return pr, k, pi, pinf
+
+    def groth16_verify_prepared(self, pvk, public_inputs_canonical, proofs, proofs_inf=None):
+        """verify_with_processed_vk for n proofs -> bool array (3 Miller loops + 1 final exponentiation per proof)."""
+        pr, k, pi, pinf = self._proof_batch(pvk, public_inputs_canonical, proofs, proofs_inf)
+        ok = (C.c_int * max(k, 1))()
+        self._check(lib().pcdhip_groth16_verify_prepared(self._ctx, pvk._h, C.c_size_t(k), _p(pi), _p(pr), _p(pinf), ok))
+        return np.array([ok[i] == 1 for i in range(k)])
+
+    def groth16_verify_batch_rlc(self, pvk, public_inputs_canonical, proofs, rho, proofs_inf=None):
+        """all n proofs with ONE shared final exponentiation; rho: (n, 2) uint64 non-zero 128-bit challenges -> bool."""
+        pr, k, pi, pinf = self._proof_batch(pvk, public_inputs_canonical, proofs, proofs_inf)
+        rho = _u64(rho).reshape(k, 2)
+        ok = C.c_int(0)
+        self._check(lib().pcdhip_groth16_verify_batch_rlc(self._ctx, pvk._h, C.c_size_t(k), _p(pi), _p(pr), _p(pinf), _p(rho), C.byref(ok)))
+        return ok.value == 1
+
     # ---- timing
     def timer_start(self):
         self._check(lib().pcdhip_timer_start(self._ctx))
@@ -362,6 +405,67 @@ class Context:
         ms = C.c_float()
         self._check(lib().pcdhip_timer_stop(self._ctx, C.byref(ms)))
         return ms.value
+
+
+# ---- wire format (host-side: no context, no GPU)
+def _wire_check(rc):
+    if rc != 0:
+        raise PcdHipError(f"{lib().pcdhip_strerror(rc).decode()} (rc={rc})")
+
+
+def serialize_points(curve, group, xy, inf=None, compressed=True):
+    """CanonicalSerialize of n affine points -> bytes."""
+    xy = _u64(xy).reshape(-1, point_limbs(curve, group))
+    n = xy.shape[0]
+    infp = np.ascontiguousarray(inf, dtype=np.uint8) if inf is not None else None
+    out = np.zeros(n * lib().pcdhip_serialized_size(curve, group, int(compressed)), dtype=np.uint8)
+    _wire_check(lib().pcdhip_serialize_points(curve, group, _p(xy), _p(infp), C.c_size_t(n), int(compressed), _p(out)))
+    return out.tobytes()
+
+
+def deserialize_points(curve, group, data, n, compressed=True):
+    buf = np.frombuffer(data, dtype=np.uint8).copy()
+    xy = np.zeros((n, point_limbs(curve, group)), dtype=np.uint64)
+    inf = np.zeros(n, dtype=np.uint8)
+    _wire_check(lib().pcdhip_deserialize_points(curve, group, _p(buf), C.c_size_t(n), int(compressed), _p(xy), _p(inf)))
+    return xy, inf
+
+
+def proof_serialize(curve, proof, proof_inf=None, compressed=True):
+    out = np.zeros(lib().pcdhip_proof_serialized_size(curve, int(compressed)), dtype=np.uint8)
+    pinf = np.ascontiguousarray(proof_inf, dtype=np.uint8) if proof_inf is not None else None
+    _wire_check(lib().pcdhip_proof_serialize(curve, _p(_u64(proof)), _p(pinf), int(compressed), _p(out)))
+    return out.tobytes()
+
+
+def proof_deserialize(curve, data, compressed=True):
+    buf = np.frombuffer(data, dtype=np.uint8).copy()
+    proof = np.zeros(2 * point_limbs(curve, G1) + point_limbs(curve, G2), dtype=np.uint64)
+    inf = np.zeros(3, dtype=np.uint8)
+    _wire_check(lib().pcdhip_proof_deserialize(curve, _p(buf), int(compressed), _p(proof), _p(inf)))
+    return proof, inf
+
+
+def vk_serialize(curve, alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1, gamma_abc_inf=None, compressed=True):
+    abc = _u64(gamma_abc_g1).reshape(-1, point_limbs(curve, G1))
+    ni = abc.shape[0]
+    gi = np.ascontiguousarray(gamma_abc_inf, dtype=np.uint8) if gamma_abc_inf is not None else None
+    out = np.zeros(lib().pcdhip_vk_serialized_size(curve, C.c_size_t(ni), int(compressed)), dtype=np.uint8)
+    _wire_check(lib().pcdhip_vk_serialize(curve, _p(_u64(alpha_g1)), _p(_u64(beta_g2)), _p(_u64(gamma_g2)), _p(_u64(delta_g2)), _p(abc), _p(gi),
+                                          C.c_size_t(ni), int(compressed), _p(out)))
+    return out.tobytes()
+
+
+def vk_deserialize(curve, data, compressed=True, max_inputs=1 << 16):
+    buf = np.frombuffer(data, dtype=np.uint8).copy()
+    l1, l2 = point_limbs(curve, G1), point_limbs(curve, G2)
+    a, b, g, d = (np.zeros(k, dtype=np.uint64) for k in (l1, l2, l2, l2))
+    abc = np.zeros((max_inputs, l1), dtype=np.uint64)
+    inf = np.zeros(max_inputs, dtype=np.uint8)
+    cnt = C.c_size_t(0)
+    _wire_check(lib().pcdhip_vk_deserialize(curve, _p(buf), C.c_size_t(len(buf)), int(compressed), _p(a), _p(b), _p(g), _p(d), _p(abc), _p(inf),
+                                            C.c_size_t(max_inputs), C.byref(cnt)))
+    return dict(alpha_g1=a, beta_g2=b, gamma_g2=g, delta_g2=d, gamma_abc_g1=abc[:cnt.value].copy(), gamma_abc_inf=inf[:cnt.value].copy())
 
 
 def pinned_like(a):
@@ -410,6 +514,16 @@ class Bases:
     def free(self):
         if self._h:
             lib().pcdhip_bases_free(self.ctx._ctx, self._h)
+            self._h = None
+
+
+class Pvk:
+    def __init__(self, ctx, h, curve, num_inputs):
+        self.ctx, self._h, self.curve, self.num_inputs = ctx, h, curve, num_inputs
+
+    def free(self):
+        if self._h:
+            lib().pcdhip_pvk_free(self.ctx._ctx, self._h)
             self._h = None
 
 

@@ -36,6 +36,14 @@ const CurveEntry& curve_entry(int curve_id) {
   return *tab[curve_id]();
 }
 
+typedef hipError_t (*G1ScaleFn)(hipStream_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*);
+G1ScaleFn pcd_g1_scale_entry_0(); G1ScaleFn pcd_g1_scale_entry_1(); G1ScaleFn pcd_g1_scale_entry_2(); G1ScaleFn pcd_g1_scale_entry_3();
+G1ScaleFn g1_scale_entry(int curve_id) {
+  typedef G1ScaleFn (*Fn)();
+  static const Fn tab[4] = {pcd_g1_scale_entry_0, pcd_g1_scale_entry_1, pcd_g1_scale_entry_2, pcd_g1_scale_entry_3};
+  return tab[curve_id]();
+}
+
 const PairingEntry& pairing_entry(int curve_id) {
   typedef const PairingEntry* (*Fn)();
   static const Fn tab[4] = {pcd_pairing_entry_0, pcd_pairing_entry_1, pcd_pairing_entry_2, pcd_pairing_entry_3};
@@ -843,53 +851,88 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
   if (h->num_vars < 1 || h->num_inputs < 1 || h->num_inputs > h->num_vars || h->l_len != h->num_vars - h->num_inputs) return PCDHIP_E_ARG;
   BIND();
   const int cid = (int)h->curve_id;
-  pcdhip_g16_pk* pk = new (std::nothrow) pcdhip_g16_pk();
-  if (!pk) return PCDHIP_E_OOM;
-  memset(pk, 0, sizeof *pk);
-  pk->curve_id = cid; pk->num_vars = h->num_vars; pk->num_inputs = h->num_inputs; pk->domain_size = h->domain_size;
-  int rc = 0;
+  const size_t m = h->num_vars, ni = h->num_inputs;
   // delta is appended to the a / b / l queries: r*delta, s*delta and -rs*delta then ride inside the MSMs as
   // one more (base, scalar) pair instead of being serial scalar multiplications in the assembly.
   // Every a / b / l query gets four trailing slots matching the scalar tail [r, s, -rs, 1] that follows the
   // assignment: delta sits in the slot whose scalar the query needs, the vk point (alpha / beta) in the last one,
   // the remaining slots hold the point at infinity.  See inst_g16.hip.
-  auto upload_plus = [&](int group, const uint64_t* q, const uint8_t* inf, size_t n, const uint64_t* delta, int delta_slot,
-                         const uint64_t* vk_point, pcdhip_bases** out) -> int {
+  struct HostQuery { std::vector<uint64_t> pts; std::vector<uint8_t> inf; size_t n = 0; int group = 1; };
+  auto with_tail = [&](int group, const uint64_t* q, const uint8_t* inf, size_t n, const uint64_t* delta, int delta_slot, const uint64_t* vk_point) {
+    HostQuery hq;
     const size_t pl = (size_t)pcdhip_point_limbs(cid, group);
-    std::vector<uint64_t> tmp((n + 4) * pl, 0);
-    std::vector<uint8_t> tinf(n + 4, 1);
-    if (n) memcpy(tmp.data(), q, n * pl * 8);
-    for (size_t i = 0; i < n; i++) tinf[i] = inf ? inf[i] : 0;
-    memcpy(tmp.data() + (n + delta_slot) * pl, delta, pl * 8);
-    tinf[n + delta_slot] = 0;
-    if (vk_point) { memcpy(tmp.data() + (n + 3) * pl, vk_point, pl * 8); tinf[n + 3] = 0; }
-    return pcdhip_bases_upload(ctx, cid, group, tmp.data(), tinf.data(), n + 4, out);
+    hq.group = group; hq.n = n + 4;
+    hq.pts.assign((n + 4) * pl, 0);
+    hq.inf.assign(n + 4, 1);
+    if (n) memcpy(hq.pts.data(), q, n * pl * 8);
+    for (size_t i = 0; i < n; i++) hq.inf[i] = inf ? inf[i] : 0;
+    memcpy(hq.pts.data() + (n + delta_slot) * pl, delta, pl * 8);
+    hq.inf[n + delta_slot] = 0;
+    if (vk_point) { memcpy(hq.pts.data() + (n + 3) * pl, vk_point, pl * 8); hq.inf[n + 3] = 0; }
+    return hq;
   };
-  rc = rc ? rc : upload_plus(1, h->a_query, h->a_inf, h->num_vars, h->delta_g1, 0, h->alpha_g1, &pk->a_query);        // r * delta + alpha
-  rc = rc ? rc : upload_plus(1, h->b_g1_query, h->b_g1_inf, h->num_vars, h->delta_g1, 1, h->beta_g1, &pk->b_g1_query);  // s * delta + beta
-  rc = rc ? rc : upload_plus(2, h->b_g2_query, h->b_g2_inf, h->num_vars, h->delta_g2, 1, h->beta_g2, &pk->b_g2_query);
-  rc = rc ? rc : pcdhip_bases_upload(ctx, cid, 1, h->h_query, h->h_inf, h->h_len, &pk->h_query);
+  HostQuery qa = with_tail(1, h->a_query, h->a_inf, m, h->delta_g1, 0, h->alpha_g1);          // r * delta + alpha
+  HostQuery qb1 = with_tail(1, h->b_g1_query, h->b_g1_inf, m, h->delta_g1, 1, h->beta_g1);     // s * delta + beta
+  HostQuery qb2 = with_tail(2, h->b_g2_query, h->b_g2_inf, m, h->delta_g2, 1, h->beta_g2);
+  HostQuery ql;
   {  // l: padded in front with num_inputs points at infinity, so that it is indexed by the variable like a / b (one
      // sort of the assignment's digits then serves all four MSMs);  -rs * delta in slot 2
-    const size_t pl = (size_t)pcdhip_point_limbs(cid, 1), m = h->num_vars, ni = h->num_inputs;
+    const size_t pl = (size_t)pcdhip_point_limbs(cid, 1);
     std::vector<uint64_t> tmp(m * pl, 0);
     std::vector<uint8_t> tinf(m, 1);
     if (h->l_len) memcpy(tmp.data() + ni * pl, h->l_query, h->l_len * pl * 8);
     for (size_t i = 0; i < h->l_len; i++) tinf[ni + i] = h->l_inf ? h->l_inf[i] : 0;
-    rc = rc ? rc : upload_plus(1, tmp.data(), tinf.data(), m, h->delta_g1, 2, nullptr, &pk->l_query);
+    ql = with_tail(1, tmp.data(), tinf.data(), m, h->delta_g1, 2, nullptr);
   }
-  if (rc) { pcdhip_g16_pk_free(ctx, pk); return rc; }
-  *out = pk;
+  // one key per device: the whole queries on an ordinary context, the entry range [lo, hi) of the a' / b' / l' queries and the
+  // range [hlo, hhi) of the h query on device g of a multi-device context
+  auto upload_range = [&](pcdhip_ctx* C, size_t lo, size_t hi, size_t hlo, size_t hhi, pcdhip_g16_pk** res) -> int {
+    pcdhip_g16_pk* pk = new pcdhip_g16_pk();
+    pk->curve_id = cid; pk->num_vars = m; pk->num_inputs = ni; pk->domain_size = h->domain_size; pk->h_len = h->h_len;
+    C->precompute = ctx->precompute; C->msm_c = ctx->msm_c;
+    auto up = [&](const HostQuery& q, pcdhip_bases** dst) -> int {
+      const size_t pl = (size_t)pcdhip_point_limbs(cid, q.group);
+      return bases_upload_single(C, cid, q.group, q.pts.data() + lo * pl, q.inf.data() + lo, hi - lo, dst);
+    };
+    int rc = up(qa, &pk->a_query);
+    rc = rc ? rc : up(qb1, &pk->b_g1_query);
+    rc = rc ? rc : up(qb2, &pk->b_g2_query);
+    rc = rc ? rc : up(ql, &pk->l_query);
+    const size_t pl1 = (size_t)pcdhip_point_limbs(cid, 1);
+    rc = rc ? rc : bases_upload_single(C, cid, 1, h->h_query ? h->h_query + hlo * pl1 : nullptr, h->h_inf ? h->h_inf + hlo : nullptr, hhi - hlo, &pk->h_query);
+    if (rc) { pcdhip_g16_pk_free(C, pk); return rc; }
+    *res = pk;
+    return PCDHIP_OK;
+  };
+  *out = nullptr;
+  if (ctx->peers.size() <= 1) return upload_range(ctx, 0, m + 4, 0, h->h_len, out);
+  pcdhip_g16_pk* parent = new pcdhip_g16_pk();
+  parent->curve_id = cid; parent->num_vars = m; parent->num_inputs = ni; parent->domain_size = h->domain_size; parent->h_len = h->h_len;
+  const size_t G = ctx->peers.size();
+  parent->lo.resize(G + 1); parent->hlo.resize(G + 1);
+  for (size_t g = 0; g < G; g++) {
+    size_t lo, hi, hlo, hhi;
+    shard_range(m + 4, g, G, &lo, &hi);
+    shard_range(h->h_len, g, G, &hlo, &hhi);
+    parent->lo[g] = lo; parent->lo[g + 1] = hi; parent->hlo[g] = hlo; parent->hlo[g + 1] = hhi;
+    pcdhip_g16_pk* sh = nullptr;
+    int rc = upload_range(ctx->peers[g], lo, hi, hlo, hhi, &sh);
+    if (rc) { pcdhip_g16_pk_free(ctx, parent); return rc; }
+    parent->shards.push_back(sh);
+  }
+  *out = parent;
   return PCDHIP_OK;
   });
 }
 int pcdhip_g16_pk_set_r1cs(pcdhip_ctx* ctx, pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C) {
   if (!ctx || !pk || !A || !B || !C) return PCDHIP_E_ARG;
+  if (!pk->shards.empty()) return pcdhip_g16_pk_set_r1cs(ctx, pk->shards[0], A, B, C);  // the witness map runs on device 0
   if (A->num_rows != B->num_rows || A->num_rows != C->num_rows || (A->num_rows >> 31)) return PCDHIP_E_ARG;
   if (!A->row_ptr || !B->row_ptr || !C->row_ptr) return PCDHIP_E_ARG;
   BIND();
   const FieldEntry& fe = field_entry(kCurveFr[pk->curve_id]);
   const pcdhip_csr* ms[3] = {A, B, C};
+  for (int k = 0; k < 3; k++) { int rc = validate_csr(ms[k], pk->num_vars); if (rc) return rc; }
   size_t total = 0, base[3], off[3];
   for (int k = 0; k < 3; k++) { base[k] = total; total += csr_bytes(ms[k], fe, off) + 64; }
   if (pk->r1cs_dev) { (void)hipFree(pk->r1cs_dev); pk->r1cs_dev = nullptr; }
@@ -906,114 +949,91 @@ int pcdhip_g16_pk_set_r1cs(pcdhip_ctx* ctx, pcdhip_g16_pk* pk, const pcdhip_csr*
 }
 void pcdhip_g16_pk_free(pcdhip_ctx* ctx, pcdhip_g16_pk* pk) {
   if (!pk) return;
+  for (size_t g = 0; g < pk->shards.size(); g++) pcdhip_g16_pk_free(ctx && g < ctx->peers.size() ? ctx->peers[g] : ctx, pk->shards[g]);
+  pk->shards.clear();
+  if (ctx) (void)hipSetDevice(ctx->device);
   if (pk->r1cs_dev) (void)hipFree(pk->r1cs_dev);
   pcdhip_bases_free(ctx, pk->a_query); pcdhip_bases_free(ctx, pk->b_g1_query); pcdhip_bases_free(ctx, pk->b_g2_query);
   pcdhip_bases_free(ctx, pk->h_query); pcdhip_bases_free(ctx, pk->l_query);
   delete pk;
 }
 
-int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C,
-                         const uint64_t* z, const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out, uint8_t* inf_out) {
-  if (!ctx || !pk || !z || !r_mont || !s_mont || !proof_out) return PCDHIP_E_ARG;
-  BIND();
-  const int cid = pk->curve_id, fr = kCurveFr[cid];
-  const FieldEntry& fe = field_entry(fr);
-  const size_t m = pk->num_vars, ni = pk->num_inputs;
-  const uint32_t sw = (uint32_t)fe.abi_words;  // words of a canonical scalar == words of an ABI element
-  const size_t sb = (size_t)sw * 4;
-  hipStream_t st = ctx->stream;
-  EventSet<8> ev;
-  TRY(ev.create());
-  TRY(hipEventRecord(ev[0], st));
-  // z (C-ABI Montgomery) -> device image for the SpMV; canonical words of z, s*z and r*z (each followed by its
-  // 4-entry tail, see inst_g16.hip) for the MSMs
-  TRY(ctx->aux_ws.ensure(AUX_Z, m * fe.words * 4));
-  TRY(ctx->aux_ws.ensure(AUX_SCAL, m * sb));
-  TRY(ctx->aux_ws.ensure(AUX_Z_CANON, 3 * (m + 4) * sb + 2 * sb));
-  uint32_t* z_dev = (uint32_t*)ctx->aux_ws.buf[AUX_Z];
-  uint32_t* z_abi = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
-  uint32_t* z_can = (uint32_t*)ctx->aux_ws.buf[AUX_Z_CANON];
-  uint32_t* sz_can = z_can + (m + 4) * sw;
-  uint32_t* rz_can = sz_can + (m + 4) * sw;
-  uint32_t* rs_dev = rz_can + (m + 4) * sw;  // r, s (C-ABI Montgomery)
-  TRY(hipMemcpyAsync(z_abi, z, m * sb, hipMemcpyHostToDevice, st));
-  TRY(hipMemcpyAsync(rs_dev, r_mont, sb, hipMemcpyHostToDevice, st));
-  TRY(hipMemcpyAsync(rs_dev + sw, s_mont, sb, hipMemcpyHostToDevice, st));
-  TRY(fe.convert(st, z_abi, z_dev, (uint32_t)m, 0));
-  TRY(fe.scale_canon(st, z_dev, nullptr, z_can, (uint32_t)m, 1));
-  TRY(fe.scale_canon(st, z_dev, rs_dev + sw, sz_can, (uint32_t)m, 1));
-  TRY(fe.scale_canon(st, z_dev, rs_dev, rz_can, (uint32_t)m, 1));
-  // ---- K3/K4/K5 first: the four MSMs that take the assignment (l', A, B_1 on G1; B on G2) do not need h, so they are
-  // launched before the witness map and run concurrently with it; the h MSM follows the witness map.  Results stay on the
-  // device (device image).  The two variable-base products of the assembly, s*A and r*B_1, are either one-lane products
-  // queued right behind the A / B_1 MSMs on their high-priority streams, where they overlap the longer MSMs, or two more
-  // MSMs over the same bases with every scalar scaled by s / r (pcdhip_groth16_set_assembly).
-  DevCsr mats[3];
-  int rc = PCDHIP_OK;
-  uint32_t rows = 0;
-  if (A && B && C) rows = (uint32_t)A->num_rows;
-  else if (!A && !B && !C && pk->r1cs_dev) rows = pk->rows;
-  else return PCDHIP_E_ARG;
-  Dom dom;
-  rc = pick_domain(fr, (size_t)rows + ni, &dom);
-  if (rc) return rc;
-  const size_t n = dom.n;
-  TRY(ctx->aux_ws.ensure(AUX_H_CANON, n * sb));
-  uint32_t* h_can = (uint32_t*)ctx->aux_ws.buf[AUX_H_CANON];
-  const GroupEntry& g1 = group_entry(cid, 1);
-  const GroupEntry& g2 = group_entry(cid, 2);
-  const size_t j1 = (size_t)g1.point_words / 2 * 3 * 4, j2 = (size_t)g2.point_words / 2 * 3 * 4;
-  const CurveEntry& ce = curve_entry(cid);
-  TRY(ctx->aux_ws.ensure(AUX_G16, 6 * j1 + j2 + 2 * 16 * j1 + ce.proof_abi_bytes + 256));
-  char* gbase = (char*)ctx->aux_ws.buf[AUX_G16];
-  uint32_t* msm_g1 = (uint32_t*)gbase;  // h, l', A, s*A, r*B_1, B_1
-  uint32_t* msm_g2 = (uint32_t*)(gbase + 6 * j1);
-  uint32_t* mul_scratch = (uint32_t*)(gbase + 6 * j1 + j2);
-  uint32_t* proof_dev = (uint32_t*)(gbase + 6 * j1 + j2 + 2 * 16 * j1);
-  auto slot = [&](int i) { return (uint32_t*)((char*)msm_g1 + i * j1); };
-  const size_t hl = std::min<size_t>(pk->h_query->n, n);
-  uint32_t* t1 = z_can + m * sw;  // [r, s, -rs, 1] canonical
-  TRY(ce.prepare_scalars(st, rs_dev, t1, sz_can + m * sw, rz_can + m * sw));
-  if (!ctx->g16_ready) {
-    TRY(hipEventCreateWithFlags(&ctx->g16_ready, hipEventDisableTiming));
-    int least = 0, greatest = 0;
-    TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    for (int k = 0; k < 6; k++) {
-      TRY(hipStreamCreateWithPriority(&ctx->g16_streams[k], hipStreamNonBlocking, k < 2 ? greatest : k == 2 ? (least + greatest) / 2 : least));
-      TRY(hipEventCreate(&ctx->g16_begin[k]));
-      TRY(hipEventCreate(&ctx->g16_end[k]));
-    }
-  }
-  TRY(hipEventRecord(ctx->g16_ready, st));  // the scalars z || t (and their scaled copies) are ready
+namespace {
+// One device's share of a Groth16 proof: the scalar vectors (assignment z followed by the tail [r, s, -rs, 1], canonical words,
+// and their s / r multiples), the MSMs over an entry range of the device's queries, their results.  An ordinary context runs one
+// of these over the whole key; a multi-device context one per device over that device's ranges.
+struct G16Run {
+  pcdhip_ctx* ctx;            // the device's context
+  const pcdhip_g16_pk* pk;    // the device's key (whole queries, or this device's shard)
+  int cid = 0;
+  size_t m = 0, sw = 0, sb = 0, j1 = 0, j2 = 0;
+  uint32_t *z_dev = nullptr, *z_can = nullptr, *sz_can = nullptr, *rz_can = nullptr, *rs_dev = nullptr, *t1 = nullptr, *h_can = nullptr;
+  uint32_t *msm_g1 = nullptr, *msm_g2 = nullptr, *mul_scratch = nullptr, *proof_dev = nullptr;
   struct Job { const GroupEntry* ge; MsmBasesView bv; const uint32_t* sc; uint32_t n; uint32_t* out; int tslot; const uint32_t* k; uint32_t* kout; int share; };
-  const int PRODUCE = MSM_SHARE_PRODUCE, CONSUME = MSM_SHARE_CONSUME, NONE = MSM_SHARE_NONE;
-  if (!ctx->g16_share.ready) TRY(hipEventCreateWithFlags(&ctx->g16_share.ready, hipEventDisableTiming));
-  ctx->g16_share.valid = false;
-  const uint32_t mt = (uint32_t)(m + 4);
-  // automatic choice: the one-lane products cost ~5 ms (298-bit) / ~75 ms (753-bit) of latency that hides under the other
-  // MSMs of a large proof; two more MSMs cost 2 x 3.5 ms (298-bit, 2^20) / 2 x 1 ms (298-bit, 2^16) / 2 x 8 ms (753-bit, 2^16)
-  // of throughput.  Measured (folded vs chained): 28.4 vs 26.7 ms (298-bit, 2^20), 7.9 vs 8.2 ms (298-bit, 2^16),
-  // 580 vs 536 ms (753-bit, 2^20), 99 vs 120 ms (753-bit, 5 * 2^14).
-  const size_t fold_below = fe.abi_words > 12 ? (1u << 18) : (1u << 17);
-  const bool folded = ctx->g16_assembly == 1 || (ctx->g16_assembly == 0 && m + 4 <= fold_below);
   Job jobs[6];
   int nj = 0;
-  // a', b1', b2', l' are indexed alike and take the same scalars z || t: the first of them sorts, the others reuse its list.
-  // The h MSM comes last in the table: it is launched after the witness map.
-  if (folded) {
-    jobs[nj++] = {&g2, pk->b_g2_query->view(0), z_can, mt, msm_g2, 5, nullptr, nullptr, PRODUCE};             // B (heaviest: high priority)
-    jobs[nj++] = {&g1, pk->a_query->view(0), z_can, mt, slot(2), 3, nullptr, nullptr, CONSUME};               // A
-    jobs[nj++] = {&g1, pk->a_query->view(0), sz_can, mt, slot(3), 3, nullptr, nullptr, NONE};                 // s * A
-    jobs[nj++] = {&g1, pk->b_g1_query->view(0), rz_can, mt, slot(4), 4, nullptr, nullptr, NONE};              // r * B_1
-    jobs[nj++] = {&g1, pk->l_query->view(0), z_can, mt, slot(1), 2, nullptr, nullptr, CONSUME};               // l' (with -rs delta)
-  } else {
-    jobs[nj++] = {&g1, pk->a_query->view(0), z_can, mt, slot(2), 3, t1 + sw, slot(3), PRODUCE};               // A, then s * A
-    jobs[nj++] = {&g1, pk->b_g1_query->view(0), z_can, mt, slot(5), 4, t1, slot(4), CONSUME};                 // B_1, then r * B_1
-    jobs[nj++] = {&g2, pk->b_g2_query->view(0), z_can, mt, msm_g2, 5, nullptr, nullptr, CONSUME};             // B
-    jobs[nj++] = {&g1, pk->l_query->view(0), z_can, mt, slot(1), 2, nullptr, nullptr, CONSUME};               // l'
+  uint32_t* slot(int i) const { return (uint32_t*)((char*)msm_g1 + (size_t)i * j1); }
+  size_t partial_bytes() const { return 6 * j1 + j2; }  // msm_g1 (six slots) and msm_g2 are contiguous
+
+  // buffers, z -> device image and canonical words (plain, times s, times r), the scalar tails; ends with g16_ready recorded
+  int prepare(const uint64_t* z, const uint64_t* r_mont, const uint64_t* s_mont, size_t n_dom) {
+    BIND();
+    cid = pk->curve_id;
+    const FieldEntry& fe = field_entry(kCurveFr[cid]);
+    m = pk->num_vars;
+    sw = (size_t)fe.abi_words;  // words of a canonical scalar == words of an ABI element
+    sb = sw * 4;
+    hipStream_t st = ctx->stream;
+    TRY(ctx->aux_ws.ensure(AUX_Z, m * fe.words * 4));
+    TRY(ctx->aux_ws.ensure(AUX_SCAL, m * sb));
+    TRY(ctx->aux_ws.ensure(AUX_Z_CANON, 3 * (m + 4) * sb + 2 * sb));
+    TRY(ctx->aux_ws.ensure(AUX_H_CANON, n_dom * sb));
+    z_dev = (uint32_t*)ctx->aux_ws.buf[AUX_Z];
+    uint32_t* z_abi = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
+    z_can = (uint32_t*)ctx->aux_ws.buf[AUX_Z_CANON];
+    sz_can = z_can + (m + 4) * sw;
+    rz_can = sz_can + (m + 4) * sw;
+    rs_dev = rz_can + (m + 4) * sw;  // r, s (C-ABI Montgomery)
+    h_can = (uint32_t*)ctx->aux_ws.buf[AUX_H_CANON];
+    TRY(hipMemcpyAsync(z_abi, z, m * sb, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(rs_dev, r_mont, sb, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(rs_dev + sw, s_mont, sb, hipMemcpyHostToDevice, st));
+    TRY(fe.convert(st, z_abi, z_dev, (uint32_t)m, 0));
+    TRY(fe.scale_canon(st, z_dev, nullptr, z_can, (uint32_t)m, 1));
+    TRY(fe.scale_canon(st, z_dev, rs_dev + sw, sz_can, (uint32_t)m, 1));
+    TRY(fe.scale_canon(st, z_dev, rs_dev, rz_can, (uint32_t)m, 1));
+    const GroupEntry& g1 = group_entry(cid, 1);
+    const GroupEntry& g2 = group_entry(cid, 2);
+    j1 = (size_t)g1.point_words / 2 * 3 * 4;
+    j2 = (size_t)g2.point_words / 2 * 3 * 4;
+    const CurveEntry& ce = curve_entry(cid);
+    TRY(ctx->aux_ws.ensure(AUX_G16, 6 * j1 + j2 + 2 * 16 * j1 + ce.proof_abi_bytes + 256));
+    char* gbase = (char*)ctx->aux_ws.buf[AUX_G16];
+    msm_g1 = (uint32_t*)gbase;  // h, l', A, s*A, r*B_1, B_1
+    msm_g2 = (uint32_t*)(gbase + 6 * j1);
+    mul_scratch = (uint32_t*)(gbase + 6 * j1 + j2);
+    proof_dev = (uint32_t*)(gbase + 6 * j1 + j2 + 2 * 16 * j1);
+    t1 = z_can + m * sw;  // [r, s, -rs, 1] canonical
+    TRY(ce.prepare_scalars(st, rs_dev, t1, sz_can + m * sw, rz_can + m * sw));
+    if (!ctx->g16_ready) {
+      TRY(hipEventCreateWithFlags(&ctx->g16_ready, hipEventDisableTiming));
+      int least = 0, greatest = 0;
+      TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      for (int k = 0; k < 6; k++) {
+        TRY(hipStreamCreateWithPriority(&ctx->g16_streams[k], hipStreamNonBlocking, k < 2 ? greatest : k == 2 ? (least + greatest) / 2 : least));
+        TRY(hipEventCreate(&ctx->g16_begin[k]));
+        TRY(hipEventCreate(&ctx->g16_end[k]));
+      }
+    }
+    TRY(hipEventRecord(ctx->g16_ready, st));  // the scalars z || t (and their scaled copies) are ready
+    if (!ctx->g16_share.ready) TRY(hipEventCreateWithFlags(&ctx->g16_share.ready, hipEventDisableTiming));
+    ctx->g16_share.valid = false;
+    nj = 0;
+    return PCDHIP_OK;
   }
-  jobs[nj++] = {&g1, pk->h_query->view(0), h_can, (uint32_t)hl, slot(0), 1, nullptr, nullptr, NONE};          // h
-  auto launch = [&](int k, hipEvent_t after) -> int {
+  int launch(int k, hipEvent_t after) {
+    BIND();
+    const CurveEntry& ce = curve_entry(cid);
     hipStream_t sk = ctx->g16_streams[k];
     TRY(hipStreamWaitEvent(sk, after, 0));
     TRY(hipEventRecord(ctx->g16_begin[k], sk));
@@ -1022,26 +1042,52 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
     if (jobs[k].k) TRY(ce.scale_g1(sk, jobs[k].out, jobs[k].k, mul_scratch + (size_t)k * 16 * (j1 / 4), jobs[k].kout));
     TRY(hipEventRecord(ctx->g16_end[k], sk));
     return PCDHIP_OK;
-  };
-  for (int k = 0; k + 1 < nj; k++) { rc = launch(k, ctx->g16_ready); if (rc) return rc; }
-  // ---- K1: h, on the context's stream, while the MSMs above run
-  if (A && B && C) { TRY(hipStreamSynchronize(st)); rc = upload_three(ctx, A, B, C, fe, m, mats); if (rc) return rc; }  // (staging slot AUX_SCAL is reused)
-  else for (int k = 0; k < 3; k++) mats[k] = {pk->rp[k], pk->col[k], pk->coeff[k], pk->rows};
-  Dom dom_used;
-  rc = witness_map_dev(ctx, fr, mats, z_dev, ni, &dom_used);
-  if (rc) return rc;
-  if (dom_used.n != dom.n) return PCDHIP_E_ARG;
-  TRY(fe.convert(st, (const uint32_t*)ctx->aux_ws.buf[AUX_A], h_can, (uint32_t)n, 2));
-  TRY(hipEventRecord(ev[1], st));
-  rc = launch(nj - 1, ev[1]);
-  if (rc) return rc;
-  for (int k = 0; k < nj; k++) TRY(hipStreamWaitEvent(st, ctx->g16_end[k], 0));
-  TRY(hipEventRecord(ev[6], st));
-  // assembly: three additions and three affine conversions (writes the proof in the C-ABI image)
-  TRY(ce.assemble(st, msm_g1, msm_g2, proof_dev));
-  TRY(hipEventRecord(ev[7], st));
-  TRY(hipMemcpyAsync(proof_out, proof_dev, ce.proof_abi_bytes, hipMemcpyDeviceToHost, st));
-  TRY(hipStreamSynchronize(st));
+  }
+  // The MSMs that take the assignment (l', A, B_1 on G1; B on G2) over the entries [lo, lo + cnt) of z || t, which are the
+  // entries [0, cnt) of this device's queries.  a', b1', b2', l' are indexed alike and take the same scalars: the first job sorts, the
+  // others reuse its list.  The two variable-base products of the assembly, s*A and r*B_1, are either one-lane products queued right
+  // behind the A / B_1 MSMs on their high-priority streams (whole-key runs only), or two more MSMs over the same bases with every
+  // scalar scaled by s / r (`folded`; the form that also adds up across devices).
+  int launch_assignment(size_t lo, size_t cnt, bool folded) {
+    const GroupEntry& g1 = group_entry(cid, 1);
+    const GroupEntry& g2 = group_entry(cid, 2);
+    const int PRODUCE = MSM_SHARE_PRODUCE, CONSUME = MSM_SHARE_CONSUME, NONE = MSM_SHARE_NONE;
+    const uint32_t n = (uint32_t)cnt;
+    const uint32_t *zc = z_can + lo * sw, *szc = sz_can + lo * sw, *rzc = rz_can + lo * sw;
+    if (folded) {
+      jobs[nj++] = {&g2, pk->b_g2_query->view(0), zc, n, msm_g2, 5, nullptr, nullptr, PRODUCE};             // B (heaviest: high priority)
+      jobs[nj++] = {&g1, pk->a_query->view(0), zc, n, slot(2), 3, nullptr, nullptr, CONSUME};               // A
+      jobs[nj++] = {&g1, pk->a_query->view(0), szc, n, slot(3), 3, nullptr, nullptr, NONE};                 // s * A
+      jobs[nj++] = {&g1, pk->b_g1_query->view(0), rzc, n, slot(4), 4, nullptr, nullptr, NONE};              // r * B_1
+      jobs[nj++] = {&g1, pk->l_query->view(0), zc, n, slot(1), 2, nullptr, nullptr, CONSUME};               // l' (with -rs delta)
+    } else {
+      jobs[nj++] = {&g1, pk->a_query->view(0), zc, n, slot(2), 3, t1 + sw, slot(3), PRODUCE};               // A, then s * A
+      jobs[nj++] = {&g1, pk->b_g1_query->view(0), zc, n, slot(5), 4, t1, slot(4), CONSUME};                 // B_1, then r * B_1
+      jobs[nj++] = {&g2, pk->b_g2_query->view(0), zc, n, msm_g2, 5, nullptr, nullptr, CONSUME};             // B
+      jobs[nj++] = {&g1, pk->l_query->view(0), zc, n, slot(1), 2, nullptr, nullptr, CONSUME};               // l'
+    }
+    for (int k = 0; k < nj; k++) { int rc = launch(k, ctx->g16_ready); if (rc) return rc; }
+    return PCDHIP_OK;
+  }
+  // the h MSM over the entries [hlo, hlo + cnt) of h (entries [0, cnt) of this device's h query), once `after` has fired
+  int launch_h(size_t hlo, size_t cnt, hipEvent_t after) {
+    const GroupEntry& g1 = group_entry(cid, 1);
+    jobs[nj] = {&g1, pk->h_query->view(0), h_can + hlo * sw, (uint32_t)cnt, slot(0), 1, nullptr, nullptr, MSM_SHARE_NONE};
+    return launch(nj++, after);
+  }
+  // the context's stream waits for every job
+  int join() {
+    BIND();
+    for (int k = 0; k < nj; k++) TRY(hipStreamWaitEvent(ctx->stream, ctx->g16_end[k], 0));
+    return PCDHIP_OK;
+  }
+};
+
+int finish_proof(pcdhip_ctx* ctx, int cid, const uint32_t* proof_dev, uint64_t* proof_out, uint8_t* inf_out) {
+  const GroupEntry& g1 = group_entry(cid, 1);
+  const GroupEntry& g2 = group_entry(cid, 2);
+  TRY(hipMemcpyAsync(proof_out, proof_dev, curve_entry(cid).proof_abi_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  TRY(hipStreamSynchronize(ctx->stream));
   if (inf_out) {
     const size_t a1 = (size_t)g1.point_abi_words * 4, a2 = (size_t)g2.point_abi_words * 4;
     const size_t offs[3] = {0, a1 / 8, (a1 + a2) / 8}, lens[3] = {a1 / 8, a2 / 8, a1 / 8};
@@ -1051,18 +1097,178 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
       inf_out[i] = (o == 0) ? 1 : 0;
     }
   }
+  return PCDHIP_OK;
+}
+
+// A proof over a key sharded across the devices of the context (BASELINE configs[4]: the merge node's MSMs on all GPUs).  Every
+// device gets z and runs the five assignment MSMs over its entry range with the two assembly products folded in (partial sums add
+// up across devices; one-lane products of partial results would not); device 0 computes h and hands each device its slice over
+// xGMI; the partial results (six G1 points and one G2 point per device) travel to device 0, one lane per MSM sums them, and the
+// ordinary assembly kernel finishes.  No host synchronisation until the proof is read back.
+int prove_sharded(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C, const uint64_t* z,
+                  const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out, uint8_t* inf_out) {
+  const size_t G = pk->shards.size();
+  if (ctx->peers.size() != G) return PCDHIP_E_ARG;
+  const int cid = pk->curve_id, fr = kCurveFr[cid];
+  const FieldEntry& fe = field_entry(fr);
+  const size_t m = pk->num_vars, ni = pk->num_inputs;
+  const pcdhip_g16_pk* pk0 = pk->shards[0];
+  uint32_t rows = 0;
+  if (A && B && C) rows = (uint32_t)A->num_rows;
+  else if (!A && !B && !C && pk0->r1cs_dev) rows = pk0->rows;
+  else return PCDHIP_E_ARG;
+  Dom dom;
+  int rc = pick_domain(fr, (size_t)rows + ni, &dom);
+  if (rc) return rc;
+  const size_t n = dom.n, hl = std::min<size_t>(pk->h_len, n);
+  BIND();
+  EventSet<3> ev;
+  TRY(ev.create());
+  TRY(hipEventRecord(ev[0], ctx->stream));
+  std::vector<G16Run> runs(G);
+  for (size_t g = 0; g < G; g++) {
+    runs[g].ctx = ctx->peers[g];
+    runs[g].pk = pk->shards[g];
+    ctx->peers[g]->msm_sort = ctx->msm_sort;
+    rc = runs[g].prepare(z, r_mont, s_mont, n);
+    if (rc) return rc;
+    rc = runs[g].launch_assignment(pk->lo[g], pk->lo[g + 1] - pk->lo[g], true);
+    if (rc) return rc;
+  }
+  // h on device 0 while the MSMs above run everywhere
+  BIND();
+  DevCsr mats[3];
+  if (A && B && C) { TRY(hipStreamSynchronize(ctx->stream)); rc = upload_three(ctx, A, B, C, fe, m, mats); if (rc) return rc; }
+  else for (int k = 0; k < 3; k++) mats[k] = {pk0->rp[k], pk0->col[k], pk0->coeff[k], pk0->rows};
+  Dom dom_used;
+  rc = witness_map_dev(ctx, fr, mats, runs[0].z_dev, ni, &dom_used);
+  if (rc) return rc;
+  if (dom_used.n != dom.n) return PCDHIP_E_ARG;
+  TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_A], runs[0].h_can, (uint32_t)n, 2));
+  TRY(hipEventRecord(ev[1], ctx->stream));
+  const size_t sw = runs[0].sw, sb = runs[0].sb;
+  for (size_t g = 0; g < G; g++) {
+    const size_t hlo = std::min(pk->hlo[g], hl), hhi = std::min(pk->hlo[g + 1], hl);
+    pcdhip_ctx* Cg = ctx->peers[g];
+    hipEvent_t after = ev[1];
+    if (g > 0) {  // this device's slice of h, device to device
+      TRY(hipSetDevice(Cg->device));
+      TRY(hipStreamWaitEvent(Cg->stream, ev[1], 0));
+      if (hhi > hlo)
+        TRY(hipMemcpyPeerAsync(runs[g].h_can + hlo * sw, Cg->device, runs[0].h_can + hlo * sw, ctx->device, (hhi - hlo) * sb, Cg->stream));
+      if (!Cg->xstream_ev) TRY(hipEventCreateWithFlags(&Cg->xstream_ev, hipEventDisableTiming));
+      TRY(hipEventRecord(Cg->xstream_ev, Cg->stream));
+      after = Cg->xstream_ev;
+    }
+    rc = runs[g].launch_h(hlo, hhi - hlo, after);
+    if (rc) return rc;
+  }
+  // partial results -> device 0
+  const size_t pb = runs[0].partial_bytes(), j1 = runs[0].j1;
+  BIND();
+  TRY(ctx->aux_ws.ensure(AUX_FB_JAC, (G + 1) * pb + 64));
+  char* gather = (char*)ctx->aux_ws.buf[AUX_FB_JAC];  // G partial blocks, then the summed block
+  for (size_t g = 0; g < G; g++) {
+    pcdhip_ctx* Cg = ctx->peers[g];
+    rc = runs[g].join();
+    if (rc) return rc;
+    TRY(hipSetDevice(Cg->device));
+    TRY(hipMemcpyPeerAsync(gather + g * pb, ctx->device, runs[g].msm_g1, Cg->device, pb, Cg->stream));
+    if (g > 0) {
+      TRY(hipEventRecord(Cg->xstream_ev, Cg->stream));
+      TRY(hipSetDevice(ctx->device));
+      TRY(hipStreamWaitEvent(ctx->stream, Cg->xstream_ev, 0));
+    }
+  }
+  BIND();
+  uint32_t* sum = (uint32_t*)(gather + G * pb);
+  TRY(group_entry(cid, 1).jac_sum_parts(ctx->stream, (const uint32_t*)gather, pb / 4, (uint32_t)G, 5, sum));               // h, l', A, s*A, r*B_1
+  TRY(group_entry(cid, 2).jac_sum_parts(ctx->stream, (const uint32_t*)(gather + 6 * j1), pb / 4, (uint32_t)G, 1, sum + 6 * j1 / 4));  // B
+  TRY(curve_entry(cid).assemble(ctx->stream, sum, sum + 6 * j1 / 4, runs[0].proof_dev));
+  TRY(hipEventRecord(ev[2], ctx->stream));
+  rc = finish_proof(ctx, cid, runs[0].proof_dev, proof_out, inf_out);
+  if (rc) return rc;
+  for (size_t g = 1; g < G; g++) { TRY(hipSetDevice(ctx->peers[g]->device)); TRY(hipStreamSynchronize(ctx->peers[g]->stream)); }
+  BIND();
+  for (int k = 0; k < 7; k++) ctx->g16_ms[k] = 0;
+  (void)hipEventElapsedTime(&ctx->g16_ms[0], ev[0], ev[1]);
+  (void)hipEventElapsedTime(&ctx->g16_ms[7], ev[0], ev[2]);
+  return PCDHIP_OK;
+}
+}  // namespace
+
+int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C,
+                         const uint64_t* z, const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out, uint8_t* inf_out) {
+  return guarded([&]() -> int {
+  if (!ctx || !pk || !z || !r_mont || !s_mont || !proof_out) return PCDHIP_E_ARG;
+  if (A && B && C) { const pcdhip_csr* ms[3] = {A, B, C}; for (int k = 0; k < 3; k++) { int v = validate_csr(ms[k], pk->num_vars); if (v) return v; } }
+  if (!pk->shards.empty()) return prove_sharded(ctx, pk, A, B, C, z, r_mont, s_mont, proof_out, inf_out);
+  if (!ctx->peers.empty() && ctx->peers.size() > 1) return PCDHIP_E_ARG;  // a whole-key handle belongs to an ordinary context
+  BIND();
+  const int cid = pk->curve_id, fr = kCurveFr[cid];
+  const FieldEntry& fe = field_entry(fr);
+  const size_t m = pk->num_vars, ni = pk->num_inputs;
+  hipStream_t st = ctx->stream;
+  EventSet<8> ev;
+  TRY(ev.create());
+  TRY(hipEventRecord(ev[0], st));
+  int rc = PCDHIP_OK;
+  uint32_t rows = 0;
+  if (A && B && C) rows = (uint32_t)A->num_rows;
+  else if (!A && !B && !C && pk->r1cs_dev) rows = pk->rows;
+  else return PCDHIP_E_ARG;
+  Dom dom;
+  rc = pick_domain(fr, (size_t)rows + ni, &dom);
+  if (rc) return rc;
+  const size_t n = dom.n;
+  // ---- K3/K4/K5 first: the four MSMs that take the assignment (l', A, B_1 on G1; B on G2) do not need h, so they are
+  // launched before the witness map and run concurrently with it; the h MSM follows the witness map.  Results stay on the
+  // device (device image).
+  G16Run run;
+  run.ctx = ctx; run.pk = pk;
+  rc = run.prepare(z, r_mont, s_mont, n);
+  if (rc) return rc;
+  // automatic choice: the one-lane products cost ~5 ms (298-bit) / ~75 ms (753-bit) of latency that hides under the other
+  // MSMs of a large proof; two more MSMs cost 2 x 3.5 ms (298-bit, 2^20) / 2 x 1 ms (298-bit, 2^16) / 2 x 8 ms (753-bit, 2^16)
+  // of throughput.  Measured (folded vs chained): 28.4 vs 26.7 ms (298-bit, 2^20), 7.9 vs 8.2 ms (298-bit, 2^16),
+  // 580 vs 536 ms (753-bit, 2^20), 99 vs 120 ms (753-bit, 5 * 2^14).
+  const size_t fold_below = fe.abi_words > 12 ? (1u << 18) : (1u << 17);
+  const bool folded = ctx->g16_assembly == 1 || (ctx->g16_assembly == 0 && m + 4 <= fold_below);
+  rc = run.launch_assignment(0, m + 4, folded);
+  if (rc) return rc;
+  // ---- K1: h, on the context's stream, while the MSMs above run
+  DevCsr mats[3];
+  if (A && B && C) { TRY(hipStreamSynchronize(st)); rc = upload_three(ctx, A, B, C, fe, m, mats); if (rc) return rc; }  // (staging slot AUX_SCAL is reused)
+  else for (int k = 0; k < 3; k++) mats[k] = {pk->rp[k], pk->col[k], pk->coeff[k], pk->rows};
+  Dom dom_used;
+  rc = witness_map_dev(ctx, fr, mats, run.z_dev, ni, &dom_used);
+  if (rc) return rc;
+  if (dom_used.n != dom.n) return PCDHIP_E_ARG;
+  TRY(fe.convert(st, (const uint32_t*)ctx->aux_ws.buf[AUX_A], run.h_can, (uint32_t)n, 2));
+  TRY(hipEventRecord(ev[1], st));
+  rc = run.launch_h(0, std::min<size_t>(pk->h_query->n, n), ev[1]);
+  if (rc) return rc;
+  rc = run.join();
+  if (rc) return rc;
+  TRY(hipEventRecord(ev[6], st));
+  // assembly: three additions and three affine conversions (writes the proof in the C-ABI image)
+  TRY(curve_entry(cid).assemble(st, run.msm_g1, run.msm_g2, run.proof_dev));
+  TRY(hipEventRecord(ev[7], st));
+  rc = finish_proof(ctx, cid, run.proof_dev, proof_out, inf_out);
+  if (rc) return rc;
   // [witness_map, msm_h, msm_l, msm_a (A and s*A), msm_b_g1 (B_1 and r*B_1), msm_b_g2 (each on its own stream: they
   //  overlap), assembly, total]
   (void)hipEventElapsedTime(&ctx->g16_ms[0], ev[0], ev[1]);
   for (int k = 1; k <= 5; k++) ctx->g16_ms[k] = 0;
-  for (int k = 0; k < nj; k++) {
+  for (int k = 0; k < run.nj; k++) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->g16_begin[k], ctx->g16_end[k]);
-    ctx->g16_ms[jobs[k].tslot] = std::max(ctx->g16_ms[jobs[k].tslot], ms);
+    ctx->g16_ms[run.jobs[k].tslot] = std::max(ctx->g16_ms[run.jobs[k].tslot], ms);
   }
   (void)hipEventElapsedTime(&ctx->g16_ms[6], ev[6], ev[7]);
   (void)hipEventElapsedTime(&ctx->g16_ms[7], ev[0], ev[7]);
   return PCDHIP_OK;
+  });
 }
 // ------------------------------------------------------------------------------------------------ fixed-base batches, setup
 namespace {
@@ -1294,111 +1500,264 @@ int pcdhip_multi_pairing(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, c
   return pairing_groups(ctx, curve_id, g1_xy, g1_inf, g2_xy, g2_inf, 1, n_pairs, gt_out);
 }
 
+// ---- prepared verifying key (ark-groth16 `prepare_verifying_key` / `SNARK::process_vk`; reference call sites
+// src/ec_cycle_pcd/mod.rs:71,371,445,495,553) and the verifications that use it
+}  // extern "C"
+
+struct pcdhip_pvk {
+  int curve_id = 0;
+  size_t num_inputs = 0;
+  std::vector<uint64_t> alpha, beta, neg_gamma, neg_delta, gamma_abc, alpha_beta /* e(alpha, beta) */, gt_one;
+  std::vector<uint8_t> gamma_abc_inf;
+  pcdhip_bases* abc = nullptr;  // gamma_abc_g1 resident (no precomputed copies: the MSMs over it are tiny)
+};
+
+namespace {
+// y -> -y of n affine points in the C-ABI image, on the host (the library's own host-callable field templates)
+template <class FQ>
+void neg_y_words(uint64_t* xy, size_t coeffs_per_coord) {
+  typedef Fp<FQ, false> B;
+  uint32_t* y = (uint32_t*)xy + coeffs_per_coord * B::ABI_WORDS;
+  for (size_t c = 0; c < coeffs_per_coord; c++) B::from_abi(y + c * B::ABI_WORDS).neg().to_abi(y + c * B::ABI_WORDS);
+}
+void negate_point(int curve_id, int group_id, uint64_t* xy) {
+  const size_t deg = group_id == 1 ? 1 : (size_t)kCurveG2Deg[curve_id];
+  bool zero = true;  // the point at infinity (zero coordinates) stays what it is
+  for (size_t k = 0; k < (size_t)pcdhip_point_limbs(curve_id, group_id); k++) zero = zero && xy[k] == 0;
+  if (zero) return;
+  switch (curve_id) {
+    case 0: neg_y_words<F298A>(xy, deg); break;
+    case 1: neg_y_words<F298B>(xy, deg); break;
+    case 2: neg_y_words<F753A>(xy, deg); break;
+    default: neg_y_words<F753B>(xy, deg); break;
+  }
+}
+// canonical scalars: out = sum_i a_i * b_i mod r  (b_i == nullptr: plain sum); `words` u32 words each
+template <class FR>
+void lincomb_words(const uint64_t* const* a, const uint64_t* const* b, size_t n, uint64_t* out) {
+  typedef Fp<FR, false> B;
+  B acc = B::zero();
+  for (size_t i = 0; i < n; i++) {
+    B x = B::from_canonical_words((const uint32_t*)a[i]);
+    if (b && b[i]) x = x * B::from_canonical_words((const uint32_t*)b[i]);
+    acc = acc + x;
+  }
+  acc.to_canonical_words((uint32_t*)out);
+}
+void scalar_lincomb(int fr, const uint64_t* const* a, const uint64_t* const* b, size_t n, uint64_t* out) {
+  switch (fr) {
+    case 0: lincomb_words<F298A>(a, b, n, out); break;
+    case 1: lincomb_words<F298B>(a, b, n, out); break;
+    case 2: lincomb_words<F753A>(a, b, n, out); break;
+    default: lincomb_words<F753B>(a, b, n, out); break;
+  }
+}
+// acc_i = gamma_abc[0] + sum_j x_ij gamma_abc[j] for k proofs (Jacobian C-ABI image -> affine + flags), through the resident bases
+int prepare_inputs(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_t k, const uint64_t* public_inputs, std::vector<uint64_t>* acc_a, std::vector<uint8_t>* acc_inf) {
+  const int cid = pvk->curve_id;
+  const size_t l1 = (size_t)pcdhip_point_limbs(cid, 1), sl = (size_t)kFieldLimbs[kCurveFr[cid]], ni = pvk->num_inputs;
+  std::vector<uint64_t> acc_j(k * (l1 / 2 * 3)), scal(ni * sl);
+  acc_a->assign(k * l1, 0);
+  acc_inf->assign(k, 0);
+  for (size_t i = 0; i < k; i++) {
+    std::fill(scal.begin(), scal.end(), 0);
+    scal[0] = 1;
+    if (ni > 1) memcpy(&scal[sl], public_inputs + i * (ni - 1) * sl, (ni - 1) * sl * 8);
+    int rc = pcdhip_msm(ctx, pvk->abc, 0, scal.data(), ni, &acc_j[i * (l1 / 2 * 3)]);
+    if (rc) return rc;
+  }
+  return pcdhip_to_affine(ctx, cid, 1, acc_j.data(), k, acc_a->data(), acc_inf->data());
+}
+}  // namespace
+
+extern "C" {
+
+int pcdhip_process_vk(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, const uint64_t* beta_g2, const uint64_t* gamma_g2,
+                      const uint64_t* delta_g2, const uint64_t* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs, pcdhip_pvk** out) {
+  return guarded([&]() -> int {
+  if (!ctx || !valid_curve(curve_id) || !alpha_g1 || !beta_g2 || !gamma_g2 || !delta_g2 || !gamma_abc_g1 || num_inputs < 1 || !out) return PCDHIP_E_ARG;
+  BIND();
+  *out = nullptr;
+  const size_t l1 = (size_t)pcdhip_point_limbs(curve_id, 1), l2 = (size_t)pcdhip_point_limbs(curve_id, 2);
+  const PairingEntry& pe = pairing_entry(curve_id);
+  pcdhip_pvk* pvk = new pcdhip_pvk();
+  pvk->curve_id = curve_id; pvk->num_inputs = num_inputs;
+  pvk->alpha.assign(alpha_g1, alpha_g1 + l1);
+  pvk->beta.assign(beta_g2, beta_g2 + l2);
+  pvk->neg_gamma.assign(gamma_g2, gamma_g2 + l2);
+  pvk->neg_delta.assign(delta_g2, delta_g2 + l2);
+  negate_point(curve_id, 2, pvk->neg_gamma.data());
+  negate_point(curve_id, 2, pvk->neg_delta.data());
+  pvk->gamma_abc.assign(gamma_abc_g1, gamma_abc_g1 + num_inputs * l1);
+  pvk->gamma_abc_inf.assign(num_inputs, 0);
+  if (gamma_abc_inf) pvk->gamma_abc_inf.assign(gamma_abc_inf, gamma_abc_inf + num_inputs);
+  pvk->alpha_beta.assign(pe.gt_words / 2, 0);
+  pvk->gt_one.assign(pe.gt_words / 2, 0);
+  const int saved = ctx->precompute;
+  ctx->precompute = 0;
+  int rc = bases_upload_single(ctx, curve_id, 1, gamma_abc_g1, gamma_abc_inf, num_inputs, &pvk->abc);  // (device 0 of a multi-device context)
+  ctx->precompute = saved;
+  rc = rc ? rc : pcdhip_multi_pairing(ctx, curve_id, alpha_g1, nullptr, beta_g2, nullptr, 1, pvk->alpha_beta.data());  // e(alpha, beta), once
+  rc = rc ? rc : pcdhip_multi_pairing(ctx, curve_id, nullptr, nullptr, nullptr, nullptr, 0, pvk->gt_one.data());
+  if (rc) { pcdhip_pvk_free(ctx, pvk); return rc; }
+  *out = pvk;
+  return PCDHIP_OK;
+  });
+}
+void pcdhip_pvk_free(pcdhip_ctx* ctx, pcdhip_pvk* pvk) {
+  if (!pvk) return;
+  pcdhip_bases_free(ctx, pvk->abc);
+  delete pvk;
+}
+
+// `verify_with_processed_vk` for n proofs under one key: e(A, B) e(acc, -gamma) e(C, -delta) == e(alpha, beta) -- three Miller
+// loops and one final exponentiation per proof, every Miller loop of the batch in one launch, one lane per proof for the products
+// and final exponentiations.
+int pcdhip_groth16_verify_prepared(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_t n_proofs, const uint64_t* public_inputs_canonical,
+                                   const uint64_t* proofs, const uint8_t* proofs_inf, int* ok) {
+  return guarded([&]() -> int {
+  if (!ctx || !pvk || (n_proofs && (!proofs || !ok)) || (pvk->num_inputs > 1 && n_proofs && !public_inputs_canonical) || n_proofs >= (1u << 20))
+    return PCDHIP_E_ARG;
+  if (n_proofs == 0) return PCDHIP_OK;
+  BIND();
+  const int cid = pvk->curve_id;
+  const size_t l1 = (size_t)pcdhip_point_limbs(cid, 1), l2 = (size_t)pcdhip_point_limbs(cid, 2), pl = 2 * l1 + l2, k = n_proofs;
+  std::vector<uint64_t> acc_a;
+  std::vector<uint8_t> acc_inf;
+  int rc = prepare_inputs(ctx, pvk, k, public_inputs_canonical, &acc_a, &acc_inf);
+  if (rc) return rc;
+  const size_t gw = pvk->alpha_beta.size();
+  std::vector<uint64_t> gt(k * gw), g1s(3 * k * l1), g2s(3 * k * l2);
+  std::vector<uint8_t> inf1(3 * k, 0), inf2(3 * k, 0);
+  for (size_t i = 0; i < k; i++) {
+    const uint64_t* pr = proofs + i * pl;
+    memcpy(&g1s[(3 * i) * l1], pr, l1 * 8);
+    memcpy(&g1s[(3 * i + 1) * l1], &acc_a[i * l1], l1 * 8);
+    memcpy(&g1s[(3 * i + 2) * l1], pr + l1 + l2, l1 * 8);
+    memcpy(&g2s[(3 * i) * l2], pr + l1, l2 * 8);
+    memcpy(&g2s[(3 * i + 1) * l2], pvk->neg_gamma.data(), l2 * 8);
+    memcpy(&g2s[(3 * i + 2) * l2], pvk->neg_delta.data(), l2 * 8);
+    inf1[3 * i + 1] = acc_inf[i];
+    if (proofs_inf) { inf1[3 * i] = proofs_inf[3 * i]; inf2[3 * i] = proofs_inf[3 * i + 1]; inf1[3 * i + 2] = proofs_inf[3 * i + 2]; }
+  }
+  rc = pairing_groups(ctx, cid, g1s.data(), inf1.data(), g2s.data(), inf2.data(), k, 3, gt.data());
+  if (rc) return rc;
+  for (size_t i = 0; i < k; i++) ok[i] = memcmp(&gt[i * gw], pvk->alpha_beta.data(), gw * 8) == 0 ? 1 : 0;
+  return PCDHIP_OK;
+  });
+}
+
+// All n proofs at once with ONE final exponentiation: with caller-supplied challenges rho_i (128 bits each, two
+// u64 limbs per proof; the library has no RNG) the n equations are raised to rho_i and multiplied,
+//   prod_i e(rho_i A_i, B_i) * e(sum_i rho_i acc_i, -gamma) * e(sum_i rho_i C_i, -delta) * e(-(sum_i rho_i) alpha, beta) == 1,
+// n + 3 Miller loops in one launch and one final exponentiation.  Sound up to 2^-128 over the choice of rho (a batch that contains an
+// invalid proof passes with that probability); when it reports failure, pcdhip_groth16_verify_prepared tells which proof is bad.
+int pcdhip_groth16_verify_batch_rlc(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_t n_proofs, const uint64_t* public_inputs_canonical,
+                                    const uint64_t* proofs, const uint8_t* proofs_inf, const uint64_t* rho, int* all_ok) {
+  return guarded([&]() -> int {
+  if (!ctx || !pvk || !all_ok || (n_proofs && (!proofs || !rho)) || (pvk->num_inputs > 1 && n_proofs && !public_inputs_canonical) || n_proofs >= (1u << 16))
+    return PCDHIP_E_ARG;
+  *all_ok = 1;
+  if (n_proofs == 0) return PCDHIP_OK;
+  BIND();
+  const int cid = pvk->curve_id, fr = kCurveFr[cid];
+  const size_t l1 = (size_t)pcdhip_point_limbs(cid, 1), l2 = (size_t)pcdhip_point_limbs(cid, 2), pl = 2 * l1 + l2, k = n_proofs;
+  const size_t sl = (size_t)kFieldLimbs[fr], ni = pvk->num_inputs, j1 = l1 / 2 * 3;
+  // challenges as full-width canonical scalars (zero is not a challenge)
+  std::vector<uint64_t> rw(k * sl, 0);
+  for (size_t i = 0; i < k; i++) { rw[i * sl] = rho[2 * i]; rw[i * sl + 1] = rho[2 * i + 1]; if (!(rho[2 * i] | rho[2 * i + 1])) return PCDHIP_E_ARG; }
+  // scalars of the gamma_abc combination: s_0 = sum rho_i, s_j = sum_i rho_i x_ij
+  std::vector<uint64_t> s(ni * sl, 0);
+  std::vector<const uint64_t*> pa(k), pb(k);
+  for (size_t i = 0; i < k; i++) pa[i] = &rw[i * sl];
+  scalar_lincomb(fr, pa.data(), nullptr, k, &s[0]);
+  for (size_t j = 1; j < ni; j++) {
+    for (size_t i = 0; i < k; i++) pb[i] = public_inputs_canonical + (i * (ni - 1) + (j - 1)) * sl;
+    scalar_lincomb(fr, pa.data(), pb.data(), k, &s[j * sl]);
+  }
+  std::vector<uint64_t> sacc_j(j1), sacc(l1);
+  uint8_t sacc_inf = 0;
+  int rc = pcdhip_msm(ctx, pvk->abc, 0, s.data(), ni, sacc_j.data());
+  rc = rc ? rc : pcdhip_to_affine(ctx, cid, 1, sacc_j.data(), 1, sacc.data(), &sacc_inf);
+  if (rc) return rc;
+  // rho_i A_i, rho_i C_i and (sum rho) alpha: 2k + 1 one-lane products in one launch
+  const size_t np = 2 * k + 1;
+  std::vector<uint64_t> pts(np * l1), ks(np * sl), prod(np * j1);
+  for (size_t i = 0; i < k; i++) {
+    const uint64_t* pr = proofs + i * pl;
+    memcpy(&pts[i * l1], pr, l1 * 8);
+    memcpy(&pts[(k + i) * l1], pr + l1 + l2, l1 * 8);
+    if (proofs_inf && proofs_inf[3 * i]) memset(&pts[i * l1], 0, l1 * 8);
+    if (proofs_inf && proofs_inf[3 * i + 2]) memset(&pts[(k + i) * l1], 0, l1 * 8);
+    memcpy(&ks[i * sl], &rw[i * sl], sl * 8);
+    memcpy(&ks[(k + i) * sl], &rw[i * sl], sl * 8);
+  }
+  memcpy(&pts[2 * k * l1], pvk->alpha.data(), l1 * 8);
+  memcpy(&ks[2 * k * sl], &s[0], sl * 8);
+  {
+    const size_t in_b = np * l1 * 8, k_b = np * sl * 8, out_b = np * j1 * 8;
+    TRY(ctx->aux_ws.ensure(AUX_MISC, in_b + k_b + out_b + 64));
+    char* d = (char*)ctx->aux_ws.buf[AUX_MISC];
+    TRY(hipMemcpyAsync(d, pts.data(), in_b, hipMemcpyHostToDevice, ctx->stream));
+    TRY(hipMemcpyAsync(d + in_b, ks.data(), k_b, hipMemcpyHostToDevice, ctx->stream));
+    TRY(g1_scale_entry(cid)(ctx->stream, (const uint32_t*)d, (const uint32_t*)(d + in_b), (uint32_t)(sl * 2), (uint32_t)np, (uint32_t*)(d + in_b + k_b)));
+    TRY(hipMemcpyAsync(prod.data(), d + in_b + k_b, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(hipStreamSynchronize(ctx->stream));
+  }
+  std::vector<uint64_t> sc_j(j1), ra(k * l1), sc(l1), sal(l1);
+  std::vector<uint8_t> ra_inf(k, 0);
+  uint8_t sc_inf = 0, sal_inf = 0;
+  rc = pcdhip_points_sum(ctx, cid, 1, &prod[k * j1], k, sc_j.data());
+  rc = rc ? rc : pcdhip_to_affine(ctx, cid, 1, sc_j.data(), 1, sc.data(), &sc_inf);
+  rc = rc ? rc : pcdhip_to_affine(ctx, cid, 1, prod.data(), k, ra.data(), ra_inf.data());
+  rc = rc ? rc : pcdhip_to_affine(ctx, cid, 1, &prod[2 * k * j1], 1, sal.data(), &sal_inf);
+  if (rc) return rc;
+  negate_point(cid, 1, sal.data());
+  // the k + 3 pairs of the single product
+  const size_t nq = k + 3;
+  std::vector<uint64_t> g1s(nq * l1), g2s(nq * l2), gt(pvk->gt_one.size());
+  std::vector<uint8_t> inf1(nq, 0), inf2(nq, 0);
+  for (size_t i = 0; i < k; i++) {
+    memcpy(&g1s[i * l1], &ra[i * l1], l1 * 8);
+    memcpy(&g2s[i * l2], proofs + i * pl + l1, l2 * 8);
+    inf1[i] = ra_inf[i];
+    if (proofs_inf) inf2[i] = proofs_inf[3 * i + 1];
+  }
+  memcpy(&g1s[k * l1], sacc.data(), l1 * 8);       memcpy(&g2s[k * l2], pvk->neg_gamma.data(), l2 * 8);       inf1[k] = sacc_inf;
+  memcpy(&g1s[(k + 1) * l1], sc.data(), l1 * 8);   memcpy(&g2s[(k + 1) * l2], pvk->neg_delta.data(), l2 * 8);   inf1[k + 1] = sc_inf;
+  memcpy(&g1s[(k + 2) * l1], sal.data(), l1 * 8);  memcpy(&g2s[(k + 2) * l2], pvk->beta.data(), l2 * 8);        inf1[k + 2] = sal_inf;
+  rc = pairing_groups(ctx, cid, g1s.data(), inf1.data(), g2s.data(), inf2.data(), 1, nq, gt.data());
+  if (rc) return rc;
+  *all_ok = memcmp(gt.data(), pvk->gt_one.data(), gt.size() * 8) == 0 ? 1 : 0;
+  return PCDHIP_OK;
+  });
+}
+
+// ark-groth16 `Groth16::verify` for n proofs under one key (reference call site mod.rs:239, once per prior message of a merge node):
+// process_vk once, then the prepared verification.  Deterministic: ok[i] per proof.
 int pcdhip_groth16_verify_batch(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, const uint64_t* beta_g2, const uint64_t* gamma_g2,
                                 const uint64_t* delta_g2, const uint64_t* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs,
                                 size_t n_proofs, const uint64_t* public_inputs_canonical, const uint64_t* proofs, const uint8_t* proofs_inf,
                                 int* ok) {
-  return guarded([&]() -> int {
   if (!ctx || !valid_curve(curve_id) || !alpha_g1 || !beta_g2 || !gamma_g2 || !delta_g2 || !gamma_abc_g1 || num_inputs < 1 ||
       (num_inputs > 1 && n_proofs && !public_inputs_canonical) || (n_proofs && (!proofs || !ok)) || n_proofs >= (1u << 20))
     return PCDHIP_E_ARG;
   if (n_proofs == 0) return PCDHIP_OK;
-  BIND();
-  const size_t l1 = (size_t)pcdhip_point_limbs(curve_id, 1), l2 = (size_t)pcdhip_point_limbs(curve_id, 2);
-  const int fr = kCurveFr[curve_id];
-  const size_t sl = (size_t)kFieldLimbs[fr], pl = 2 * l1 + l2;
-  const size_t k = n_proofs;
-  // acc_i = gamma_abc[0] + sum_j x_ij gamma_abc[j]: small MSMs over the same bases (scalars 1, x_i1, ...)
-  const int saved = ctx->precompute;
-  ctx->precompute = 0;
-  pcdhip_bases* gb = nullptr;
-  int rc = pcdhip_bases_upload(ctx, curve_id, 1, gamma_abc_g1, gamma_abc_inf, num_inputs, &gb);
-  ctx->precompute = saved;
+  pcdhip_pvk* pvk = nullptr;
+  int rc = pcdhip_process_vk(ctx, curve_id, alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1, gamma_abc_inf, num_inputs, &pvk);
   if (rc) return rc;
-  std::vector<uint64_t> acc_j(k * (l1 / 2 * 3)), acc_a(k * l1), scal(num_inputs * sl);
-  std::vector<uint8_t> acc_inf(k, 0);
-  for (size_t i = 0; i < k && !rc; i++) {
-    std::fill(scal.begin(), scal.end(), 0);
-    scal[0] = 1;
-    if (num_inputs > 1) memcpy(&scal[sl], public_inputs_canonical + i * (num_inputs - 1) * sl, (num_inputs - 1) * sl * 8);
-    rc = pcdhip_msm(ctx, gb, 0, scal.data(), num_inputs, &acc_j[i * (l1 / 2 * 3)]);
-  }
-  pcdhip_bases_free(ctx, gb);
-  if (rc) return rc;
-  rc = pcdhip_to_affine(ctx, curve_id, 1, acc_j.data(), k, acc_a.data(), acc_inf.data());
-  if (rc) return rc;
-  // e(A_i, B_i) == e(alpha, beta) e(acc_i, gamma) e(C_i, delta): every Miller loop of the batch in one launch, one lane
-  // per proof for the products and final exponentiations
-  const PairingEntry& pe = pairing_entry(curve_id);
-  const size_t gw = (size_t)pe.gt_words / 2;
-  std::vector<uint64_t> lhs(k * gw), rhs(k * gw), g1s(3 * k * l1), g2s(3 * k * l2), a1(k * l1), b2(k * l2);
-  std::vector<uint8_t> inf1(3 * k, 0), infA(k, 0), infB(k, 0);
-  for (size_t i = 0; i < k; i++) {
-    const uint64_t* pr = proofs + i * pl;
-    memcpy(&a1[i * l1], pr, l1 * 8);
-    memcpy(&b2[i * l2], pr + l1, l2 * 8);
-    memcpy(&g1s[(3 * i) * l1], alpha_g1, l1 * 8);
-    memcpy(&g1s[(3 * i + 1) * l1], &acc_a[i * l1], l1 * 8);
-    memcpy(&g1s[(3 * i + 2) * l1], pr + l1 + l2, l1 * 8);
-    memcpy(&g2s[(3 * i) * l2], beta_g2, l2 * 8);
-    memcpy(&g2s[(3 * i + 1) * l2], gamma_g2, l2 * 8);
-    memcpy(&g2s[(3 * i + 2) * l2], delta_g2, l2 * 8);
-    inf1[3 * i + 1] = acc_inf[i];
-    if (proofs_inf) { infA[i] = proofs_inf[3 * i]; infB[i] = proofs_inf[3 * i + 1]; inf1[3 * i + 2] = proofs_inf[3 * i + 2]; }
-  }
-  rc = pairing_groups(ctx, curve_id, a1.data(), infA.data(), b2.data(), infB.data(), k, 1, lhs.data());
-  if (rc) return rc;
-  rc = pairing_groups(ctx, curve_id, g1s.data(), inf1.data(), g2s.data(), nullptr, k, 3, rhs.data());
-  if (rc) return rc;
-  for (size_t i = 0; i < k; i++) ok[i] = memcmp(&lhs[i * gw], &rhs[i * gw], gw * 8) == 0 ? 1 : 0;
-  return PCDHIP_OK;
-  });
+  rc = pcdhip_groth16_verify_prepared(ctx, pvk, n_proofs, public_inputs_canonical, proofs, proofs_inf, ok);
+  pcdhip_pvk_free(ctx, pvk);
+  return rc;
 }
 
 int pcdhip_groth16_verify(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, const uint64_t* beta_g2, const uint64_t* gamma_g2,
                           const uint64_t* delta_g2, const uint64_t* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs,
                           const uint64_t* public_inputs_canonical, const uint64_t* proof, const uint8_t* proof_inf, int* ok) {
-  return guarded([&]() -> int {
-  if (!ctx || !valid_curve(curve_id) || !alpha_g1 || !beta_g2 || !gamma_g2 || !delta_g2 || !gamma_abc_g1 || num_inputs < 1 ||
-      (num_inputs > 1 && !public_inputs_canonical) || !proof || !ok)
-    return PCDHIP_E_ARG;
-  BIND();
+  if (!proof || !ok) return PCDHIP_E_ARG;
   *ok = 0;
-  const size_t l1 = (size_t)pcdhip_point_limbs(curve_id, 1), l2 = (size_t)pcdhip_point_limbs(curve_id, 2);
-  const int fr = kCurveFr[curve_id];
-  const size_t sl = (size_t)kFieldLimbs[fr];
-  // acc = gamma_abc[0] + sum_i x_i gamma_abc[i]   (a small MSM through the ordinary path, scalars 1, x_1, ...)
-  std::vector<uint64_t> scal(num_inputs * sl, 0);
-  scal[0] = 1;
-  for (size_t i = 1; i < num_inputs; i++) memcpy(&scal[i * sl], public_inputs_canonical + (i - 1) * sl, sl * 8);
-  const int saved = ctx->precompute;
-  ctx->precompute = 0;
-  pcdhip_bases* gb = nullptr;
-  int rc = pcdhip_bases_upload(ctx, curve_id, 1, gamma_abc_g1, gamma_abc_inf, num_inputs, &gb);
-  ctx->precompute = saved;
-  if (rc) return rc;
-  std::vector<uint64_t> acc_j(l1 / 2 * 3), acc_a(l1);
-  uint8_t acc_inf = 0;
-  rc = pcdhip_msm(ctx, gb, 0, scal.data(), num_inputs, acc_j.data());
-  pcdhip_bases_free(ctx, gb);
-  if (rc) return rc;
-  rc = pcdhip_to_affine(ctx, curve_id, 1, acc_j.data(), 1, acc_a.data(), &acc_inf);
-  if (rc) return rc;
-  // e(A, B) == e(alpha, beta) e(acc, gamma) e(C, delta)
-  const PairingEntry& pe = pairing_entry(curve_id);
-  std::vector<uint64_t> lhs(pe.gt_words / 2), rhs(pe.gt_words / 2);
-  uint8_t inf1[3] = {0, acc_inf, (uint8_t)(proof_inf ? proof_inf[2] : 0)};
-  uint8_t infA = proof_inf ? proof_inf[0] : 0, infB = proof_inf ? proof_inf[1] : 0;
-  rc = pcdhip_multi_pairing(ctx, curve_id, proof, &infA, proof + l1, &infB, 1, lhs.data());
-  if (rc) return rc;
-  std::vector<uint64_t> g1s(3 * l1), g2s(3 * l2);
-  memcpy(&g1s[0], alpha_g1, l1 * 8); memcpy(&g1s[l1], acc_a.data(), l1 * 8); memcpy(&g1s[2 * l1], proof + l1 + l2, l1 * 8);
-  memcpy(&g2s[0], beta_g2, l2 * 8); memcpy(&g2s[l2], gamma_g2, l2 * 8); memcpy(&g2s[2 * l2], delta_g2, l2 * 8);
-  rc = pcdhip_multi_pairing(ctx, curve_id, g1s.data(), inf1, g2s.data(), nullptr, 3, rhs.data());
-  if (rc) return rc;
-  *ok = (lhs == rhs) ? 1 : 0;
-  return PCDHIP_OK;
-  });
+  return pcdhip_groth16_verify_batch(ctx, curve_id, alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1, gamma_abc_inf, num_inputs, 1,
+                                     public_inputs_canonical, proof, proof_inf, ok);
 }
 
 int pcdhip_groth16_last_timings(pcdhip_ctx* ctx, float out_ms[8]) {

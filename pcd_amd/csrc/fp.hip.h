@@ -583,6 +583,8 @@ struct Fp2S {
   PCD_DEV Fp2S sqr() const { return *this * *this; }
   PCD_DEV static Fp2S load(const uint32_t* p) { return {F::load(p + parity() * F::WORDS)}; }
   PCD_DEV void store(uint32_t* p) const { c.store(p + parity() * F::WORDS); }
+  PCD_DEV static Fp2S from_abi(const uint32_t* w) { return {F::from_abi(w + parity() * F::ABI_WORDS)}; }
+  PCD_DEV void to_abi(uint32_t* w) const { c.to_abi(w + parity() * F::ABI_WORDS); }
 };
 
 // F[u]/(u^3 - NR)   (ark-ff Fp3; G2 coordinates of MNT6)
@@ -717,6 +719,8 @@ struct Fp3S {
   PCD_DEV Fp3S mul_by_au2(unsigned a) const { return {from_lane(c, lane_next()).mul_small_var(role() < 2 ? a * NR : a)}; }
   PCD_DEV static Fp3S load(const uint32_t* p) { return {F::load(p + role() * F::WORDS)}; }
   PCD_DEV void store(uint32_t* p) const { c.store(p + role() * F::WORDS); }
+  PCD_DEV static Fp3S from_abi(const uint32_t* w) { return {F::from_abi(w + role() * F::ABI_WORDS)}; }
+  PCD_DEV void to_abi(uint32_t* w) const { c.to_abi(w + role() * F::ABI_WORDS); }
 };
 
 }  // namespace pcd

@@ -29,24 +29,34 @@ namespace {
 
 typedef typename GT::F F;
 
+// the point sums run in the lane-split form of the group (see MsmItems): per-lane scratch and latency shrink with it
+typedef MsmItems<GT> IT;
+typedef typename IT::GA GA;
+typedef typename GA::F FA;
+
 // host-facing utilities: inputs and outputs in the C-ABI image
 __global__ void __launch_bounds__(64) points_sum_kernel(const uint32_t* __restrict__ in_abi, uint32_t n, uint32_t* __restrict__ scratch,
                                                         uint32_t* __restrict__ out_abi) {
-  // one wave: strided partial sums per lane, then a tree through `scratch` (64 Jacobian points, device image)
+  // one workgroup: strided partial sums per item, then a tree through `scratch` (64 Jacobian points, device image)
   if (blockIdx.x != 0) return;
-  Jac<F> acc = Jac<F>::infinity();
-  for (uint32_t i = threadIdx.x; i < n; i += 64) acc = EC<GT>::add(acc, Jac<F>::from_abi(in_abi + (size_t)i * Jac<F>::ABI_WORDS));
-  acc.store(scratch + (size_t)threadIdx.x * Jac<F>::WORDS);
+  constexpr uint32_t PW = IT::PER_WAVE;
+  const bool live = !IT::idle();
+  const uint32_t it = IT::local();
+  Jac<FA> acc = Jac<FA>::infinity();
+  if (live) {
+    for (uint32_t i = it; i < n; i += PW) acc = EC<GA>::add(acc, Jac<FA>::from_abi(in_abi + (size_t)i * Jac<F>::ABI_WORDS));
+    acc.store(scratch + (size_t)it * Jac<F>::WORDS);
+  }
   __syncthreads();
-  for (int s = 32; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s && threadIdx.x + s < n) {  // (lanes >= n hold the identity)
-      acc = EC<GT>::add(acc, Jac<F>::load(scratch + (size_t)(threadIdx.x + s) * Jac<F>::WORDS));
-      acc.store(scratch + (size_t)threadIdx.x * Jac<F>::WORDS);
+  for (uint32_t s = 32; s > 0; s >>= 1) {
+    if (live && it < s && it + s < PW && it + s < n) {  // (items >= n hold the identity)
+      acc = EC<GA>::add(acc, Jac<FA>::load(scratch + (size_t)(it + s) * Jac<F>::WORDS));
+      acc.store(scratch + (size_t)it * Jac<F>::WORDS);
     }
     __syncthreads();
   }
-  if (threadIdx.x != 0) return;
-  if (acc.is_inf()) acc = Jac<F>::infinity();
+  if (!live || it != 0) return;
+  if (acc.is_inf()) acc = Jac<FA>::infinity();
   acc.to_abi(out_abi);
 }
 __global__ void __launch_bounds__(64) to_affine_kernel(const uint32_t* __restrict__ in_abi, uint32_t n, uint32_t* __restrict__ out_abi) {
@@ -58,15 +68,16 @@ __global__ void __launch_bounds__(64) to_affine_kernel(const uint32_t* __restric
 
 __global__ void __launch_bounds__(64) jac_sum_parts_kernel(const uint32_t* __restrict__ in, size_t part_stride_words, uint32_t parts, uint32_t slots,
                                                            uint32_t* __restrict__ out) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;  // one lane per slot
+  if (IT::idle()) return;
+  const uint32_t s = IT::item();  // one item per slot
   if (s >= slots) return;
-  Jac<F> acc = Jac<F>::load(in + (size_t)s * Jac<F>::WORDS);
-  for (uint32_t g = 1; g < parts; g++) acc = EC<GT>::add(acc, Jac<F>::load(in + (size_t)g * part_stride_words + (size_t)s * Jac<F>::WORDS));
+  Jac<FA> acc = Jac<FA>::load(in + (size_t)s * Jac<F>::WORDS);
+  for (uint32_t g = 1; g < parts; g++) acc = EC<GA>::add(acc, Jac<FA>::load(in + (size_t)g * part_stride_words + (size_t)s * Jac<F>::WORDS));
   acc.store(out + (size_t)s * Jac<F>::WORDS);
 }
 hipError_t jac_sum_parts_entry(hipStream_t st, const uint32_t* in, size_t part_stride_words, uint32_t parts, uint32_t slots, uint32_t* out) {
   if (slots == 0) return hipSuccess;
-  hipLaunchKernelGGL(jac_sum_parts_kernel, dim3((slots + 63) / 64), dim3(64), 0, st, in, part_stride_words, parts, slots, out);
+  hipLaunchKernelGGL(jac_sum_parts_kernel, dim3(IT::grid(slots)), dim3(64), 0, st, in, part_stride_words, parts, slots, out);
   return hipGetLastError();
 }
 

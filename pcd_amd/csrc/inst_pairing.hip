@@ -53,6 +53,28 @@ hipError_t multi_pairing(hipStream_t st, const uint32_t* g1_dev, const uint32_t*
   return hipGetLastError();
 }
 
+// out[i] = k_i * P_i as a Jacobian point in the C-ABI image; k_i: `kwords` canonical u32 words; P_i affine, C-ABI image ((0, 0) =
+// infinity).  One lane per product (the random-linear-combination batch verification scales each proof's A and C by a 128-bit
+// challenge: a few hundred group operations of latency next to Miller loops of tens of thousands).
+typedef typename PCT::G1 G1C;
+__global__ void __launch_bounds__(64) g1_scale_kernel(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ k, uint32_t kwords, uint32_t n,
+                                                      uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Aff<Fq> p = Aff<Fq>::from_abi(g1 + (size_t)i * A1A);
+  Jac<Fq> r = Jac<Fq>::infinity();
+  if (!p.is_inf()) {
+    const Jac<Fq> pj = {p.x, p.y, Fq::one()};
+    r = EC<G1C>::mul(pj, k + (size_t)i * kwords, (int)kwords);
+  }
+  if (r.is_inf()) r = Jac<Fq>::infinity();
+  r.to_abi(out + (size_t)i * Jac<Fq>::ABI_WORDS);
+}
+hipError_t g1_scale(hipStream_t st, const uint32_t* g1_dev, const uint32_t* k_dev, uint32_t kwords, uint32_t n, uint32_t* out_dev) {
+  if (n) hipLaunchKernelGGL(g1_scale_kernel, dim3((n + 63) / 64), dim3(64), 0, st, g1_dev, k_dev, kwords, n, out_dev);
+  return hipGetLastError();
+}
+
 }  // namespace
 
 #define PCD_CAT_(a, b) a##b
@@ -61,5 +83,7 @@ const PairingEntry* PCD_CAT(pcd_pairing_entry_, PCD_CURVE_IDX)() {
   static const PairingEntry e = {GWA, GW, multi_pairing};
   return &e;
 }
+typedef hipError_t (*G1ScaleFn)(hipStream_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*);
+G1ScaleFn PCD_CAT(pcd_g1_scale_entry_, PCD_CURVE_IDX)() { return g1_scale; }
 
 }  // namespace pcd

@@ -588,14 +588,30 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
   else acc.flush(buckets + (size_t)cur.key * Jac<F>::WORDS);
 }
 
+// Work-item indexing of the kernels behind the accumulation (pieces, bucket reduction, window combine).  They compute in the
+// lane-split form of the group too: an Fq2 / Fq3 point operation is shared by 2 / 3 adjacent lanes, which divides the latency of
+// these latency-bound levels and the per-lane scratch footprint (9.9 KB per lane for the unsplit Fq3-753 addition: enough to
+// exhaust the queues' scratch reservations once a few contexts are alive) by the same factor.  A 64-lane workgroup holds
+// PER_WAVE items; the lanes of an item follow the same control flow (decisions depend on the item only).
+template <class G>
+struct MsmItems {
+  typedef typename SplitOf<G>::type GA;
+  static constexpr uint32_t LANES = SplitOf<G>::LANES, PER_WAVE = 64 / LANES;
+  PCD_DEV static bool idle() { return threadIdx.x >= PER_WAVE * LANES; }
+  PCD_DEV static uint32_t local() { return threadIdx.x / LANES; }
+  PCD_DEV static uint32_t item() { return blockIdx.x * PER_WAVE + threadIdx.x / LANES; }
+  static uint32_t grid(uint32_t items) { return (items + PER_WAVE - 1) / PER_WAVE; }
+};
+
 // bucket (window 0, digit 1) += pseudo bucket of the scalars equal to one
 template <class G>
 __global__ void __launch_bounds__(64) msm_merge_ones_kernel(uint32_t* __restrict__ buckets, uint32_t ones_key) {
-  typedef typename G::F F;
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  typedef typename MsmItems<G>::GA GA;
+  typedef typename GA::F F;
+  if (blockIdx.x != 0 || threadIdx.x >= MsmItems<G>::LANES) return;
   Jac<F> a = Jac<F>::load(buckets + (size_t)1 * Jac<F>::WORDS);
   Jac<F> b = Jac<F>::load(buckets + (size_t)ones_key * Jac<F>::WORDS);
-  EC<G>::add(a, b).store(buckets + (size_t)1 * Jac<F>::WORDS);
+  EC<GA>::add(a, b).store(buckets + (size_t)1 * Jac<F>::WORDS);
 }
 
 // One lane per bucket: a bucket whose sorted run crosses chunk edges is the sum of the pieces its chunks
@@ -608,9 +624,12 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
                                                        uint32_t* __restrict__ buckets, uint32_t big_limit, uint32_t* __restrict__ big_count,
                                                        uint32_t* __restrict__ big_list /* (key, first segment, #segments) */, uint32_t big_cap,
                                                        uint32_t* __restrict__ seg_list /* (t_lo, t_hi, t_last) */, uint32_t seg_len) {
-  typedef typename G::F F;
-  typedef EC<G> E;
-  uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+  typedef typename MsmItems<G>::GA GA;
+  typedef typename GA::F F;
+  typedef EC<GA> E;
+  if (MsmItems<G>::idle()) return;
+  const bool lead = threadIdx.x % MsmItems<G>::LANES == 0;  // one lane of the item does the list bookkeeping
+  uint32_t key = MsmItems<G>::item();
   if (key >= nkeys) return;
   uint32_t lo = off[key], hi = off[key + 1];
   if (hi == lo) {  // empty bucket: nobody else writes it, and the identity is Z = 0 (X, Y are never looked at then)
@@ -619,10 +638,11 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
   }
   uint32_t t0 = lo / chunk, t1 = (hi - 1) / chunk;
   if (t1 == t0) {  // the whole run lies inside one chunk: msm_accumulate wrote the bucket itself (unreduced for the lazy groups)
-    if (MsmStored<G>::NEEDS_FIXUP) MsmStored<G>::load(buckets + (size_t)key * Jac<F>::WORDS).store(buckets + (size_t)key * Jac<F>::WORDS);
+    if (MsmStored<GA>::NEEDS_FIXUP) MsmStored<GA>::load(buckets + (size_t)key * Jac<F>::WORDS).store(buckets + (size_t)key * Jac<F>::WORDS);
     return;
   }
   if (t1 - t0 + 1 > big_limit) {  // big bucket: its pieces are cut into segments of seg_len, one wave each
+    if (!lead) return;
     uint32_t nseg = (t1 - t0 + seg_len) / seg_len;
     uint32_t slot = atomicAdd(&big_count[0], 1u);
     uint32_t s0 = atomicAdd(&big_count[1], nseg);
@@ -633,47 +653,54 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
     }
     return;
   }
-  Jac<F> acc = MsmStored<G>::load(piece_last + (size_t)t0 * Jac<F>::WORDS);
-  for (uint32_t u = t0 + 1; u < t1; u++) acc = E::add(acc, MsmStored<G>::load(piece_last + (size_t)u * Jac<F>::WORDS));
-  acc = E::add(acc, MsmStored<G>::load(piece_first + (size_t)t1 * Jac<F>::WORDS));
+  Jac<F> acc = MsmStored<GA>::load(piece_last + (size_t)t0 * Jac<F>::WORDS);
+  for (uint32_t u = t0 + 1; u < t1; u++) acc = E::add(acc, MsmStored<GA>::load(piece_last + (size_t)u * Jac<F>::WORDS));
+  acc = E::add(acc, MsmStored<GA>::load(piece_first + (size_t)t1 * Jac<F>::WORDS));
   acc.store(buckets + (size_t)key * Jac<F>::WORDS);
 }
 
 // Big buckets, two levels (all counts live on the device; grid-stride loops):
-//   A: one wave per segment of <= seg_len pieces -> partial[segment]      B: one wave per big bucket sums its partials.
-// A wave sums strided pieces per lane, then a 6-level tree through global scratch.
+//   A: one workgroup per segment of <= seg_len pieces -> partial[segment]      B: one workgroup per big bucket sums its partials.
+// The items of a workgroup sum strided pieces, then a tree through global scratch.
 template <class G>
-PCD_DEV void msm_wave_tree(Jac<typename G::F> acc, uint32_t* my /* 64 points of scratch */, uint32_t* dst) {
-  typedef typename G::F F;
-  typedef EC<G> E;
-  acc.store(my + (size_t)threadIdx.x * Jac<F>::WORDS);
+PCD_DEV void msm_wave_tree(Jac<typename MsmItems<G>::GA::F> acc, uint32_t* my /* PER_WAVE points of scratch */, uint32_t* dst) {
+  typedef typename MsmItems<G>::GA GA;
+  typedef typename GA::F F;
+  typedef EC<GA> E;
+  constexpr uint32_t PW = MsmItems<G>::PER_WAVE;
+  const uint32_t it = MsmItems<G>::local();
+  const bool live = !MsmItems<G>::idle();
+  if (live) acc.store(my + (size_t)it * Jac<F>::WORDS);
   __syncthreads();
-  for (int s = 32; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-      Jac<F> o = Jac<F>::load(my + (size_t)(threadIdx.x + s) * Jac<F>::WORDS);
+  for (uint32_t s = 32; s > 0; s >>= 1) {
+    if (live && it < s && it + s < PW) {
+      Jac<F> o = Jac<F>::load(my + (size_t)(it + s) * Jac<F>::WORDS);
       acc = E::add(acc, o);
-      acc.store(my + (size_t)threadIdx.x * Jac<F>::WORDS);
+      acc.store(my + (size_t)it * Jac<F>::WORDS);
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) acc.store(dst);
+  if (live && it == 0) acc.store(dst);
   __syncthreads();
 }
 template <class G>
 __global__ void __launch_bounds__(64) msm_big_segments_kernel(const uint32_t* __restrict__ seg_list, const uint32_t* __restrict__ big_count,
                                                               const uint32_t* __restrict__ piece_first, const uint32_t* __restrict__ piece_last,
                                                               uint32_t* __restrict__ partial, uint32_t* __restrict__ scratch) {
-  typedef typename G::F F;
-  typedef EC<G> E;
+  typedef typename MsmItems<G>::GA GA;
+  typedef typename GA::F F;
+  typedef EC<GA> E;
+  constexpr uint32_t PW = MsmItems<G>::PER_WAVE;
   const uint32_t nseg = big_count[1];
   uint32_t* my = scratch + (size_t)blockIdx.x * 64 * Jac<F>::WORDS;
   for (uint32_t sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
     uint32_t lo = seg_list[3 * sg], hi = seg_list[3 * sg + 1], tlast = seg_list[3 * sg + 2];
     Jac<F> acc = Jac<F>::infinity();
-    for (uint32_t u = lo + threadIdx.x; u <= hi; u += 64) {
-      const uint32_t* src = (u == tlast) ? piece_first : piece_last;
-      acc = E::add(acc, MsmStored<G>::load(src + (size_t)u * Jac<F>::WORDS));
-    }
+    if (!MsmItems<G>::idle())
+      for (uint32_t u = lo + MsmItems<G>::local(); u <= hi; u += PW) {
+        const uint32_t* src = (u == tlast) ? piece_first : piece_last;
+        acc = E::add(acc, MsmStored<GA>::load(src + (size_t)u * Jac<F>::WORDS));
+      }
     msm_wave_tree<G>(acc, my, partial + (size_t)sg * Jac<F>::WORDS);
   }
 }
@@ -681,14 +708,17 @@ template <class G>
 __global__ void __launch_bounds__(64) msm_big_bucket_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count,
                                                             const uint32_t* __restrict__ partial, uint32_t* __restrict__ buckets,
                                                             uint32_t* __restrict__ scratch) {
-  typedef typename G::F F;
-  typedef EC<G> E;
+  typedef typename MsmItems<G>::GA GA;
+  typedef typename GA::F F;
+  typedef EC<GA> E;
+  constexpr uint32_t PW = MsmItems<G>::PER_WAVE;
   const uint32_t nbig = big_count[0];
   uint32_t* my = scratch + (size_t)blockIdx.x * 64 * Jac<F>::WORDS;
   for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
     uint32_t key = big_list[3 * b], s0 = big_list[3 * b + 1], ns = big_list[3 * b + 2];
     Jac<F> acc = Jac<F>::infinity();
-    for (uint32_t u = threadIdx.x; u < ns; u += 64) acc = E::add(acc, Jac<F>::load(partial + (size_t)(s0 + u) * Jac<F>::WORDS));
+    if (!MsmItems<G>::idle())
+      for (uint32_t u = MsmItems<G>::local(); u < ns; u += PW) acc = E::add(acc, Jac<F>::load(partial + (size_t)(s0 + u) * Jac<F>::WORDS));
     msm_wave_tree<G>(acc, my, buckets + (size_t)key * Jac<F>::WORDS);
   }
 }
@@ -702,12 +732,14 @@ __global__ void __launch_bounds__(64) msm_tail_level_kernel(const uint32_t* __re
                                                             const uint32_t* __restrict__ C_in, uint32_t mC, size_t strideC_in,
                                                             uint32_t* __restrict__ A_out, size_t strideA_out,
                                                             uint32_t* __restrict__ C_out, size_t strideC_out, int k) {
-  typedef typename G::F F;
-  typedef EC<G> E;
+  typedef typename MsmItems<G>::GA GA;
+  typedef typename GA::F F;
+  typedef EC<GA> E;
   constexpr int PW = Jac<F>::WORDS;
+  if (MsmItems<G>::idle()) return;
   uint32_t K = 1u << k;
   uint32_t JA = (mA + K - 1) >> k, JC = (mC + K - 1) >> k;
-  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t tid = MsmItems<G>::item();
   uint32_t w = blockIdx.y;
   if (tid < JA) {
     const uint32_t* A = A_in + w * strideA_in * PW;
@@ -743,11 +775,13 @@ __global__ void __launch_bounds__(64) msm_tail_pair_kernel(const uint32_t* __res
                                                            const uint32_t* __restrict__ C_in, uint32_t mC, size_t strideC_in,
                                                            uint32_t* __restrict__ A_out, size_t strideA_out,
                                                            uint32_t* __restrict__ C_out, size_t strideC_out) {
-  typedef typename G::F F;
-  typedef EC<G> E;
+  typedef typename MsmItems<G>::GA GA;
+  typedef typename GA::F F;
+  typedef EC<GA> E;
   constexpr int PW = Jac<F>::WORDS;
+  if (MsmItems<G>::idle()) return;
   const uint32_t JA = (mA + 1) >> 1, JC = (mC + 1) >> 1;
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = MsmItems<G>::item();
   const uint32_t w = blockIdx.y;
   const int role = blockIdx.z;
   if (role < 2) {
@@ -775,10 +809,11 @@ __global__ void __launch_bounds__(64) msm_tail_pair_kernel(const uint32_t* __res
 // total = sum_w 2^(c w) V_w, V_w = C[w * strideC];  plus `extra` points added at the end
 template <class G>
 __global__ void __launch_bounds__(64) msm_horner_kernel(const uint32_t* __restrict__ C, size_t strideC, int W, int c, uint32_t* __restrict__ out) {
-  typedef typename G::F F;
-  typedef EC<G> E;
+  typedef typename MsmItems<G>::GA GA;
+  typedef typename GA::F F;
+  typedef EC<GA> E;
   constexpr int PW = Jac<F>::WORDS;
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (blockIdx.x != 0 || threadIdx.x >= MsmItems<G>::LANES) return;
   Jac<F> total = Jac<F>::load(C + (size_t)(W - 1) * strideC * PW);
   for (int w = W - 2; w >= 0; w--) {
     for (int d = 0; d < c; d++) total = E::dbl(total);
@@ -1048,7 +1083,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   }
   PCD_HIP_TRY(mark(4));
   // 5. pieces
-  hipLaunchKernelGGL((msm_fixup_kernel<G>), dim3((tkeys + 63) / 64), dim3(64), 0, st, off, tkeys, pl.chunk, pfirst, plast, buckets,
+  hipLaunchKernelGGL((msm_fixup_kernel<G>), dim3(MsmItems<G>::grid(tkeys)), dim3(64), 0, st, off, tkeys, pl.chunk, pfirst, plast, buckets,
                      big_limit, big_count, big, big_cap, seg_list, seg_len);
   {
     const uint32_t big_grid = std::min<uint32_t>(seg_cap, 2048);
@@ -1086,10 +1121,10 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
       uint32_t* C_out = (uint32_t*)ws.buf[flip ? WS_C1 : WS_C0];
       uint32_t threads = JA + JC;
       if (k == 1)
-        hipLaunchKernelGGL((msm_tail_pair_kernel<G>), dim3((std::max(JA, JC) + 63) / 64, Wg, 3), dim3(64), 0, st, A_in, mA, strideA_in, C_in,
+        hipLaunchKernelGGL((msm_tail_pair_kernel<G>), dim3(MsmItems<G>::grid(std::max(JA, JC)), Wg, 3), dim3(64), 0, st, A_in, mA, strideA_in, C_in,
                            mC, strideC_in, A_out, strideAC, C_out, strideAC);
       else
-        hipLaunchKernelGGL((msm_tail_level_kernel<G>), dim3((threads + 63) / 64, Wg), dim3(64), 0, st, A_in, mA, strideA_in, C_in, mC,
+        hipLaunchKernelGGL((msm_tail_level_kernel<G>), dim3(MsmItems<G>::grid(threads), Wg), dim3(64), 0, st, A_in, mA, strideA_in, C_in, mC,
                            strideC_in, A_out, strideAC, C_out, strideAC, k);
       mA = JA ? JA - 1 : 0;
       mC = JC + JA;

@@ -156,8 +156,34 @@ def gen_pairing():
     np.savez_compressed(os.path.join(OUT, "pairing.npz"), **out)
 
 
+def gen_wire():
+    """CanonicalSerialize images (oracle/pyoracle.py serialize_*): per curve and group six points -- both signs of y, the point at
+    infinity -- compressed and uncompressed, plus one proof-shaped triple and one verifying-key-shaped tuple."""
+    rnd = random.Random(SEED + 5)
+    out = {}
+    for cid, c in enumerate(O.CURVES):
+        pts = {}
+        for g in (1, 2):
+            F, a = c.group(g)
+            gen = c.g1 if g == 1 else c.g2
+            ps = [O.ec_mul(F, a, rnd.randrange(1, 1 << 64), gen) for _ in range(3)]
+            ps = [ps[0], O.ec_neg(F, ps[0]), None, ps[1], ps[2], O.ec_neg(F, ps[2])]
+            pts[g] = ps
+            xy, inf = O.pack_points(c, g, ps)
+            out[f"c{cid}_g{g}_xy"] = xy
+            out[f"c{cid}_g{g}_inf"] = inf
+            for comp in (0, 1):
+                out[f"c{cid}_g{g}_ser{comp}"] = np.frombuffer(b"".join(O.serialize_point(c, g, P, bool(comp)) for P in ps), dtype=np.uint8)
+        proof = (pts[1][0], pts[2][3], pts[1][4])
+        vk = (pts[1][3], pts[2][0], pts[2][1], pts[2][4], [pts[1][0], pts[1][1], pts[1][5]])
+        for comp in (0, 1):
+            out[f"c{cid}_proof_ser{comp}"] = np.frombuffer(O.serialize_proof(c, proof, bool(comp)), dtype=np.uint8)
+            out[f"c{cid}_vk_ser{comp}"] = np.frombuffer(O.serialize_vk(c, *vk, compressed=bool(comp)), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "wire.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fields", "msm", "fft", "groth16", "pairing"]
+    which = sys.argv[1:] or ["fields", "msm", "fft", "groth16", "pairing", "wire"]
     for w in which:
         globals()["gen_" + w]()
     print("done")

@@ -91,6 +91,64 @@ def test_groth16_verify_batch(co, gpu_ctx, cid, nc):
     assert gpu_ctx.groth16_verify_batch(*args, np.stack(pubs)[:0], np.stack(proofs)[:0]).shape == (0,)
 
 
+@pytest.mark.parametrize("cid,nc", [(0, 300), (1, 200), (3, 40)])
+def test_process_vk_prepared_and_rlc_batch(co, gpu_ctx, cid, nc):
+    """SNARK::process_vk + verify_with_processed_vk (three Miller loops, one final exponentiation per proof, e(alpha, beta) cached) and
+    the random-linear-combination batch with ONE shared final exponentiation: accept a batch of valid proofs, reject a batch with a
+    wrong public input / a tampered proof; the prepared answers equal the plain ones and the oracle's."""
+    fr = co.CURVE_FR[cid]
+    r = co.synthetic_r1cs(fr, nc, 3, seed=161)
+    keys = co.groth16_setup(cid, r, co.gen_field(fr, 5, seed=162), nthreads=16)
+    pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
+    k = 5
+    pub = co.fp_op(fr, "to_canonical", np.ascontiguousarray(r.z[1:r.num_inputs]))
+    proofs = []
+    for i in range(k):
+        rs = co.gen_field(fr, 2, seed=170 + i)
+        proofs.append(gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])[0])
+        assert co.groth16_verify(keys, np.ascontiguousarray(r.z[1:r.num_inputs]), proofs[-1])
+    pk.free()
+    pubs = np.stack([pub] * k)
+    proofs = np.stack(proofs)
+    pvk = gpu_ctx.process_vk(cid, keys.alpha_g1, keys.beta_g2, keys.gamma_g2, keys.delta_g2, keys.gamma_abc_g1)
+    rho = np.random.default_rng(5).integers(1, 1 << 62, size=(k, 2), dtype=np.uint64)
+    try:
+        assert gpu_ctx.groth16_verify_prepared(pvk, pubs, proofs).all()
+        assert gpu_ctx.groth16_verify_batch_rlc(pvk, pubs, proofs, rho)
+        bad_pub = pubs.copy(); bad_pub[3, 0, 0] ^= 1
+        assert np.array_equal(gpu_ctx.groth16_verify_prepared(pvk, bad_pub, proofs), np.arange(k) != 3)
+        assert not gpu_ctx.groth16_verify_batch_rlc(pvk, bad_pub, proofs, rho)
+        w1 = co.point_words(cid, 1)
+        bad_pr = proofs.copy(); bad_pr[1, :w1] = keys.alpha_g1            # a valid point, wrong proof
+        assert np.array_equal(gpu_ctx.groth16_verify_prepared(pvk, pubs, bad_pr), np.arange(k) != 1)
+        assert not gpu_ctx.groth16_verify_batch_rlc(pvk, pubs, bad_pr, rho)
+        assert gpu_ctx.groth16_verify_batch_rlc(pvk, pubs[:1], proofs[:1], rho[:1])
+        with pytest.raises(Exception):
+            gpu_ctx.groth16_verify_batch_rlc(pvk, pubs, proofs, np.zeros((k, 2), dtype=np.uint64))   # zero is not a challenge
+    finally:
+        pvk.free()
+
+
+def test_proof_wire_round_trip_verifies(co, gpu_ctx):
+    """a GPU-made proof and its key leave as CanonicalSerialize bytes (compressed), come back, and still verify"""
+    from pcd_amd import capi
+    cid, fr = 1, co.CURVE_FR[1]
+    r = co.synthetic_r1cs(fr, 150, 2, seed=181)
+    keys = co.groth16_setup(cid, r, co.gen_field(fr, 5, seed=182), nthreads=8)
+    pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
+    rs = co.gen_field(fr, 2, seed=183)
+    proof, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
+    pk.free()
+    blob = capi.proof_serialize(cid, proof, inf)
+    vkb = capi.vk_serialize(cid, keys.alpha_g1, keys.beta_g2, keys.gamma_g2, keys.delta_g2, keys.gamma_abc_g1, keys.gamma_abc_inf)
+    assert len(blob) == 2 * 38 + 3 * 38                        # MNT6-298: G1 38 B, G2 over Fq3 114 B
+    proof2, inf2 = capi.proof_deserialize(cid, blob)
+    vk = capi.vk_deserialize(cid, vkb, max_inputs=16)
+    assert np.array_equal(proof2, proof) and np.array_equal(inf2, inf)
+    pub = co.fp_op(fr, "to_canonical", np.ascontiguousarray(r.z[1:r.num_inputs]))
+    assert gpu_ctx.groth16_verify(cid, vk["alpha_g1"], vk["beta_g2"], vk["gamma_g2"], vk["delta_g2"], vk["gamma_abc_g1"], pub, proof2)
+
+
 def test_kzg_prefix_commitments(co, gpu_ctx):
     """Marlin/KZG10 shape: one resident `powers_of_g`, commitments are MSMs over prefixes of it (coefficients with
     leading zeros skipped by the caller: offset), plus a hiding MSM over `powers_of_gamma_g`."""
