@@ -98,6 +98,15 @@ int pcdhip_msm(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const 
 /* Same with scalars already resident on the device (element `scalar_offset` onwards). */
 int pcdhip_msm_dev(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars,
                    size_t scalar_offset, size_t n, uint64_t* out_xyz_mont);
+/* Throughput form of pcdhip_msm_dev for a caller with several INDEPENDENT MSMs to make (the commitments of a Marlin round over one
+ * resident committer key, BASELINE configs[3]; consecutive steps of a benchmark): submit enqueues the MSM on one of the context's four
+ * side streams (own stream and workspace, round robin) and returns at once with a ticket; collect waits for that submission and
+ * returns its result (PCDHIP_E_ARG as from pcdhip_msm_dev for an unreduced scalar).  The latency-bound bucket reduction of one MSM
+ * then overlaps the sort and accumulation of the next.  At most four tickets may be outstanding (a fifth submit fails with
+ * PCDHIP_E_ARG); pcdhip_groth16_prove refuses to run while any is (it uses the same side streams).  Not for sharded bases. */
+int pcdhip_msm_submit(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset, size_t n,
+                      int* ticket);
+int pcdhip_msm_collect(pcdhip_ctx* ctx, int ticket, uint64_t* out_xyz_mont);
 /* Precomputed window-shifted copies of bases uploaded AFTER this call through this context
  * (HBM capacity traded against the serial window combine; the proving key of a PCD is fixed for the whole
  * computation, so the one-time cost amortises over every step):

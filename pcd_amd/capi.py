@@ -44,7 +44,7 @@ EXPORTS = [
     "pcdhip_strerror", "pcdhip_device_count", "pcdhip_init", "pcdhip_init_devices", "pcdhip_ctx_devices", "pcdhip_destroy", "pcdhip_sync", "pcdhip_host_alloc", "pcdhip_host_free", "pcdhip_last_hip_error",
     "pcdhip_field_limbs", "pcdhip_curve_base_field", "pcdhip_curve_scalar_field", "pcdhip_point_limbs",
     "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
-    "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config", "pcdhip_bases_info", "pcdhip_stream_wait",
+    "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config", "pcdhip_msm_submit", "pcdhip_msm_collect", "pcdhip_bases_info", "pcdhip_stream_wait",
     "pcdhip_set_precompute", "pcdhip_msm_set_sort", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
     "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
@@ -152,6 +152,19 @@ class Context:
             scalars = _u64(scalars)
             n = scalars.shape[0] if n is None else n
             self._check(lib().pcdhip_msm(self._ctx, bases._h, C.c_size_t(offset), _p(scalars), C.c_size_t(n), _p(out)))
+        return out
+
+    def msm_submit(self, bases, scalars, offset=0, n=None, scalar_offset=0):
+        """enqueue an MSM over resident scalars on a side stream -> ticket (at most four outstanding); see msm_collect"""
+        n = scalars.n - scalar_offset if n is None else n
+        t = C.c_int(-1)
+        self._check(lib().pcdhip_msm_submit(self._ctx, bases._h, C.c_size_t(offset), scalars._h, C.c_size_t(scalar_offset), C.c_size_t(n), C.byref(t)))
+        return (t.value, bases.curve, bases.group)
+
+    def msm_collect(self, ticket):
+        t, curve, group = ticket
+        out = np.zeros(3 * point_limbs(curve, group) // 2, dtype=np.uint64)
+        self._check(lib().pcdhip_msm_collect(self._ctx, t, _p(out)))
         return out
 
     def msm_partial_to_device(self, bases, scalars, out_device_ptr, offset=0, n=None):

@@ -285,6 +285,8 @@ void pcdhip_destroy(pcdhip_ctx* ctx) {
     (void)hipFree(kv.second.coset); (void)hipFree(kv.second.coset_inv_scaled);
   }
   if (ctx->xstream_ev) (void)hipEventDestroy(ctx->xstream_ev);
+  for (int k = 0; k < pcdhip_ctx::PIPE_SLOTS; k++) if (ctx->pipe_done[k]) (void)hipEventDestroy(ctx->pipe_done[k]);
+  if (ctx->pipe_host) (void)hipHostFree(ctx->pipe_host);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   (void)hipStreamDestroy(ctx->stream);
@@ -515,6 +517,75 @@ static int msm_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset,
   if (ctx->msm_ws.last_err_dev) TRY(hipMemcpyAsync(&too_wide, ctx->msm_ws.last_err_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
   return too_wide ? PCDHIP_E_ARG : PCDHIP_OK;
+}
+
+// the context's side streams (created on first use): 0 and 1 with the highest priority, 2 with the default one, 3..5 with the lowest
+static int ensure_side_streams(pcdhip_ctx* ctx) {
+  if (ctx->g16_ready) return PCDHIP_OK;
+  TRY(hipEventCreateWithFlags(&ctx->g16_ready, hipEventDisableTiming));
+  int least = 0, greatest = 0;
+  TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  for (int k = 0; k < 6; k++) {
+    TRY(hipStreamCreateWithPriority(&ctx->g16_streams[k], hipStreamNonBlocking, k < 2 ? greatest : k == 2 ? (least + greatest) / 2 : least));
+    TRY(hipEventCreate(&ctx->g16_begin[k]));
+    TRY(hipEventCreate(&ctx->g16_end[k]));
+  }
+  return PCDHIP_OK;
+}
+static bool pipe_pending(const pcdhip_ctx* ctx) {
+  for (int k = 0; k < pcdhip_ctx::PIPE_SLOTS; k++) if (ctx->pipe_busy[k]) return true;
+  return false;
+}
+
+int pcdhip_msm_submit(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset, size_t n,
+                      int* ticket) {
+  if (!ctx || !bases || !scalars || !ticket || !bases->shards.empty()) return PCDHIP_E_ARG;
+  if (offset + n > bases->n || scalar_offset + n > scalars->n || n >= (1ull << 31)) return PCDHIP_E_ARG;
+  if (scalars->field_id != kCurveFr[bases->curve_id]) return PCDHIP_E_ARG;
+  BIND();
+  int rc = ensure_side_streams(ctx);
+  if (rc) return rc;
+  int slot = -1;
+  for (int t = 0; t < pcdhip_ctx::PIPE_SLOTS; t++) {
+    const int k = (ctx->pipe_next + t) % pcdhip_ctx::PIPE_SLOTS;
+    if (!ctx->pipe_busy[k]) { slot = k; break; }
+  }
+  if (slot < 0) return PCDHIP_E_ARG;  // PIPE_SLOTS submissions are in flight: collect one first
+  ctx->pipe_next = (slot + 1) % pcdhip_ctx::PIPE_SLOTS;
+  if (!ctx->pipe_host) TRY(hipHostMalloc((void**)&ctx->pipe_host, pcdhip_ctx::PIPE_SLOTS * pcdhip_ctx::PIPE_HOST_WORDS * 8, hipHostMallocDefault));
+  if (!ctx->pipe_done[slot]) TRY(hipEventCreateWithFlags(&ctx->pipe_done[slot], hipEventDisableTiming));
+  const GroupEntry& ge = group_entry(bases->curve_id, bases->group_id);
+  const size_t jac_b = (size_t)ge.point_words / 2 * 3 * 4, jac_abi_b = (size_t)ge.point_abi_words / 2 * 3 * 4;
+  MsmWorkspace& ws = ctx->g16_ws[2 + slot];
+  hipStream_t sk = ctx->g16_streams[2 + slot];
+  TRY(ws.ensure(WS_OUT, jac_b + jac_abi_b + 64));
+  uint32_t* out_dev = (uint32_t*)ws.buf[WS_OUT];
+  uint32_t* out_abi = out_dev + jac_b / 4;
+  // ordered behind whatever the context's own stream has queued so far (uploads of the operands)
+  TRY(hipEventRecord(ctx->g16_ready, ctx->stream));
+  TRY(hipStreamWaitEvent(sk, ctx->g16_ready, 0));
+  const size_t sw = (size_t)kFieldLimbs[scalars->field_id] * 2;
+  TRY(ge.msm(ws, sk, bases->view(offset), scalars->dptr + scalar_offset * sw, (uint32_t)n, out_dev, ctx->msm_c, ctx->msm_chunk, ctx->msm_sort, nullptr,
+             nullptr, MSM_SHARE_NONE));
+  TRY(ge.jac_out(sk, out_dev, 1, out_abi));
+  uint64_t* host = ctx->pipe_host + (size_t)slot * pcdhip_ctx::PIPE_HOST_WORDS;
+  host[pcdhip_ctx::PIPE_HOST_WORDS - 1] = 0;
+  TRY(hipMemcpyAsync(host, out_abi, jac_abi_b, hipMemcpyDeviceToHost, sk));
+  if (ws.last_err_dev) TRY(hipMemcpyAsync(&host[pcdhip_ctx::PIPE_HOST_WORDS - 1], ws.last_err_dev, 4, hipMemcpyDeviceToHost, sk));
+  TRY(hipEventRecord(ctx->pipe_done[slot], sk));
+  ctx->pipe_busy[slot] = true;
+  ctx->pipe_out_bytes[slot] = jac_abi_b;
+  *ticket = slot;
+  return PCDHIP_OK;
+}
+int pcdhip_msm_collect(pcdhip_ctx* ctx, int ticket, uint64_t* out_xyz) {
+  if (!ctx || ticket < 0 || ticket >= pcdhip_ctx::PIPE_SLOTS || !ctx->pipe_busy[ticket] || !out_xyz) return PCDHIP_E_ARG;
+  BIND();
+  ctx->pipe_busy[ticket] = false;
+  TRY(hipEventSynchronize(ctx->pipe_done[ticket]));
+  const uint64_t* host = ctx->pipe_host + (size_t)ticket * pcdhip_ctx::PIPE_HOST_WORDS;
+  memcpy(out_xyz, host, ctx->pipe_out_bytes[ticket]);
+  return (uint32_t)host[pcdhip_ctx::PIPE_HOST_WORDS - 1] ? PCDHIP_E_ARG : PCDHIP_OK;
 }
 
 // MSM over bases sharded across the devices of the context: every device runs the whole pipeline on the part of [offset, offset + n)
@@ -1015,16 +1086,8 @@ struct G16Run {
     proof_dev = (uint32_t*)(gbase + 6 * j1 + j2 + 2 * 16 * j1);
     t1 = z_can + m * sw;  // [r, s, -rs, 1] canonical
     TRY(ce.prepare_scalars(st, rs_dev, t1, sz_can + m * sw, rz_can + m * sw));
-    if (!ctx->g16_ready) {
-      TRY(hipEventCreateWithFlags(&ctx->g16_ready, hipEventDisableTiming));
-      int least = 0, greatest = 0;
-      TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      for (int k = 0; k < 6; k++) {
-        TRY(hipStreamCreateWithPriority(&ctx->g16_streams[k], hipStreamNonBlocking, k < 2 ? greatest : k == 2 ? (least + greatest) / 2 : least));
-        TRY(hipEventCreate(&ctx->g16_begin[k]));
-        TRY(hipEventCreate(&ctx->g16_end[k]));
-      }
-    }
+    { int rc = ensure_side_streams(ctx); if (rc) return rc; }
+    if (pipe_pending(ctx)) return PCDHIP_E_ARG;  // submitted MSMs still own side-stream workspaces: collect them first
     TRY(hipEventRecord(ctx->g16_ready, st));  // the scalars z || t (and their scaled copies) are ready
     if (!ctx->g16_share.ready) TRY(hipEventCreateWithFlags(&ctx->g16_share.ready, hipEventDisableTiming));
     ctx->g16_share.valid = false;

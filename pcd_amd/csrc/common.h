@@ -85,6 +85,15 @@ struct pcdhip_ctx {
   float g16_ms[8] = {0};
   int g16_assembly = 0;  // s*A and r*B_1: 0 automatic, 1 folded into two extra MSMs, 2 chained one-lane products
   hipEvent_t t0 = nullptr, t1 = nullptr;
+  // pcdhip_msm_submit / collect: up to PIPE_SLOTS independent MSMs in flight, each on one of the side streams (g16_streams[2 + slot],
+  // with that stream's workspace); results land in page-locked host memory
+  static constexpr int PIPE_SLOTS = 4;
+  bool pipe_busy[PIPE_SLOTS] = {false, false, false, false};
+  hipEvent_t pipe_done[PIPE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t* pipe_host = nullptr;  // PIPE_SLOTS x PIPE_HOST_WORDS u64
+  static constexpr size_t PIPE_HOST_WORDS = 256;  // >= one Jacobian point in the C-ABI image (216 u64 for Fq3-753) + the error word
+  size_t pipe_out_bytes[PIPE_SLOTS] = {0, 0, 0, 0};
+  int pipe_next = 0;
   hipEvent_t xstream_ev = nullptr;  // pcdhip_stream_wait: ordering against a caller-owned stream (e.g. the RCCL stream)
   std::string last_hip_error;
 };

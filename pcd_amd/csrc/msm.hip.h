@@ -842,21 +842,60 @@ __global__ void __launch_bounds__(64) jac_internal_to_abi_kernel(const uint32_t*
 
 // ------------------------------------------------------------------------------------------------ precomputed bases
 // out[g * n + i] = 2^(shift * g) * P_i  (affine), g = 0 .. groups-1.  One lane per point; one-time cost at
-// key upload (the proving key of a PCD is fixed for the whole computation).
+// key upload (the proving key of a PCD is fixed for the whole computation).  The copies of one point are made in blocks of BLK: the
+// doubling chain runs on in Jacobian form and the block shares ONE field inversion (Montgomery's trick inside the lane) -- the
+// inversions, one per copy before, were five sixths of this kernel (753-bit: ~1 100 products each against ~200 for the doublings
+// between two copies; key upload of BASELINE configs[2] 20.7 s).
 template <class G>
 __global__ void __launch_bounds__(64) msm_precompute_kernel(uint32_t* __restrict__ pts, uint32_t n, int groups, int shift) {
   typedef typename G::F F;
   typedef EC<G> E;
+  constexpr int BLK = (F::Base::N > 11 || F::DEG > 1) ? 4 : 8;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   constexpr int STRIDE = MsmBaseStride<G>::value;
   Aff<F> p = Aff<F>::load(pts + (size_t)i * STRIDE);
-  Jac<F> q = p.is_inf() ? Jac<F>::infinity() : Jac<F>{p.x, p.y, F::one()};
-  for (int g = 1; g < groups; g++) {
-    for (int d = 0; d < shift; d++) q = E::dbl(q);
-    Aff<F> a = E::to_affine(q);
-    a.store(pts + ((size_t)g * n + i) * STRIDE);
-    if (!q.is_inf()) q = Jac<F>{a.x, a.y, F::one()};  // keep Z = 1: cheaper doublings, same point
+  if (p.is_inf()) {  // every copy of the identity is the identity
+    for (int g = 1; g < groups; g++) p.store(pts + ((size_t)g * n + i) * STRIDE);
+    return;
+  }
+  Jac<F> q = {p.x, p.y, F::one()};
+  for (int g0 = 1; g0 < groups; g0 += BLK) {
+    const int nb = min(BLK, groups - g0);
+    F zs[BLK], pre[BLK];
+    unsigned infm = 0;  // (a point of odd prime order never doubles to the identity; kept for robustness)
+#pragma unroll
+    for (int j = 0; j < BLK; j++) {
+      if (j < nb) {
+        for (int d = 0; d < shift; d++) q = E::dbl(q);
+        uint32_t* dst = pts + ((size_t)(g0 + j) * n + i) * STRIDE;
+        q.X.store(dst);
+        q.Y.store(dst + F::WORDS);
+        const bool inf = q.is_inf();
+        if (inf) infm |= 1u << j;
+        zs[j] = inf ? F::one() : q.Z;
+        pre[j] = j ? pre[j - 1] * zs[j] : zs[j];
+      }
+    }
+    F inv = pre[0];
+#pragma unroll
+    for (int j = 1; j < BLK; j++) if (j == nb - 1) inv = pre[j];
+    inv = inv.inv();
+    Aff<F> last = {F::zero(), F::zero()};
+#pragma unroll
+    for (int j = BLK - 1; j >= 0; j--) {
+      if (j < nb) {
+        const F zi = j ? inv * pre[j - 1] : inv;
+        inv = inv * zs[j];
+        uint32_t* dst = pts + ((size_t)(g0 + j) * n + i) * STRIDE;
+        const F zi2 = zi.sqr();
+        Aff<F> a = {F::load(dst) * zi2, F::load(dst + F::WORDS) * zi2 * zi};
+        if (infm & (1u << j)) a = {F::zero(), F::zero()};
+        a.store(dst);
+        if (j == nb - 1) last = a;
+      }
+    }
+    q = (infm >> (nb - 1)) & 1u ? Jac<F>::infinity() : Jac<F>{last.x, last.y, F::one()};  // back to Z = 1: cheaper doublings, same point
   }
 }
 template <class G>

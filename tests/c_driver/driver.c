@@ -1,0 +1,90 @@
+/* A plain-C caller of include/pcdhip.h, driving pcdhip_groth16_prove exactly as the Rust shim (rust/src/prover.rs) does: points
+ * repacked as x || y limbs plus infinity bytes, the assignment as Montgomery limbs, r then s, constraint matrices made resident
+ * first -- no Python, no ctypes between the caller and the library.  Input: a blob written by tests/test_c_driver.py
+ * (u64 header, then the arrays in the order read below); exit code 0 iff the proof equals the expected bytes and a second
+ * entry point (pcdhip_msm over the key's a_query) equals its expected point.  Test infrastructure. */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pcdhip.h"
+
+static unsigned char* blob;
+static size_t pos;
+static const void* take(size_t bytes) { const void* p = blob + pos; pos += (bytes + 7) / 8 * 8; return p; }
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: driver <blob>\n"); return 2; }
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) { perror("blob"); return 2; }
+  fseek(f, 0, SEEK_END);
+  long len = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  blob = (unsigned char*)malloc((size_t)len);
+  if (!blob || fread(blob, 1, (size_t)len, f) != (size_t)len) { fprintf(stderr, "short read\n"); return 2; }
+  fclose(f);
+  const uint64_t* h = (const uint64_t*)take(12 * 8);
+  const uint64_t curve = h[0], m = h[1], ni = h[2], dom = h[3], h_len = h[4], l_len = h[5], nc = h[6], nnz_a = h[7], nnz_b = h[8], nnz_c = h[9];
+  const size_t L = (size_t)pcdhip_field_limbs(pcdhip_curve_scalar_field((int)curve));
+  const size_t l1 = (size_t)pcdhip_point_limbs((int)curve, PCDHIP_G1), l2 = (size_t)pcdhip_point_limbs((int)curve, PCDHIP_G2);
+
+  pcdhip_g16_pk_host k;
+  memset(&k, 0, sizeof k);
+  k.curve_id = (uint32_t)curve; k.num_vars = m; k.num_inputs = ni; k.domain_size = dom; k.h_len = h_len; k.l_len = l_len;
+  k.alpha_g1 = (const uint64_t*)take(l1 * 8); k.beta_g1 = (const uint64_t*)take(l1 * 8); k.delta_g1 = (const uint64_t*)take(l1 * 8);
+  k.beta_g2 = (const uint64_t*)take(l2 * 8); k.delta_g2 = (const uint64_t*)take(l2 * 8);
+  k.a_query = (const uint64_t*)take(m * l1 * 8); k.a_inf = (const uint8_t*)take(m);
+  k.b_g1_query = (const uint64_t*)take(m * l1 * 8); k.b_g1_inf = (const uint8_t*)take(m);
+  k.b_g2_query = (const uint64_t*)take(m * l2 * 8); k.b_g2_inf = (const uint8_t*)take(m);
+  k.h_query = (const uint64_t*)take(h_len * l1 * 8); k.h_inf = (const uint8_t*)take(h_len);
+  k.l_query = (const uint64_t*)take(l_len * l1 * 8); k.l_inf = (const uint8_t*)take(l_len);
+  pcdhip_csr A, B, C;
+  const uint64_t nnz[3] = {nnz_a, nnz_b, nnz_c};
+  pcdhip_csr* ms[3] = {&A, &B, &C};
+  for (int i = 0; i < 3; i++) {
+    ms[i]->num_rows = nc;
+    ms[i]->row_ptr = (const uint64_t*)take((nc + 1) * 8);
+    ms[i]->col = (const uint32_t*)take(nnz[i] * 4);
+    ms[i]->coeff = (const uint64_t*)take(nnz[i] * L * 8);
+  }
+  const uint64_t* z = (const uint64_t*)take(m * L * 8);
+  const uint64_t* r = (const uint64_t*)take(L * 8);
+  const uint64_t* s = (const uint64_t*)take(L * 8);
+  const size_t pw = 2 * l1 + l2;
+  const uint64_t* want = (const uint64_t*)take(pw * 8);
+  const uint8_t* want_inf = (const uint8_t*)take(3);
+  const uint64_t* msm_scalars = (const uint64_t*)take(m * L * 8);
+  const uint64_t* msm_want_xy = (const uint64_t*)take(l1 * 8);
+  if (pos > (size_t)len) { fprintf(stderr, "blob too short\n"); return 2; }
+
+  pcdhip_ctx* ctx = NULL;
+  int rc = pcdhip_init(0, &ctx);
+  if (rc) { fprintf(stderr, "pcdhip_init: %s\n", pcdhip_strerror(rc)); return 3; }
+  pcdhip_g16_pk* pk = NULL;
+  rc = pcdhip_g16_pk_upload(ctx, &k, &pk);
+  if (!rc) rc = pcdhip_g16_pk_set_r1cs(ctx, pk, &A, &B, &C);
+  uint64_t* proof = (uint64_t*)calloc(pw, 8);
+  uint8_t inf[3] = {0, 0, 0};
+  if (!rc) rc = pcdhip_groth16_prove(ctx, pk, NULL, NULL, NULL, z, r, s, proof, inf);
+  if (rc) { fprintf(stderr, "prove: %s (%s)\n", pcdhip_strerror(rc), pcdhip_last_hip_error(ctx)); return 4; }
+  int bad = memcmp(proof, want, pw * 8) != 0 || memcmp(inf, want_inf, 3) != 0;
+  /* the same key material through the MSM entry point */
+  pcdhip_bases* bases = NULL;
+  uint64_t* xyz = (uint64_t*)calloc(l1 / 2 * 3, 8);
+  uint64_t* xy = (uint64_t*)calloc(l1, 8);
+  uint8_t pinf = 0;
+  rc = pcdhip_bases_upload(ctx, (int)curve, PCDHIP_G1, k.a_query, k.a_inf, m, &bases);
+  if (!rc) rc = pcdhip_msm(ctx, bases, 0, msm_scalars, m, xyz);
+  if (!rc) rc = pcdhip_to_affine(ctx, (int)curve, PCDHIP_G1, xyz, 1, xy, &pinf);
+  if (rc) { fprintf(stderr, "msm: %s\n", pcdhip_strerror(rc)); return 5; }
+  bad |= memcmp(xy, msm_want_xy, l1 * 8) != 0 || pinf != 0;
+  /* error behaviour from C: bad arguments are codes, never aborts */
+  bad |= pcdhip_msm(ctx, bases, 1, msm_scalars, m, xyz) != PCDHIP_E_ARG;
+  bad |= pcdhip_groth16_prove(ctx, pk, &A, NULL, NULL, z, r, s, proof, inf) != PCDHIP_E_ARG;
+  pcdhip_bases_free(ctx, bases);
+  pcdhip_g16_pk_free(ctx, pk);
+  pcdhip_destroy(ctx);
+  printf(bad ? "MISMATCH\n" : "c driver ok: proof and MSM equal the expected bytes\n");
+  return bad ? 1 : 0;
+}

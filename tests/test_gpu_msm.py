@@ -200,3 +200,39 @@ def test_c_abi_error_behaviour(co, gpu_ctx):
     xy, inf = gpu_ctx.to_affine(0, 1, gpu_ctx.msm(b, sc[:0], n=0))
     assert inf[0] == 1
     b.free(); wrong.free()
+
+
+def test_submit_collect_pipelined(co, gpu_ctx):
+    """pcdhip_msm_submit / collect: four independent MSMs in flight (different bases, sizes, offsets, groups) return what the
+    one-at-a-time calls return; a fifth submission is refused until a ticket is collected; an unreduced scalar surfaces at collect."""
+    ctx = gpu_ctx
+    fr = co.CURVE_FR[0]
+    n = 30000
+    pts = co.gen_points(0, 1, 3 * n, seed=1501)
+    pts2 = co.gen_points(0, 2, n, seed=1502)
+    sc = co.gen_scalars(fr, 3 * n, seed=1503)
+    b1 = ctx.bases_upload(0, 1, pts)
+    b2 = ctx.bases_upload(0, 2, pts2)
+    sb = ctx.buf_upload(fr, sc)
+    jobs = [(b1, 0, n), (b1, 0, 3 * n), (b2, 0, n), (b1, n + 7, n), (b2, 5, 100), (b1, 0, 5000), (b1, 2 * n, n)]
+    want = [co.to_affine(b.curve, b.group, ctx.msm(b, sb, offset=off, n=cnt)) for b, off, cnt in jobs]
+    for rounds in range(2):
+        got, pending = [], []
+        for b, off, cnt in jobs:
+            pending.append(ctx.msm_submit(b, sb, offset=off, n=cnt))
+            if len(pending) == 4:
+                with pytest.raises(Exception):
+                    ctx.msm_submit(b, sb, offset=off, n=cnt)            # four tickets are outstanding
+                got.append(ctx.msm_collect(pending.pop(0)))
+        while pending:
+            got.append(ctx.msm_collect(pending.pop(0)))
+        for (b, off, cnt), g, w in zip(jobs, got, want):
+            a = co.to_affine(b.curve, b.group, g)
+            assert np.array_equal(a[0], w[0]) and np.array_equal(a[1], w[1]), (off, cnt, rounds)
+    bad = sc[:64].copy(); bad[3, -1] = 1 << 60
+    bb = ctx.buf_upload(fr, bad)
+    t = ctx.msm_submit(b1, bb, n=64)
+    with pytest.raises(Exception):
+        ctx.msm_collect(t)
+    for h in (b1, b2, sb, bb):
+        h.free()
