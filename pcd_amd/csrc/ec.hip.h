@@ -98,6 +98,11 @@ struct SplitOf<G2Cfg2<FQ, FRP, A, NR, CURVE, true>> { typedef G2Cfg2S<FQ, FRP, A
 #endif
 template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE, bool INL>
 struct SplitOf<G2Cfg3<FQ, FRP, A, NR, CURVE, INL>> { typedef G2Cfg3S<FQ, FRP, A, NR, CURVE, INL> type; static constexpr int LANES = 3; };
+// SplitOfTail<G>: the same choice for the latency-bound kernels behind the accumulation (pieces, bucket reduction, combine): there
+// two lanes per point halve the latency of every level, so the inlined 298-bit Fq2 group is split as well
+template <class G> struct SplitOfTail : SplitOf<G> {};
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+struct SplitOfTail<G2Cfg2<FQ, FRP, A, NR, CURVE, true>> { typedef G2Cfg2S<FQ, FRP, A, NR, CURVE, true> type; static constexpr int LANES = 2; };
 
 typedef G1Cfg<F298A, F298B, PCD_MNT4_298_A_SMALL, 0> G1_MNT4_298;
 typedef G1Cfg<F298B, F298A, PCD_MNT6_298_A_SMALL, 1> G1_MNT6_298;

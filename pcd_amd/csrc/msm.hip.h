@@ -595,8 +595,8 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
 // PER_WAVE items; the lanes of an item follow the same control flow (decisions depend on the item only).
 template <class G>
 struct MsmItems {
-  typedef typename SplitOf<G>::type GA;
-  static constexpr uint32_t LANES = SplitOf<G>::LANES, PER_WAVE = 64 / LANES;
+  typedef typename SplitOfTail<G>::type GA;
+  static constexpr uint32_t LANES = SplitOfTail<G>::LANES, PER_WAVE = 64 / LANES;
   PCD_DEV static bool idle() { return threadIdx.x >= PER_WAVE * LANES; }
   PCD_DEV static uint32_t local() { return threadIdx.x / LANES; }
   PCD_DEV static uint32_t item() { return blockIdx.x * PER_WAVE + threadIdx.x / LANES; }

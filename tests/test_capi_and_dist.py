@@ -98,3 +98,53 @@ def test_sharded_msm_two_ranks_gloo(co, tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("OK") == 2
+
+
+GPU_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from oracle import coracle as co
+from pcd_amd import capi
+from pcd_amd.dist import sharded_msm, shard_range, DeviceExchange
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+ngpu = torch.cuda.device_count()
+two = ngpu >= world
+dev = rank if two else 0                      # one GPU per rank when there are enough; otherwise the ranks share cuda:0
+torch.cuda.set_device(dev)
+torch.zeros(1, device=f"cuda:{dev}")
+dist.init_process_group("nccl" if two else "gloo")   # RCCL needs distinct devices; with one GPU the exchange runs over gloo
+ctx = capi.Context(dev)
+cid, grp, n = 0, 1, 40001
+fr = co.CURVE_FR[cid]
+pts = co.gen_points(cid, grp, n, seed=5)
+sc = co.gen_scalars(fr, n, seed=6, dist=1)
+lo, hi = shard_range(n, rank, world)
+bases = ctx.bases_upload(cid, grp, pts[lo:hi])             # this rank's point range of the key is resident on ITS device
+sbuf = ctx.buf_upload(fr, sc[lo:hi])
+if two:
+    full = DeviceExchange(ctx, cid, grp, torch.device("cuda", dev)).msm(bases, sbuf)   # partial -> RCCL all-gather -> EC sum, on device
+else:
+    full = sharded_msm(lambda a, b: ctx.msm(bases, sbuf), lambda parts: ctx.points_sum(cid, grp, parts), n)
+want = co.msm(cid, grp, pts, sc, nthreads=4)
+ok = np.array_equal(co.to_affine(cid, grp, full)[0], co.to_affine(cid, grp, want)[0])
+print("RANK", rank, "backend", "nccl" if two else "gloo", "OK" if ok else "MISMATCH", flush=True)
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+@pytest.mark.gpu
+def test_sharded_msm_two_ranks_gpu(co, tmp_path):
+    """world_size 2 with the GPU pipeline per rank: RCCL + the device-resident exchange when two devices are visible, otherwise both
+    ranks on cuda:0 with the exchange over gloo -- partition, per-rank HIP MSM, gather, EC sum == the oracle's full MSM on both ranks."""
+    script = tmp_path / "gpu_worker.py"
+    script.write_text(GPU_WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", str(script), ROOT]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("OK") == 2
