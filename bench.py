@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--no-step", action="store_true", help="skip the PCD-step sections (Groth16 main + help, 298- and 753-bit)")
     ap.add_argument("--no-753", action="store_true", help="skip the 753-bit PCD step (about two minutes of input generation and CPU checking)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-strong", action="store_true", help="skip the fixed-total (strong scaling) section")
     ap.add_argument("--no-pipeline", action="store_true", help="headline = one MSM at a time (no second MSM in flight)")
     args = ap.parse_args()
 
@@ -200,7 +201,7 @@ def main():
                          f"(threads over windows, c=15), {cpu_s:.2f} s; host has {os.cpu_count()} cores"}
 
     strong = None
-    if not headline_strong:
+    if not headline_strong and not args.no_strong:
         k = max(5, args.steps // 2)
         strong = {f"2^{lt}": strong_run(lt, k, 2) for lt in (20, 22)}
 

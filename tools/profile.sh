@@ -11,4 +11,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d /tmp/prof_${tag}_$c -- python3 "$@" > /dev/null 2>&1
   python3 tools/pmc_summary.py /tmp/prof_${tag}_$c gpurun_out/${tag}_$(echo $c | tr A-Z a-z | cut -d_ -f1).csv > /dev/null
 done
+if [ -n "$PROFILE_SQ" ]; then
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d /tmp/prof_${tag}_sq -- python3 "$@" > /dev/null 2>&1
+  python3 tools/pmc_summary.py /tmp/prof_${tag}_sq gpurun_out/${tag}_sq.csv > /dev/null
+fi
 head -12 gpurun_out/${tag}_stats.csv; grep -i "fft_pass\|accumulate" gpurun_out/${tag}_fetch.csv gpurun_out/${tag}_write.csv
