@@ -42,11 +42,11 @@ CONTRACT = {0: (220, 210, 120), 2: (561, 1176, 288)}   # curve -> (modmul per pa
 def madd_mads(curve):
     """32-bit multiply-adds one mixed addition of the G1 accumulate kernel EXECUTES (28-bit limbs: product 2 N^2, square
     N (N + 1) / 2 + N^2, fused two-term product 3 N^2; N = 11 / 27):
-      298-bit  lazily reduced madd (ec.hip.h madd_lz): 3 squares + 6 products + 1 fused two-term product
-      753-bit  madd-2007-bl: 4 squares + 7 products"""
+      298-bit  lazily reduced XYZZ madd (ec.hip.h madd_lz, madd-2008-s): 2 squares + 6 products + 1 fused two-term product = 2 189
+      753-bit  madd-2007-bl: 4 squares + 7 products = 14 634"""
     n = 11 if curve < 2 else 27
     mul, sqr, dot2 = 2 * n * n, n * (n + 1) // 2 + n * n, 3 * n * n
-    return 3 * sqr + 6 * mul + dot2 if curve < 2 else 4 * sqr + 7 * mul
+    return 2 * sqr + 6 * mul + dot2 if curve < 2 else 4 * sqr + 7 * mul
 
 
 def main():

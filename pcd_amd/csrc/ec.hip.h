@@ -200,62 +200,70 @@ struct EC {
     return r;
   }
   // ---- mixed addition with lazily reduced coordinates (G1 of the 298-bit curves: F = Fp with the Lz helpers of fp.hip.h) ----
-  // The bucket accumulation is a long chain acc <- acc + P_i; here the accumulator keeps X and Y unreduced between steps:
-  //   X  carry-propagated limbs, value < 16p      Y  = 2 D, limbs < 2^29, value < 4p      Z  in [0, 2p) as usual
-  // and every addition / subtraction of madd-2007-bl is limb-wise (no carry chain, no reduction); the products absorb it.
-  // Rewritten with r = 2 r0:  X3 = 4 r0^2 - J - 2V,  Y3 = 2 (r0 (V - X3) - Y1 J) (one fused two-term product),  Z3 = 2 Z1 H.
-  // Bounds (value as a multiple of p | needed for the product: ca cb <= 1024; limb products per column < 2^63):
-  //   H = U2 - X1 + 16p < 18p (carried)   r0 = S2 - Y1 + 4p < 6p (carried)   I = 4 HH < 8p, limbs < 2^30
-  //   J = H I: 144   V = X1 I: 128   X3 = 4 r0^2 - J - 2V + 8p in (0, 16p) (carried)
-  //   t2 = V - X3 + 16p < 18p, limbs in (-2^28, 1.25 * 2^30)   Y1' = 4p - Y1 in (0, 4p]
-  //   D = r0 t2 + Y1' J: 6 * 18 + 4 * 2 = 116;  columns < 11 (2^28 * 1.25 * 2^30 + 2^29 * 2^28) + 11 * 2^56 < 2^62
+  // The bucket accumulation is a long chain acc <- acc + P_i.  The accumulator lives in XYZZ coordinates (x = X / ZZ, y = Y / ZZZ,
+  // ZZ^3 = ZZZ^2; EFD madd-2008-s: 8M + 2S against 7M + 4S for the Jacobian madd-2007-bl, and no (Z1 + H)^2 trick to unfold) with
+  // X kept UNREDUCED between steps:
+  //   X  carry-propagated limbs, value < 16p      Y, ZZ, ZZZ  in [0, 2p) as usual
+  // and every addition / subtraction of the formula is limb-wise (no carry chain, no reduction); the products absorb it.
+  //   U2 = x2 ZZ1   S2 = y2 ZZZ1   P = U2 - X1   R = S2 - Y1   PP = P^2   PPP = P PP   Q = X1 PP
+  //   X3 = R^2 - PPP - 2Q   Y3 = R (Q - X3) - Y1 PPP (one fused two-term product)   ZZ3 = ZZ1 PP   ZZZ3 = ZZZ1 PPP
+  // 6 products of 2 N^2 mads, 2 squares, one fused two-term product of 3 N^2: 2 189 mads (N = 11) against 2 376 for the lazily
+  // reduced Jacobian form this replaces.  Bounds (value as a multiple of p | needed for a product: ca cb <= 1024; limb products
+  // per column < 2^63):
+  //   P = U2 - X1 + 16p < 18p (carried)   R = S2 - Y1 + 4p < 6p (carried)   PP, R^2, PPP, Q < 2p
+  //   X3 = R^2 - PPP - 2Q + 8p in (2p, 10p) (carried)   t = Q - X3 + 16p in (6p, 18p), limbs in (-2^28, 1.25 * 2^30)
+  //   Y1' = 4p - Y1 in (2p, 4p]   Y3 = R t + Y1' PPP: 6 * 18 + 4 * 2 = 116;  columns < 11 (2^28 * 1.25 * 2^30 + 2^29 * 2^28) + 11 * 2^56 < 2^62
   struct AccLz {
-    typename F::Lz X, Y;
-    F Z;
+    typename F::Lz X;
+    F Y, ZZ, ZZZ;
     bool inf;
   };
-  PCD_HD static AccLz lz_infinity() { AccLz a; a.X = F::zero().lz(); a.Y = F::one().lz(); a.Z = F::zero(); a.inf = true; return a; }
-  PCD_HD static AccLz lz_from(const J& p) { AccLz a; a.X = p.X.lz(); a.Y = p.Y.lz(); a.Z = p.Z; a.inf = p.is_inf(); return a; }
-  // fully reduced Jacobian point (each lazy coordinate times the Montgomery one)
+  static constexpr int ACC_WORDS = 4 * F::WORDS;  // record the accumulation flushes: X (unreduced limbs) || Y || ZZ || ZZZ, identity = ZZ 0
+  PCD_HD static AccLz lz_infinity() { AccLz a; a.X = F::zero().lz(); a.Y = F::one(); a.ZZ = F::zero(); a.ZZZ = F::zero(); a.inf = true; return a; }
+  PCD_HD static AccLz lz_from(const J& p) {
+    AccLz a;
+    a.inf = p.is_inf();
+    a.X = p.X.lz(); a.Y = p.Y; a.ZZ = p.Z.sqr(); a.ZZZ = a.ZZ * p.Z;
+    return a;
+  }
+  // fully reduced Jacobian point (X ZZ : Y ZZZ : ZZ) -- x = X ZZ / ZZ^2, y = Y ZZZ / ZZ^3 since ZZ^3 = ZZZ^2
   PCD_HD static J lz_to_jac(const AccLz& a) {
     if (a.inf) return J::infinity();
-    const typename F::Lz one = F::one().lz();
-    return {F::lz_mul(a.X, one), F::lz_mul(a.Y, one), a.Z};
+    return {F::lz_mul(a.X, a.ZZ.lz()), a.Y * a.ZZZ, a.ZZ};
   }
   PCD_HD static AccLz madd_lz(const AccLz& p, const A& q) {
     typedef typename F::Lz L;
     if (q.is_inf()) return p;
-    if (p.inf) { AccLz o; o.X = q.x.lz(); o.Y = q.y.lz(); o.Z = F::one(); o.inf = false; return o; }
-    const L Z1 = p.Z.lz();
-    const F Z1Z1 = F::lz_sqr(Z1);
-    const L zz = Z1Z1.lz();
+    if (p.inf) { AccLz o; o.X = q.x.lz(); o.Y = q.y; o.ZZ = F::one(); o.ZZZ = F::one(); o.inf = false; return o; }
+    const L zz = p.ZZ.lz(), zzz = p.ZZZ.lz();
     const F U2 = F::lz_mul(q.x.lz(), zz);
-    const F S2 = F::lz_mul(F::lz_mul(q.y.lz(), Z1).lz(), zz);
-    const L H = F::lz_carry(F::template lz_sub<2>(U2.lz(), p.X));
-    const L r0 = F::lz_carry(F::template lz_sub<0>(S2.lz(), p.Y));
-    const F HH = F::lz_sqr(H);
-    const F rr0 = F::lz_sqr(r0);
-    if (HH.is_zero()) {  // same x: the same point (double it the ordinary way) or opposite points
-      if (!rr0.is_zero()) return lz_infinity();
+    const F S2 = F::lz_mul(q.y.lz(), zzz);
+    const L P = F::lz_carry(F::template lz_sub<2>(U2.lz(), p.X));
+    const L R = F::lz_carry(F::template lz_sub<0>(S2.lz(), p.Y.lz()));
+    const F PP = F::lz_sqr(P);
+    const F RR = F::lz_sqr(R);
+    if (PP.is_zero()) {  // same x: the same point (double it the ordinary way) or opposite points
+      if (!RR.is_zero()) return lz_infinity();
       return lz_from(dbl(lz_to_jac(p)));
     }
-    const L I = F::lz_shl(HH.lz(), 2);
-    const F Jv = F::lz_mul(H, I);
-    const F V = F::lz_mul(p.X, I);
+    const L pp = PP.lz();
+    const F PPP = F::lz_mul(P, pp);
+    const F Q = F::lz_mul(p.X, pp);
     AccLz o;
     o.inf = false;
-    {  // X3 = 4 r0^2 - J - 2V + 8p
+    {  // X3 = R^2 - PPP - 2Q + 8p
       L t;
 #pragma unroll
       for (int i = 0; i < F::N; i++)
-        t.v[i] = (int32_t)(rr0.v[i] << 2) - (int32_t)Jv.v[i] - (int32_t)(V.v[i] << 1) + (int32_t)(F::Params::mod4(i) << 1);
+        t.v[i] = (int32_t)RR.v[i] - (int32_t)PPP.v[i] - (int32_t)(Q.v[i] << 1) + (int32_t)(F::Params::mod4(i) << 1);
       o.X = F::lz_carry(t);
     }
-    const L t2 = F::template lz_sub<2>(V.lz(), o.X);
-    const L y1n = F::template lz_sub<0>(F::zero().lz(), p.Y);
-    const F D = F::lz_dot2(r0, t2, y1n, Jv.lz());
-    o.Y = F::lz_shl(D.lz(), 1);
-    o.Z = F::lz_mul(F::lz_shl(Z1, 1), H);
+    const L t2 = F::template lz_sub<2>(Q.lz(), o.X);
+    const L y1n = F::template lz_sub<0>(F::zero().lz(), p.Y.lz());
+    const L ppp = PPP.lz();
+    o.Y = F::lz_dot2(R, t2, y1n, ppp);
+    o.ZZ = F::lz_mul(zz, pp);
+    o.ZZZ = F::lz_mul(zzz, ppp);
     return o;
   }
 

@@ -446,10 +446,10 @@ struct MsmRunPlain {
   PCD_DEV void add(const Aff<F>& q) { a = EC<G>::madd(a, q); }
   PCD_DEV void flush(uint32_t* dst) { a.store(dst); a = Jac<F>::infinity(); }
 };
-// The lazily reduced accumulator is flushed AS IT IS (X carry-propagated < 16p, Y limbs < 2^29, Z reduced; the identity as
-// Z = 0): the two reducing products of lz_to_jac would run inside the divergent flush branch that some lane of the wave takes in
-// nearly every iteration.  Whatever msm_accumulate wrote -- buckets and pieces -- is reduced by its reader (MsmStored::load: the
-// fix-up pass, one lane per bucket, coalesced and convergent).
+// The lazily reduced accumulator is flushed AS IT IS (XYZZ: X carry-propagated < 16p, Y / ZZ / ZZZ reduced; the identity as
+// ZZ = 0) into records of four field elements: the products that turn it into a reduced Jacobian point would run inside the divergent
+// flush branch that some lane of the wave takes in nearly every iteration.  Whatever msm_accumulate wrote -- buckets and pieces -- is
+// converted by its reader (MsmStored::load: the fix-up pass, one lane per bucket, coalesced and convergent).
 template <class G>
 struct MsmRunLazy {
   typedef typename G::F F;
@@ -458,34 +458,37 @@ struct MsmRunLazy {
   PCD_DEV void flush(uint32_t* dst) {
     if (a.inf) { F::zero().store(dst + 2 * F::WORDS); return; }
 #pragma unroll
-    for (int i = 0; i < F::N; i++) { dst[i] = (uint32_t)a.X.v[i]; dst[F::WORDS + i] = (uint32_t)a.Y.v[i]; }
-    a.Z.store(dst + 2 * F::WORDS);
+    for (int i = 0; i < F::N; i++) dst[i] = (uint32_t)a.X.v[i];
+    a.Y.store(dst + F::WORDS);
+    a.ZZ.store(dst + 2 * F::WORDS);
+    a.ZZZ.store(dst + 3 * F::WORDS);
     a = EC<G>::lz_infinity();
   }
 };
-// a point written by msm_accumulate's flush, as a reduced Jacobian point
+// a point written by msm_accumulate's flush, as a reduced Jacobian point; WORDS = u32 words of one flushed record
 template <class G, bool LAZY = LazyCapable<typename G::F>::value>
 struct MsmStored {
   typedef typename G::F F;
+  static constexpr int WORDS = Jac<F>::WORDS;
   PCD_DEV static Jac<F> load(const uint32_t* p) { return Jac<F>::load(p); }
-  static constexpr bool NEEDS_FIXUP = false;
+  static constexpr bool SEPARATE = false;  // flushed buckets ARE the bucket array
 };
 template <class G>
 struct MsmStored<G, true> {
   typedef typename G::F F;
+  static constexpr int WORDS = EC<G>::ACC_WORDS;
   PCD_DEV static Jac<F> load(const uint32_t* p) {
-    Jac<F> r;
-    r.Z = F::load(p + 2 * F::WORDS);
-    if (r.Z.is_zero()) return Jac<F>::infinity();
-    typename F::Lz x, y;
+    typename EC<G>::AccLz a;
+    a.ZZ = F::load(p + 2 * F::WORDS);
+    if (a.ZZ.is_zero()) return Jac<F>::infinity();
+    a.inf = false;
 #pragma unroll
-    for (int i = 0; i < F::N; i++) { x.v[i] = (int32_t)p[i]; y.v[i] = (int32_t)p[F::WORDS + i]; }
-    const typename F::Lz one = F::one().lz();
-    r.X = F::lz_mul(x, one);
-    r.Y = F::lz_mul(y, one);
-    return r;
+    for (int i = 0; i < F::N; i++) a.X.v[i] = (int32_t)p[i];
+    a.Y = F::load(p + F::WORDS);
+    a.ZZZ = F::load(p + 3 * F::WORDS);
+    return EC<G>::lz_to_jac(a);
   }
-  static constexpr bool NEEDS_FIXUP = true;  // buckets written whole by one chunk still need the reduction
+  static constexpr bool SEPARATE = true;  // flushed buckets live in their own array (wider records); the fix-up pass fills the bucket array
 };
 
 // Waves per SIMD the register allocation of the accumulate kernel aims at: 2 for the 298-bit G1 (194 registers, no spills);
@@ -503,6 +506,7 @@ struct MsmAccWaves {
 #endif
   static constexpr int value = !FA::Base::INLINE_ARITH ? 1 : FA::DEG == 1 ? PCD_ACC_WAVES_G1 : SplitOf<G>::LANES > 1 ? PCD_ACC_WAVES_SPLIT : 1;
 };
+
 // COMPACT: the entries form one list (`sorted_idx`, the scalars equal to one possibly in their own list `ones_idx` behind it), so
 // entry p is found without knowing its bucket; otherwise (single-pass binning, pcdhip_msm_set_sort 1) entries sit in per-bucket slots
 // and are addressed through the cursor.
@@ -516,6 +520,7 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
   typedef typename SplitOf<G>::type GA;
   typedef typename GA::F F;
   typedef EC<GA> E;
+  constexpr int RW = MsmStored<GA>::WORDS;  // u32 words of a flushed record (`buckets` here = the array the flushes go to)
   constexpr uint32_t LANES = SplitOf<G>::LANES, PER_WAVE = 64 / LANES;  // chunks per 64-lane workgroup (three lanes per point: 21, lane 63 idles)
   if (threadIdx.x >= PER_WAVE * LANES) return;
   uint32_t t = blockIdx.x * PER_WAVE + threadIdx.x / LANES;
@@ -548,8 +553,8 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
     if (PREFETCH) nxt = point_of(entry_at(start));
     for (uint32_t p = start; p < end; p++) {
       if (p >= cur.key_end) {  // run of `key` is complete
-        if (open_start) { acc.flush(piece_first + (size_t)t * Jac<F>::WORDS); open_start = false; }
-        else acc.flush(buckets + (size_t)cur.key * Jac<F>::WORDS);
+        if (open_start) { acc.flush(piece_first + (size_t)t * RW); open_start = false; }
+        else acc.flush(buckets + (size_t)cur.key * RW);
         cur.advance_to(off, nkeys, p);
       }
       if (PREFETCH) {
@@ -566,8 +571,8 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
     if (PREFETCH) nxt = point_of(msm_entry(src, false, cur, start));
     for (uint32_t p = start; p < end; p++) {
       if (p >= cur.key_end) {
-        if (open_start) { acc.flush(piece_first + (size_t)t * Jac<F>::WORDS); open_start = false; }
-        else acc.flush(buckets + (size_t)cur.key * Jac<F>::WORDS);
+        if (open_start) { acc.flush(piece_first + (size_t)t * RW); open_start = false; }
+        else acc.flush(buckets + (size_t)cur.key * RW);
         cur.advance_to(off, nkeys, p);
       }
       if (PREFETCH) {
@@ -583,9 +588,9 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
     }
   }
   bool open_end = cur.key_end > end;
-  if (open_end) acc.flush(piece_last + (size_t)t * Jac<F>::WORDS);          // also the "middle piece" case
-  else if (open_start) acc.flush(piece_first + (size_t)t * Jac<F>::WORDS);
-  else acc.flush(buckets + (size_t)cur.key * Jac<F>::WORDS);
+  if (open_end) acc.flush(piece_last + (size_t)t * RW);          // also the "middle piece" case
+  else if (open_start) acc.flush(piece_first + (size_t)t * RW);
+  else acc.flush(buckets + (size_t)cur.key * RW);
 }
 
 // Work-item indexing of the kernels behind the accumulation (pieces, bucket reduction, window combine).  They compute in the
@@ -621,12 +626,14 @@ __global__ void __launch_bounds__(64) msm_merge_ones_kernel(uint32_t* __restrict
 template <class G>
 __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t chunk,
                                                        const uint32_t* __restrict__ piece_first, const uint32_t* __restrict__ piece_last,
+                                                       const uint32_t* __restrict__ acc_buckets /* what msm_accumulate flushed whole buckets into */,
                                                        uint32_t* __restrict__ buckets, uint32_t big_limit, uint32_t* __restrict__ big_count,
                                                        uint32_t* __restrict__ big_list /* (key, first segment, #segments) */, uint32_t big_cap,
                                                        uint32_t* __restrict__ seg_list /* (t_lo, t_hi, t_last) */, uint32_t seg_len) {
   typedef typename MsmItems<G>::GA GA;
   typedef typename GA::F F;
   typedef EC<GA> E;
+  constexpr int RW = MsmStored<GA>::WORDS;
   if (MsmItems<G>::idle()) return;
   const bool lead = threadIdx.x % MsmItems<G>::LANES == 0;  // one lane of the item does the list bookkeeping
   uint32_t key = MsmItems<G>::item();
@@ -638,7 +645,7 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
   }
   uint32_t t0 = lo / chunk, t1 = (hi - 1) / chunk;
   if (t1 == t0) {  // the whole run lies inside one chunk: msm_accumulate wrote the bucket itself (unreduced for the lazy groups)
-    if (MsmStored<GA>::NEEDS_FIXUP) MsmStored<GA>::load(buckets + (size_t)key * Jac<F>::WORDS).store(buckets + (size_t)key * Jac<F>::WORDS);
+    if (MsmStored<GA>::SEPARATE) MsmStored<GA>::load(acc_buckets + (size_t)key * RW).store(buckets + (size_t)key * Jac<F>::WORDS);
     return;
   }
   if (t1 - t0 + 1 > big_limit) {  // big bucket: its pieces are cut into segments of seg_len, one wave each
@@ -653,9 +660,9 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
     }
     return;
   }
-  Jac<F> acc = MsmStored<GA>::load(piece_last + (size_t)t0 * Jac<F>::WORDS);
-  for (uint32_t u = t0 + 1; u < t1; u++) acc = E::add(acc, MsmStored<GA>::load(piece_last + (size_t)u * Jac<F>::WORDS));
-  acc = E::add(acc, MsmStored<GA>::load(piece_first + (size_t)t1 * Jac<F>::WORDS));
+  Jac<F> acc = MsmStored<GA>::load(piece_last + (size_t)t0 * RW);
+  for (uint32_t u = t0 + 1; u < t1; u++) acc = E::add(acc, MsmStored<GA>::load(piece_last + (size_t)u * RW));
+  acc = E::add(acc, MsmStored<GA>::load(piece_first + (size_t)t1 * RW));
   acc.store(buckets + (size_t)key * Jac<F>::WORDS);
 }
 
@@ -699,7 +706,7 @@ __global__ void __launch_bounds__(64) msm_big_segments_kernel(const uint32_t* __
     if (!MsmItems<G>::idle())
       for (uint32_t u = lo + MsmItems<G>::local(); u <= hi; u += PW) {
         const uint32_t* src = (u == tlast) ? piece_first : piece_last;
-        acc = E::add(acc, MsmStored<GA>::load(src + (size_t)u * Jac<F>::WORDS));
+        acc = E::add(acc, MsmStored<GA>::load(src + (size_t)u * MsmStored<GA>::WORDS));
       }
     msm_wave_tree<G>(acc, my, partial + (size_t)sg * Jac<F>::WORDS);
   }
@@ -908,8 +915,8 @@ hipError_t msm_precompute(hipStream_t st, uint32_t* pts, uint32_t n, int groups,
 // ------------------------------------------------------------------------------------------------ host driver
 struct MsmWorkspace {
   // device buffers, grown on demand and reused across calls (no allocation on the hot path once warm)
-  void* buf[20] = {nullptr};
-  size_t cap[20] = {0};
+  void* buf[24] = {nullptr};
+  size_t cap[24] = {0};
   const uint32_t* last_err_dev = nullptr;  // device word raised by the last MSM's digit pass when a scalar was not reduced (null: not checked)
   hipError_t ensure(int slot, size_t bytes) {
     if (cap[slot] >= bytes) return hipSuccess;
@@ -920,7 +927,7 @@ struct MsmWorkspace {
     cap[slot] = want;
     return hipSuccess;
   }
-  void release() { for (int i = 0; i < 20; i++) if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; } }
+  void release() { for (int i = 0; i < 24; i++) if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; } }
 };
 
 struct MsmTimings {  // milliseconds, filled when events are requested
@@ -928,7 +935,7 @@ struct MsmTimings {  // milliseconds, filled when events are requested
 };
 
 enum { WS_CNT = 0, WS_OFF, WS_BSUM, WS_SORTED, WS_BUCKETS, WS_PFIRST, WS_PLAST, WS_BIG, WS_BIGSCR, WS_A0, WS_A1, WS_C0, WS_C1, WS_OUT, WS_SCAL,
-       WS_BIGPART, WS_ONES, WS_SLOTS, WS_CUR, WS_ENTRIES };
+       WS_BIGPART, WS_ONES, WS_SLOTS, WS_CUR, WS_ENTRIES, WS_ACCB };
 
 #define PCD_HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -1096,8 +1103,12 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   // 4. accumulate.  Nothing below waits for the host: grids are sized for the largest possible list (n W entries;
   //    the actual count M = off[nkeys] is read on the device) so the whole MSM is one asynchronous chain of launches.
   const uint32_t nchunks = (uint32_t)((maxM + pl.chunk - 1) / pl.chunk);
-  PCD_HIP_TRY(ws.ensure(WS_PFIRST, (size_t)nchunks * PB));
-  PCD_HIP_TRY(ws.ensure(WS_PLAST, (size_t)nchunks * PB));
+  typedef MsmStored<typename SplitOf<G>::type> Stored;
+  constexpr size_t RB = (size_t)Stored::WORDS * 4;  // bytes of a flushed record
+  PCD_HIP_TRY(ws.ensure(WS_PFIRST, (size_t)nchunks * RB));
+  PCD_HIP_TRY(ws.ensure(WS_PLAST, (size_t)nchunks * RB));
+  uint32_t* acc_buckets = buckets;  // where whole-bucket flushes go: the bucket array itself, or (wider records) an array of their own
+  if (Stored::SEPARATE) { PCD_HIP_TRY(ws.ensure(WS_ACCB, (size_t)tkeys * RB)); acc_buckets = (uint32_t*)ws.buf[WS_ACCB]; }
   const uint32_t big_limit = 8, seg_len = 256;
   const uint32_t big_cap = nchunks / big_limit + 2;   // a big bucket spans more than big_limit chunks
   const uint32_t seg_cap = nchunks / seg_len + big_cap + 2;
@@ -1117,12 +1128,12 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     constexpr uint32_t per_wave = 64 / SplitOf<G>::LANES;  // chunks per workgroup
     const dim3 acc_grid((nchunks + per_wave - 1) / per_wave);
     // (with per-bucket slots both instantiations are queued: the device's overflow flag decides which of them does the work)
-    if (src.slots) hipLaunchKernelGGL((msm_accumulate_kernel<G, false>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, buckets, pfirst, plast);
-    hipLaunchKernelGGL((msm_accumulate_kernel<G, true>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, buckets, pfirst, plast);
+    if (src.slots) hipLaunchKernelGGL((msm_accumulate_kernel<G, false>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast);
+    hipLaunchKernelGGL((msm_accumulate_kernel<G, true>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast);
   }
   PCD_HIP_TRY(mark(4));
   // 5. pieces
-  hipLaunchKernelGGL((msm_fixup_kernel<G>), dim3(MsmItems<G>::grid(tkeys)), dim3(64), 0, st, off, tkeys, pl.chunk, pfirst, plast, buckets,
+  hipLaunchKernelGGL((msm_fixup_kernel<G>), dim3(MsmItems<G>::grid(tkeys)), dim3(64), 0, st, off, tkeys, pl.chunk, pfirst, plast, acc_buckets, buckets,
                      big_limit, big_count, big, big_cap, seg_list, seg_len);
   {
     const uint32_t big_grid = std::min<uint32_t>(seg_cap, 2048);
