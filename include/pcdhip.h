@@ -268,7 +268,8 @@ void pcdhip_pvk_free(pcdhip_ctx* ctx, pcdhip_pvk* pvk);
 /* `Groth16::verify_with_processed_vk` for n_proofs proofs under one key (`ECCyclePCD::verify`, mod.rs:239, once per prior message
  * of a merge node):  e(A, B) e(acc, -gamma) e(C, -delta) == e(alpha, beta)  -- three Miller loops and ONE final exponentiation per
  * proof (upstream's form; four and two without the prepared key), every Miller loop of the batch in one launch (3 n_proofs lanes),
- * the products and final exponentiations in another (one lane per proof).  Deterministic: ok[i] = 1 / 0 per proof.
+ * the products and final exponentiations in another (one lane per proof); the input combinations acc_i = gamma_abc[0] + sum_j
+ * x_ij gamma_abc[j] are n_proofs small MSMs over the resident gamma_abc vector.  Deterministic: ok[i] = 1 / 0 per proof.
  * public inputs: n_proofs x (num_inputs - 1) canonical scalars; proofs: n_proofs x (A || B || C); proofs_inf: n_proofs x 3 or NULL. */
 int pcdhip_groth16_verify_prepared(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_t n_proofs, const uint64_t* public_inputs_canonical,
                                    const uint64_t* proofs, const uint8_t* proofs_inf, int* ok);

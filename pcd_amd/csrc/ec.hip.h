@@ -284,4 +284,93 @@ struct EC {
   }
 };
 
+// ------------------------------------------------------------------------------------------------ two lanes per group operation
+// The latency-bound levels of the bucket reduction run ONE addition (or doubling) per handful of lanes; in one lane that is 16 (9)
+// dependent field products.  add-2007-bl has two independent operand chains (Z1Z1, U2, S2 | Z2Z2, U1, S1) and pairs of independent
+// products after them, dbl-2007-bl likewise: here an even / odd lane pair shares one operation, each lane computing one product of
+// every slot with role-selected operands and handing results across with `ds_swizzle`-class shuffles (`__shfl_xor 1`).  8 product
+// slots instead of 16 products for an addition, 5 instead of 9 for a doubling.  Both lanes pass the same points and both return the
+// whole result.  Prime-field groups only (the extension-field groups are already spread over lanes at the field level).
+template <class G>
+struct EC2 {
+  typedef typename G::F F;
+  typedef Jac<F> J;
+  typedef EC<G> E;
+  PCD_DEV static bool odd() { return (threadIdx.x & 1u) != 0; }
+  PCD_DEV static F xch(const F& a) { F r;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) r.v[i] = (uint32_t)__shfl_xor((int)a.v[i], 1, 64);
+    return r; }
+  PCD_DEV static F sel(bool t, const F& a, const F& b) { F r;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) r.v[i] = t ? a.v[i] : b.v[i];
+    return r; }
+  // one product slot: the even lane computes ea * eb, the odd lane oa * ob
+  PCD_DEV static F slot(const F& ea, const F& eb, const F& oa, const F& ob) { const bool o = odd(); return sel(o, oa, ea) * sel(o, ob, eb); }
+
+  PCD_DEV static J dbl2(const J& p) {
+    if (p.is_inf()) return p;
+    const bool o = odd();
+    const F s1 = slot(p.X, p.X, p.Y, p.Y);            // even: XX          odd: YY
+    const F s1x = xch(s1);
+    const F XX = sel(o, s1x, s1), YY = sel(o, s1, s1x);
+    const F s2 = slot(p.Z, p.Z, YY, YY);               // even: ZZ          odd: YYYY
+    const F s2x = xch(s2);
+    const F ZZ = sel(o, s2x, s2), YYYY = sel(o, s2, s2x);
+    const F xyy = p.X + YY;
+    const F s3 = slot(ZZ, ZZ, xyy, xyy);               // even: ZZ^2        odd: (X + YY)^2
+    const F s3x = xch(s3);
+    const F ZZ2 = sel(o, s3x, s3), XYY2 = sel(o, s3, s3x);
+    const F S = (XYY2 - XX - YYYY).dbl();
+    const F M = XX.dbl() + XX + G::mul_by_a(ZZ2);
+    const F yz = p.Y + p.Z;
+    const F s4 = slot(M, M, yz, yz);                   // even: M^2         odd: (Y + Z)^2
+    const F s4x = xch(s4);
+    const F MM = sel(o, s4x, s4), YZ2 = sel(o, s4, s4x);
+    J r;
+    r.X = MM - S.dbl();
+    r.Z = YZ2 - YY - ZZ;
+    r.Y = M * (S - r.X) - YYYY.dbl().dbl().dbl();     // (the last product is computed by both lanes)
+    return r;
+  }
+  PCD_DEV static J add2(const J& p, const J& q) {
+    if (p.is_inf()) return q;
+    if (q.is_inf()) return p;
+    const bool o = odd();
+    const F s1 = slot(p.Z, p.Z, q.Z, q.Z);             // even: Z1Z1        odd: Z2Z2
+    const F s1x = xch(s1);
+    const F Z1Z1 = sel(o, s1x, s1), Z2Z2 = sel(o, s1, s1x);
+    const F s2 = slot(p.X, Z2Z2, q.X, Z1Z1);           // even: U1          odd: U2
+    const F s3 = slot(p.Y, q.Z, q.Y, p.Z);             // even: Y1 Z2       odd: Y2 Z1
+    const F s4 = slot(s3, Z2Z2, s3, Z1Z1);             // even: S1          odd: S2
+    const F s2x = xch(s2), s4x = xch(s4);
+    const F U1 = sel(o, s2x, s2), U2 = sel(o, s2, s2x), S1 = sel(o, s4x, s4), S2 = sel(o, s4, s4x);
+    const F H = U2 - U1;
+    F r = S2 - S1;
+    if (H.is_zero()) return r.is_zero() ? dbl2(p) : J::infinity();
+    r = r.dbl();
+    const F h2 = H.dbl(), zs = p.Z + q.Z;
+    const F s5 = slot(h2, h2, zs, zs);                 // even: I = (2H)^2  odd: (Z1 + Z2)^2
+    const F s5x = xch(s5);
+    const F I = sel(o, s5x, s5), ZS = sel(o, s5, s5x);
+    const F zc = ZS - Z1Z1 - Z2Z2;
+    const F s6 = slot(H, I, zc, H);                    // even: J = H I     odd: Z3
+    const F s7 = slot(U1, I, r, r);                    // even: V = U1 I    odd: r^2
+    const F s6x = xch(s6), s7x = xch(s7);
+    const F Jv = sel(o, s6x, s6), Z3 = sel(o, s6, s6x), V = sel(o, s7x, s7), rr = sel(o, s7, s7x);
+    J out;
+    out.X = rr - Jv - V.dbl();
+    out.Z = Z3;
+    const F vx = V - out.X;
+    const F s8 = slot(S1, Jv, r, vx);                  // even: S1 J        odd: r (V - X3)
+    const F s8x = xch(s8);
+    const F S1J = sel(o, s8x, s8), rv = sel(o, s8, s8x);
+    out.Y = rv - S1J.dbl();
+    return out;
+  }
+};
+// groups whose latency-bound pair levels run two lanes per operation
+template <class G> struct TwoLaneOps { static constexpr bool value = false; };
+template <class FQ, class FRP, unsigned A, int CURVE, bool INL> struct TwoLaneOps<G1Cfg<FQ, FRP, A, CURVE, INL>> { static constexpr bool value = true; };
+
 }  // namespace pcd

@@ -732,34 +732,62 @@ __global__ void __launch_bounds__(64) msm_big_bucket_kernel(const uint32_t* __re
 
 // ------------------------------------------------------------------------------------------------ tail: sum_d d * B_d
 // State per window: weighted array A (weights 1..mA) and plain array C;  V = WS(A) + S(C).
+// Items of the bucket-reduction levels.  Prime-field groups spend TWO lanes on every item (EC2: 8 product slots per addition
+// instead of 16 products, 5 per doubling instead of 9); the extension-field groups are spread over lanes at the field level already.
+template <class G, bool ENABLE = true>
+struct MsmPairItems {
+  static constexpr bool TWO = ENABLE && TwoLaneOps<G>::value && MsmItems<G>::LANES == 1;
+  static constexpr uint32_t LANES = TWO ? 2 : MsmItems<G>::LANES, PER_WAVE = 64 / LANES;
+  PCD_DEV static bool idle() { return threadIdx.x >= PER_WAVE * LANES; }
+  PCD_DEV static uint32_t item() { return blockIdx.x * PER_WAVE + threadIdx.x / LANES; }
+  PCD_DEV static bool writer() { return !TWO || (threadIdx.x & 1u) == 0; }  // (both lanes of a pair hold the whole result)
+  static uint32_t grid(uint32_t items) { return (items + PER_WAVE - 1) / PER_WAVE; }
+};
+template <class G, bool TWO = MsmPairItems<G, true>::TWO>
+struct MsmPairOps {
+  typedef typename MsmItems<G>::GA GA;
+  typedef Jac<typename GA::F> J;
+  PCD_DEV static J add(const J& a, const J& b) { return EC<GA>::add(a, b); }
+  PCD_DEV static J dbl(const J& a) { return EC<GA>::dbl(a); }
+};
+template <class G>
+struct MsmPairOps<G, true> {
+  typedef G GA;
+  typedef Jac<typename G::F> J;
+  PCD_DEV static J add(const J& a, const J& b) { return EC2<G>::add2(a, b); }
+  PCD_DEV static J dbl(const J& a) { return EC2<G>::dbl2(a); }
+};
 // One level with block size K = 2^k:  block j of A -> T_j (plain sum), L_j (weighted sum, weights 1..K)
 //   V = S(C) + S(L) + WS({K * T_j}_{j>=1});   A' = {2^k T_j}_{j>=1},  C' = blocksums(C) ++ L
-template <class G>
+// (WIDE: two lanes per item where the group allows it -- pays when the level is latency-bound, i.e. has few items; a first level over
+//  2^16 blocks fills the chip with one lane per item: G1-298 at c = 20 measured 0.71 -> 0.73 ms with two, G1-753 at c = 19 2.79 -> 2.32)
+template <class G, bool WIDE>
 __global__ void __launch_bounds__(64) msm_tail_level_kernel(const uint32_t* __restrict__ A_in, uint32_t mA, size_t strideA_in,
                                                             const uint32_t* __restrict__ C_in, uint32_t mC, size_t strideC_in,
                                                             uint32_t* __restrict__ A_out, size_t strideA_out,
                                                             uint32_t* __restrict__ C_out, size_t strideC_out, int k) {
-  typedef typename MsmItems<G>::GA GA;
+  typedef MsmPairItems<G, WIDE> IT;
+  typedef MsmPairOps<G, IT::TWO> O;
+  typedef typename O::GA GA;
   typedef typename GA::F F;
-  typedef EC<GA> E;
   constexpr int PW = Jac<F>::WORDS;
-  if (MsmItems<G>::idle()) return;
+  if (IT::idle()) return;
   uint32_t K = 1u << k;
   uint32_t JA = (mA + K - 1) >> k, JC = (mC + K - 1) >> k;
-  uint32_t tid = MsmItems<G>::item();
+  uint32_t tid = IT::item();
   uint32_t w = blockIdx.y;
   if (tid < JA) {
     const uint32_t* A = A_in + w * strideA_in * PW;
     Jac<F> run = Jac<F>::infinity(), acc = Jac<F>::infinity();
     for (int tt = (int)K - 1; tt >= 0; tt--) {
       uint32_t i = tid * K + tt;
-      if (i < mA) run = E::add(run, Jac<F>::load(A + (size_t)i * PW));
-      acc = E::add(acc, run);
+      if (i < mA) run = O::add(run, Jac<F>::load(A + (size_t)i * PW));
+      acc = O::add(acc, run);
     }
-    acc.store(C_out + (w * strideC_out + JC + tid) * PW);
+    if (IT::writer()) acc.store(C_out + (w * strideC_out + JC + tid) * PW);
     if (tid >= 1) {
-      for (int d = 0; d < k; d++) run = E::dbl(run);
-      run.store(A_out + (w * strideA_out + tid - 1) * PW);
+      for (int d = 0; d < k; d++) run = O::dbl(run);
+      if (IT::writer()) run.store(A_out + (w * strideA_out + tid - 1) * PW);
     }
   } else if (tid < JA + JC) {
     uint32_t j = tid - JA;
@@ -767,9 +795,9 @@ __global__ void __launch_bounds__(64) msm_tail_level_kernel(const uint32_t* __re
     Jac<F> acc = Jac<F>::infinity();
     for (uint32_t tt = 0; tt < K; tt++) {
       uint32_t i = j * K + tt;
-      if (i < mC) acc = E::add(acc, Jac<F>::load(Cw + (size_t)i * PW));
+      if (i < mC) acc = O::add(acc, Jac<F>::load(Cw + (size_t)i * PW));
     }
-    acc.store(C_out + (w * strideC_out + j) * PW);
+    if (IT::writer()) acc.store(C_out + (w * strideC_out + j) * PW);
   }
 }
 
@@ -777,18 +805,20 @@ __global__ void __launch_bounds__(64) msm_tail_level_kernel(const uint32_t* __re
 // the critical path of a level is one addition and one doubling instead of two additions and a doubling -- these levels
 // are pure latency (a handful of lanes), so the extra doubling is free:
 //   z = 0:  A'_{j-1} = 2 (A_{2j} + A_{2j+1})        z = 1:  L_j = A_{2j} + 2 A_{2j+1} -> C'[JC + j]        z = 2:  C'_j = C_{2j} + C_{2j+1}
+// (items and operations: MsmPairItems / MsmPairOps above)
 template <class G>
 __global__ void __launch_bounds__(64) msm_tail_pair_kernel(const uint32_t* __restrict__ A_in, uint32_t mA, size_t strideA_in,
                                                            const uint32_t* __restrict__ C_in, uint32_t mC, size_t strideC_in,
                                                            uint32_t* __restrict__ A_out, size_t strideA_out,
                                                            uint32_t* __restrict__ C_out, size_t strideC_out) {
-  typedef typename MsmItems<G>::GA GA;
+  typedef MsmPairOps<G> O;
+  typedef typename O::GA GA;
   typedef typename GA::F F;
-  typedef EC<GA> E;
+  typedef MsmPairItems<G> IT;
   constexpr int PW = Jac<F>::WORDS;
-  if (MsmItems<G>::idle()) return;
+  if (IT::idle()) return;
   const uint32_t JA = (mA + 1) >> 1, JC = (mC + 1) >> 1;
-  const uint32_t j = MsmItems<G>::item();
+  const uint32_t j = IT::item();
   const uint32_t w = blockIdx.y;
   const int role = blockIdx.z;
   if (role < 2) {
@@ -798,18 +828,19 @@ __global__ void __launch_bounds__(64) msm_tail_pair_kernel(const uint32_t* __res
     const Jac<F> a0 = Jac<F>::load(A + (size_t)(2 * j) * PW);
     if (role == 0) {
       if (j == 0) return;
-      Jac<F> run = two ? E::add(a0, Jac<F>::load(A + (size_t)(2 * j + 1) * PW)) : a0;
-      E::dbl(run).store(A_out + (w * strideA_out + j - 1) * PW);
+      Jac<F> run = two ? O::add(a0, Jac<F>::load(A + (size_t)(2 * j + 1) * PW)) : a0;
+      run = O::dbl(run);
+      if (IT::writer()) run.store(A_out + (w * strideA_out + j - 1) * PW);
     } else {
-      Jac<F> acc = two ? E::add(E::dbl(Jac<F>::load(A + (size_t)(2 * j + 1) * PW)), a0) : a0;
-      acc.store(C_out + (w * strideC_out + JC + j) * PW);
+      Jac<F> acc = two ? O::add(O::dbl(Jac<F>::load(A + (size_t)(2 * j + 1) * PW)), a0) : a0;
+      if (IT::writer()) acc.store(C_out + (w * strideC_out + JC + j) * PW);
     }
   } else {
     if (j >= JC) return;
     const uint32_t* Cw = C_in + w * strideC_in * PW;
     Jac<F> acc = Jac<F>::load(Cw + (size_t)(2 * j) * PW);
-    if (2 * j + 1 < mC) acc = E::add(acc, Jac<F>::load(Cw + (size_t)(2 * j + 1) * PW));
-    acc.store(C_out + (w * strideC_out + j) * PW);
+    if (2 * j + 1 < mC) acc = O::add(acc, Jac<F>::load(Cw + (size_t)(2 * j + 1) * PW));
+    if (IT::writer()) acc.store(C_out + (w * strideC_out + j) * PW);
   }
 }
 
@@ -1171,10 +1202,13 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
       uint32_t* C_out = (uint32_t*)ws.buf[flip ? WS_C1 : WS_C0];
       uint32_t threads = JA + JC;
       if (k == 1)
-        hipLaunchKernelGGL((msm_tail_pair_kernel<G>), dim3(MsmItems<G>::grid(std::max(JA, JC)), Wg, 3), dim3(64), 0, st, A_in, mA, strideA_in, C_in,
+        hipLaunchKernelGGL((msm_tail_pair_kernel<G>), dim3(MsmPairItems<G>::grid(std::max(JA, JC)), Wg, 3), dim3(64), 0, st, A_in, mA, strideA_in, C_in,
                            mC, strideC_in, A_out, strideAC, C_out, strideAC);
+      else if (threads <= (1u << 15))
+        hipLaunchKernelGGL((msm_tail_level_kernel<G, true>), dim3(MsmPairItems<G, true>::grid(threads), Wg), dim3(64), 0, st, A_in, mA, strideA_in, C_in, mC,
+                           strideC_in, A_out, strideAC, C_out, strideAC, k);
       else
-        hipLaunchKernelGGL((msm_tail_level_kernel<G>), dim3(MsmItems<G>::grid(threads), Wg), dim3(64), 0, st, A_in, mA, strideA_in, C_in, mC,
+        hipLaunchKernelGGL((msm_tail_level_kernel<G, false>), dim3(MsmPairItems<G, false>::grid(threads), Wg), dim3(64), 0, st, A_in, mA, strideA_in, C_in, mC,
                            strideC_in, A_out, strideAC, C_out, strideAC, k);
       mA = JA ? JA - 1 : 0;
       mC = JC + JA;

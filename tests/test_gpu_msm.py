@@ -234,5 +234,9 @@ def test_submit_collect_pipelined(co, gpu_ctx):
     t = ctx.msm_submit(b1, bb, n=64)
     with pytest.raises(Exception):
         ctx.msm_collect(t)
+    with pytest.raises(Exception):
+        ctx.msm(b1, bb, n=64)                  # the one-at-a-time entry points report it too (PCDHIP_E_ARG)
+    with pytest.raises(Exception):
+        ctx.msm(b1, bad, n=64)
     for h in (b1, b2, sb, bb):
         h.free()
