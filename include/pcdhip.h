@@ -112,7 +112,8 @@ int pcdhip_msm_collect(pcdhip_ctx* ctx, int ticket, uint64_t* out_xyz_mont);
  * computation, so the one-time cost amortises over every step):
  *   -1 (default) one copy per scalar window: a single bucket window, no doubling chain at all;
  *    0           none (W bucket windows + Horner combine, as upstream);   k >= 2  k copies.
- * Falls back to fewer copies when device memory does not suffice. */
+ * Falls back to fewer copies when device memory does not suffice (the Horner combine comes back for the windows that share a
+ * copy); pcdhip_bases_info reports the number of copies a handle actually holds, so the fallback is never silent. */
 int pcdhip_set_precompute(pcdhip_ctx* ctx, int mode);
 /* The plan an MSM of n pairs over these bases runs with (n = 0: the whole vector): signed-digit window bits c, scalar
  * windows W = ceil((bits + 1) / c), and how many window-shifted copies of the vector are resident (1 = none).  bench.py
