@@ -675,72 +675,6 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
   acc.store(buckets + (size_t)key * Jac<F>::WORDS);
 }
 
-// Big buckets, two levels (all counts live on the device; grid-stride loops):
-//   A: one workgroup per segment of <= seg_len pieces -> partial[segment]      B: one workgroup per big bucket sums its partials.
-// The items of a workgroup sum strided pieces, then a tree through global scratch.
-template <class G>
-PCD_DEV void msm_wave_tree(Jac<typename MsmItems<G>::GA::F> acc, uint32_t* my /* PER_WAVE points of scratch */, uint32_t* dst) {
-  typedef typename MsmItems<G>::GA GA;
-  typedef typename GA::F F;
-  typedef EC<GA> E;
-  constexpr uint32_t PW = MsmItems<G>::PER_WAVE;
-  const uint32_t it = MsmItems<G>::local();
-  const bool live = !MsmItems<G>::idle();
-  if (live) acc.store(my + (size_t)it * Jac<F>::WORDS);
-  __syncthreads();
-  for (uint32_t s = 32; s > 0; s >>= 1) {
-    if (live && it < s && it + s < PW) {
-      Jac<F> o = Jac<F>::load(my + (size_t)(it + s) * Jac<F>::WORDS);
-      acc = E::add(acc, o);
-      acc.store(my + (size_t)it * Jac<F>::WORDS);
-    }
-    __syncthreads();
-  }
-  if (live && it == 0) acc.store(dst);
-  __syncthreads();
-}
-template <class G>
-__global__ void __launch_bounds__(64) msm_big_segments_kernel(const uint32_t* __restrict__ seg_list, const uint32_t* __restrict__ big_count,
-                                                              const uint32_t* __restrict__ piece_first, const uint32_t* __restrict__ piece_last,
-                                                              uint32_t* __restrict__ partial, uint32_t* __restrict__ scratch) {
-  typedef typename MsmItems<G>::GA GA;
-  typedef typename GA::F F;
-  typedef EC<GA> E;
-  constexpr uint32_t PW = MsmItems<G>::PER_WAVE;
-  const uint32_t nseg = big_count[1];
-  uint32_t* my = scratch + (size_t)blockIdx.x * 64 * Jac<F>::WORDS;
-  for (uint32_t sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
-    uint32_t lo = seg_list[3 * sg], hi = seg_list[3 * sg + 1], tlast = seg_list[3 * sg + 2];
-    Jac<F> acc = Jac<F>::infinity();
-    if (!MsmItems<G>::idle())
-      for (uint32_t u = lo + MsmItems<G>::local(); u <= hi; u += PW) {
-        const uint32_t* src = (u == tlast) ? piece_first : piece_last;
-        acc = E::add(acc, MsmStored<GA>::load(src + (size_t)u * MsmStored<GA>::WORDS));
-      }
-    msm_wave_tree<G>(acc, my, partial + (size_t)sg * Jac<F>::WORDS);
-  }
-}
-template <class G>
-__global__ void __launch_bounds__(64) msm_big_bucket_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count,
-                                                            const uint32_t* __restrict__ partial, uint32_t* __restrict__ buckets,
-                                                            uint32_t* __restrict__ scratch) {
-  typedef typename MsmItems<G>::GA GA;
-  typedef typename GA::F F;
-  typedef EC<GA> E;
-  constexpr uint32_t PW = MsmItems<G>::PER_WAVE;
-  const uint32_t nbig = big_count[0];
-  uint32_t* my = scratch + (size_t)blockIdx.x * 64 * Jac<F>::WORDS;
-  for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
-    uint32_t key = big_list[3 * b], s0 = big_list[3 * b + 1], ns = big_list[3 * b + 2];
-    Jac<F> acc = Jac<F>::infinity();
-    if (!MsmItems<G>::idle())
-      for (uint32_t u = MsmItems<G>::local(); u < ns; u += PW) acc = E::add(acc, Jac<F>::load(partial + (size_t)(s0 + u) * Jac<F>::WORDS));
-    msm_wave_tree<G>(acc, my, buckets + (size_t)key * Jac<F>::WORDS);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ tail: sum_d d * B_d
-// State per window: weighted array A (weights 1..mA) and plain array C;  V = WS(A) + S(C).
 // Items of the bucket-reduction levels.  Prime-field groups spend TWO lanes on every item (EC2: 8 product slots per addition
 // instead of 16 products, 5 per doubling instead of 9); the extension-field groups are spread over lanes at the field level already.
 template <class G, bool ENABLE = true>
@@ -749,6 +683,7 @@ struct MsmPairItems {
   static constexpr uint32_t LANES = TWO ? 2 : MsmItems<G>::LANES, PER_WAVE = 64 / LANES;
   PCD_DEV static bool idle() { return threadIdx.x >= PER_WAVE * LANES; }
   PCD_DEV static uint32_t item() { return blockIdx.x * PER_WAVE + threadIdx.x / LANES; }
+  PCD_DEV static uint32_t local() { return threadIdx.x / LANES; }
   PCD_DEV static bool writer() { return !TWO || (threadIdx.x & 1u) == 0; }  // (both lanes of a pair hold the whole result)
   static uint32_t grid(uint32_t items) { return (items + PER_WAVE - 1) / PER_WAVE; }
 };
@@ -766,6 +701,75 @@ struct MsmPairOps<G, true> {
   PCD_DEV static J add(const J& a, const J& b) { return EC2<G>::add2(a, b); }
   PCD_DEV static J dbl(const J& a) { return EC2<G>::dbl2(a); }
 };
+// Big buckets, two levels (all counts live on the device; grid-stride loops):
+//   A: one workgroup per segment of <= seg_len pieces -> partial[segment]      B: one workgroup per big bucket sums its partials.
+// The items of a workgroup sum strided pieces, then a tree through global scratch -- latency-bound chains of additions, so with the
+// item / operation choice of the reduction levels (two lanes per addition for the prime-field groups).
+template <class G>
+PCD_DEV void msm_wave_tree(Jac<typename MsmPairOps<G>::GA::F> acc, uint32_t* my /* PER_WAVE points of scratch */, uint32_t* dst) {
+  typedef MsmPairItems<G> IT;
+  typedef MsmPairOps<G> O;
+  typedef typename O::GA::F F;
+  constexpr uint32_t PW = IT::PER_WAVE;
+  const uint32_t it = IT::local();
+  const bool live = !IT::idle();
+  if (live && IT::writer()) acc.store(my + (size_t)it * Jac<F>::WORDS);
+  __syncthreads();
+  for (uint32_t s = 32; s > 0; s >>= 1) {
+    if (live && it < s && it + s < PW) {
+      Jac<F> o = Jac<F>::load(my + (size_t)(it + s) * Jac<F>::WORDS);
+      acc = O::add(acc, o);
+      if (IT::writer()) acc.store(my + (size_t)it * Jac<F>::WORDS);
+    }
+    __syncthreads();
+  }
+  if (live && it == 0 && IT::writer()) acc.store(dst);
+  __syncthreads();
+}
+template <class G>
+__global__ void __launch_bounds__(64) msm_big_segments_kernel(const uint32_t* __restrict__ seg_list, const uint32_t* __restrict__ big_count,
+                                                              const uint32_t* __restrict__ piece_first, const uint32_t* __restrict__ piece_last,
+                                                              uint32_t* __restrict__ partial, uint32_t* __restrict__ scratch) {
+  typedef MsmPairItems<G> IT;
+  typedef MsmPairOps<G> O;
+  typedef typename O::GA GA;
+  typedef typename GA::F F;
+  constexpr uint32_t PW = IT::PER_WAVE;
+  const uint32_t nseg = big_count[1];
+  uint32_t* my = scratch + (size_t)blockIdx.x * 64 * Jac<F>::WORDS;
+  for (uint32_t sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
+    uint32_t lo = seg_list[3 * sg], hi = seg_list[3 * sg + 1], tlast = seg_list[3 * sg + 2];
+    Jac<F> acc = Jac<F>::infinity();
+    if (!IT::idle())
+      for (uint32_t u = lo + IT::local(); u <= hi; u += PW) {
+        const uint32_t* src = (u == tlast) ? piece_first : piece_last;
+        acc = O::add(acc, MsmStored<GA>::load(src + (size_t)u * MsmStored<GA>::WORDS));
+      }
+    msm_wave_tree<G>(acc, my, partial + (size_t)sg * Jac<F>::WORDS);
+  }
+}
+template <class G>
+__global__ void __launch_bounds__(64) msm_big_bucket_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count,
+                                                            const uint32_t* __restrict__ partial, uint32_t* __restrict__ buckets,
+                                                            uint32_t* __restrict__ scratch) {
+  typedef MsmPairItems<G> IT;
+  typedef MsmPairOps<G> O;
+  typedef typename O::GA GA;
+  typedef typename GA::F F;
+  constexpr uint32_t PW = IT::PER_WAVE;
+  const uint32_t nbig = big_count[0];
+  uint32_t* my = scratch + (size_t)blockIdx.x * 64 * Jac<F>::WORDS;
+  for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+    uint32_t key = big_list[3 * b], s0 = big_list[3 * b + 1], ns = big_list[3 * b + 2];
+    Jac<F> acc = Jac<F>::infinity();
+    if (!IT::idle())
+      for (uint32_t u = IT::local(); u < ns; u += PW) acc = O::add(acc, Jac<F>::load(partial + (size_t)(s0 + u) * Jac<F>::WORDS));
+    msm_wave_tree<G>(acc, my, buckets + (size_t)key * Jac<F>::WORDS);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ tail: sum_d d * B_d
+// State per window: weighted array A (weights 1..mA) and plain array C;  V = WS(A) + S(C).
 // One level with block size K = 2^k:  block j of A -> T_j (plain sum), L_j (weighted sum, weights 1..K)
 //   V = S(C) + S(L) + WS({K * T_j}_{j>=1});   A' = {2^k T_j}_{j>=1},  C' = blocksums(C) ++ L
 // (WIDE: two lanes per item where the group allows it -- pays when the level is latency-bound, i.e. has few items; a first level over
@@ -1149,7 +1153,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   PCD_HIP_TRY(ws.ensure(WS_PLAST, (size_t)nchunks * RB));
   uint32_t* acc_buckets = buckets;  // where whole-bucket flushes go: the bucket array itself, or (wider records) an array of their own
   if (Stored::SEPARATE) { PCD_HIP_TRY(ws.ensure(WS_ACCB, (size_t)tkeys * RB)); acc_buckets = (uint32_t*)ws.buf[WS_ACCB]; }
-  const uint32_t big_limit = 8, seg_len = 256;
+  const uint32_t big_limit = 8, seg_len = 128;  // pieces per segment: 4 per item and a 5-level tree with two lanes per addition
   const uint32_t big_cap = nchunks / big_limit + 2;   // a big bucket spans more than big_limit chunks
   const uint32_t seg_cap = nchunks / seg_len + big_cap + 2;
   PCD_HIP_TRY(ws.ensure(WS_BIG, (size_t)(3 * big_cap + 3 * seg_cap + 8) * 4));
