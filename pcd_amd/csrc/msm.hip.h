@@ -6,20 +6,19 @@
 // canonical scalars k_i.  The value is a unique group element, so the GPU is free to organise the
 // bucket method differently from upstream (which parallelises over windows only):
 //
-//   1. msm_count     digits of every scalar -> per-(window,bucket) histogram          (HBM-bound)
-//   2. scan          exclusive prefix sum of the histogram
-//   3. msm_scatter   counting sort of base indices by (window,bucket)                  (HBM-bound)
-//   4. msm_accumulate fixed-size chunks of the sorted list, one lane per chunk: every lane does the
-//                    same number of mixed additions whatever the scalar distribution; runs that
-//                    cross a chunk edge are emitted as "pieces"                        (int-VALU-bound)
-//   5. msm_fixup / msm_big_bucket   pieces of one bucket are summed (tree in LDS for big buckets)
-//   6. msm_tail_level  sum_d d*B_d per window by blocked running sums, log_K(2^c) levels
-//   7. msm_horner    windows combined by c doublings each
+//   1. sort          signed digits of every scalar -> (bucket, base index) entries sorted by bucket: an MSD partition through LDS
+//                    (msm_coarse_kernel x2, msm_bin_scan_kernel, msm_bin_sort_kernel); counting-sort and single-pass binning
+//                    variants stay selectable (msm_digits_kernel, scan_*)
+//   2. msm_accumulate fixed-size chunks of the sorted list, one lane (or 2 / 3 lanes: lane-split extension fields) per chunk:
+//                    every lane does the same number of mixed additions whatever the scalar distribution; runs that cross
+//                    a chunk edge are emitted as "pieces"; lazily reduced XYZZ accumulator for the 298-bit G1 (int-VALU-bound)
+//   3. msm_fixup / msm_big_segments / msm_big_bucket   pieces of one bucket are summed; flushed records become Jacobian points
+//   4. msm_tail_level / msm_tail_pair  sum_d d*B_d by blocked running sums, then pair levels (two lanes per group operation)
+//   5. msm_horner    windows combined by c doublings each (not needed with one precomputed copy of the bases per window)
 //
-// Zero digits never enter the sorted list (upstream skips zero scalars); a scalar equal to one is a
-// single entry in bucket (window 0, digit 1) exactly as its digits say, and its histogram / scatter
-// atomics are wave-aggregated so that bit-decomposition-heavy witnesses do not serialise on one
-// counter.
+// Zero digits never enter the sorted list (upstream skips zero scalars); scalars equal to one go, staged per workgroup, to a list
+// of their own that forms a pseudo bucket added to bucket (window 0, digit 1), so that bit-decomposition-heavy witnesses neither
+// serialise on one counter nor pile up in one chunk-straddling run of the ordinary list.
 #pragma once
 #include <cstdlib>
 #include <math.h>
@@ -448,8 +447,28 @@ struct MsmBaseStride {
   static constexpr int value = (PCD_BASE_ALIGN && W == 22) ? 32 : W;
 };
 
+// Which coordinates the running sum of a bucket run uses.  XYZZ (EC::madd_x: 8M + 2S, half the additions) wins where the arithmetic
+// is inlined or the point is spread thin over lanes -- same-box A/B of the accumulation: Fq2-298 7.07 -> 6.60 ms, Fq3-298 (split)
+// 14.8 -> 13.8 ms at 2^20, Fq2-753 (split) 19.3 -> 18.1 ms at 2^16 -- and loses where every product is a call and the fourth
+// coordinate is 27 more registers to keep alive across it: G1-753 45.5 -> 48.6 ms (2^20), Fq3-753 (split) 36.1 -> 39.0 ms (2^16).
 template <class G>
+struct MsmUseXyzz {
+  typedef typename G::F F;
+  static constexpr bool value = F::Base::INLINE_ARITH || F::DEG == 2;
+};
+// the running sum of a bucket run, flushed as it is: XYZZ (X || Y || ZZ || ZZZ, the identity as ZZ = 0) or Jacobian
+template <class G, bool XYZZ = MsmUseXyzz<G>::value>
 struct MsmRunPlain {
+  typedef typename G::F F;
+  typename EC<G>::AccX a = EC<G>::x_infinity();
+  PCD_DEV void add(const Aff<F>& q) { a = EC<G>::madd_x(a, q); }
+  PCD_DEV void flush(uint32_t* dst) {
+    a.X.store(dst); a.Y.store(dst + F::WORDS); a.ZZ.store(dst + 2 * F::WORDS); a.ZZZ.store(dst + 3 * F::WORDS);
+    a = EC<G>::x_infinity();
+  }
+};
+template <class G>
+struct MsmRunPlain<G, false> {
   typedef typename G::F F;
   Jac<F> a = Jac<F>::infinity();
   PCD_DEV void add(const Aff<F>& q) { a = EC<G>::madd(a, q); }
@@ -475,13 +494,25 @@ struct MsmRunLazy {
   }
 };
 // a point written by msm_accumulate's flush, as a reduced Jacobian point; WORDS = u32 words of one flushed record
-template <class G, bool LAZY = LazyCapable<typename G::F>::value>
-struct MsmStored {
+template <class G, bool XYZZ = MsmUseXyzz<G>::value>
+struct MsmStoredPlain {  // XYZZ record
+  typedef typename G::F F;
+  static constexpr int WORDS = EC<G>::ACCX_WORDS;
+  PCD_DEV static Jac<F> load(const uint32_t* p) {
+    typename EC<G>::AccX a = {F::load(p), F::load(p + F::WORDS), F::load(p + 2 * F::WORDS), F::load(p + 3 * F::WORDS)};
+    return EC<G>::x_to_jac(a);
+  }
+  static constexpr bool SEPARATE = true;  // flushed buckets live in their own array (four coordinates); the fix-up pass fills the bucket array
+};
+template <class G>
+struct MsmStoredPlain<G, false> {  // Jacobian record
   typedef typename G::F F;
   static constexpr int WORDS = Jac<F>::WORDS;
   PCD_DEV static Jac<F> load(const uint32_t* p) { return Jac<F>::load(p); }
   static constexpr bool SEPARATE = false;  // flushed buckets ARE the bucket array
 };
+template <class G, bool LAZY = LazyCapable<typename G::F>::value>
+struct MsmStored : MsmStoredPlain<G> {};
 template <class G>
 struct MsmStored<G, true> {
   typedef typename G::F F;

@@ -87,6 +87,36 @@ extern "C" int hc_madd_chain(int curve, const uint32_t* bases, int n, uint32_t* 
   return 0;
 }
 
+// the same chain in plain XYZZ coordinates (EC::madd_x: what the accumulation of every other group runs on) against the Jacobian madd
+template <class G>
+static void maddx_chain(const uint32_t* bases, int n, uint32_t* out) {
+  typedef typename G::F F;
+  typedef EC<G> E;
+  typename E::AccX ax = E::x_infinity();
+  Jac<F> acc = Jac<F>::infinity();
+  for (int i = 0; i < n; i++) {
+    Aff<F> p = Aff<F>::from_abi(bases + (size_t)i * Aff<F>::ABI_WORDS);
+    ax = E::madd_x(ax, p);
+    acc = E::madd(acc, p);
+  }
+  E::x_to_jac(ax).to_abi(out);
+  acc.to_abi(out + Jac<F>::ABI_WORDS);
+}
+extern "C" int hc_maddx_chain(int group_idx, const uint32_t* bases, int n, uint32_t* out) {
+  switch (group_idx) {
+    case 0: maddx_chain<G1_MNT4_298>(bases, n, out); break;
+    case 1: maddx_chain<G2_MNT4_298>(bases, n, out); break;
+    case 2: maddx_chain<G1_MNT6_298>(bases, n, out); break;
+    case 3: maddx_chain<G2_MNT6_298>(bases, n, out); break;
+    case 4: maddx_chain<G1_MNT4_753>(bases, n, out); break;
+    case 5: maddx_chain<G2_MNT4_753>(bases, n, out); break;
+    case 6: maddx_chain<G1_MNT6_753>(bases, n, out); break;
+    case 7: maddx_chain<G2_MNT6_753>(bases, n, out); break;
+    default: return -1;
+  }
+  return 0;
+}
+
 #include "../../pcd_amd/csrc/pairing.hip.h"
 template <class PC>
 static void pairing_host(const uint32_t* g1, const uint32_t* g2, uint32_t* out) {

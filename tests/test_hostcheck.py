@@ -102,3 +102,34 @@ def test_lazy_madd_chain(hc, co, cid):
         for got in (lazy, plain):
             g, ginf = co.to_affine(cid, 1, got)
             assert ginf[0] == winf[0] and np.array_equal(g, want), name
+
+
+@pytest.mark.parametrize("cid,grp", [(0, 1), (0, 2), (1, 2), (2, 1), (3, 2)])
+def test_xyzz_madd_chain(hc, co, cid, grp):
+    """EC::madd_x (mixed addition in XYZZ coordinates: the bucket-accumulation step of every group without the lazy form) against the
+    Jacobian madd and the oracle, with the doubling branch, a cancellation to infinity and infinity entries in the stream."""
+    w = co.point_words(cid, grp)
+    n = 40 if cid < 2 else 14
+    pts = co.gen_points(cid, grp, n, seed=41 + cid)
+    neg = pts[3].copy()
+    deg = w // 2 // co.FIELD_N64[co.CURVE_FQ[cid]]
+    ycoef = pts[3][w // 2:].reshape(deg, -1)
+    neg[w // 2:] = co.fp_op(co.CURVE_FQ[cid], "neg", np.ascontiguousarray(ycoef)).reshape(-1)
+    seqs = {
+        "random": pts,
+        "double": np.concatenate([pts[:1], pts[:1], pts[1:8]]),
+        "cancel": np.concatenate([pts[3:4], neg[None], pts[4:10]]),
+        "inf": np.concatenate([pts[:3], np.zeros((2, w), dtype=np.uint64), pts[3:9]]),
+    }
+    gi = 2 * cid + (grp - 1)
+    for name, seq in seqs.items():
+        seq = np.ascontiguousarray(seq)
+        out = np.zeros(2 * 3 * w // 2, dtype=np.uint64)
+        assert hc.hc_maddx_chain(gi, P(seq), seq.shape[0], P(out)) == 0
+        xyzz, plain = out[:3 * w // 2], out[3 * w // 2:]
+        sc = np.zeros((seq.shape[0], co.FIELD_N64[co.CURVE_FR[cid]]), dtype=np.uint64); sc[:, 0] = 1
+        inf = np.array([0 if r.any() else 1 for r in seq], dtype=np.uint8)
+        want, winf = co.to_affine(cid, grp, co.msm(cid, grp, seq, sc, inf=inf))
+        for got in (xyzz, plain):
+            g, ginf = co.to_affine(cid, grp, got)
+            assert ginf[0] == winf[0] and np.array_equal(g, want), name
