@@ -1054,8 +1054,25 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   pl.W = msm_num_windows(G::FR::BITS, pl.c);
   const int Wg = (pl.W + bv.groups - 1) / bv.groups;  // bucket windows
   pl.nkeys = (uint32_t)Wg << pl.c;
-  pl.chunk = chunk_override ? chunk_override : 40;  // sorted entries per lane (median-of-8 A/B on MI355X at 2^18 / 2^20, G1 and G2: 40 beats 32 by 3-5 %, 48 ties, 64 loses)
   const uint64_t maxM = (uint64_t)n * pl.W;
+  // sorted entries per lane (median-of-8 A/B on MI355X at 2^18 / 2^20, G1 and G2: 40 beats 32 by 3-5 %, 48 ties, 64 loses) -- nudged, among
+  // 40 .. 56, to the value whose wave count fills whole rounds of the chip: a one-wave-per-SIMD kernel that needs 14.4 rounds idles
+  // 60 % of the SIMDs during the last one (G1-753 at 2^20: 48 entries = 12.0 rounds, 55.5 -> 53.7 ms)
+  pl.chunk = chunk_override ? chunk_override : 40;
+  if (!chunk_override) {
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    const double slots = (double)cus * 4 * MsmAccWaves<G>::value, per_wave = 64 / SplitOf<G>::LANES;
+    double best = 1e300;
+    for (uint32_t ch = 40; ch <= 56; ch += 2) {
+      const double x = ceil(ceil((double)maxM / ch) / per_wave) / slots;
+      const double waste = ceil(x) / x;
+      if (waste < best - 0.01) { best = waste; pl.chunk = ch; }
+    }
+  }
   if (maxM >= 0xFFFFFFF0ull || (uint64_t)bv.n_total * bv.groups >= 0x7FFFFFF0ull) return hipErrorInvalidValue;  // bit 31 of an entry: sign
 
   EventSet<9> ev;

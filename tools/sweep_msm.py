@@ -14,15 +14,17 @@ pts = co.gen_points(cid, grp, n, seed=1)
 sc = co.gen_scalars(fr, n, seed=2, dist=0)
 sb = ctx.buf_upload(fr, sc)
 want = co.to_affine(cid, grp, co.msm(cid, grp, pts, sc, nthreads=32))[0]
-for c in (18, 19, 20, 21):
-    for chunk in (24, 32, 48):
+cs = [int(x) for x in os.environ.get('SWEEP_C', '19,20,21').split(',')]
+chunks = [int(x) for x in os.environ.get('SWEEP_CHUNK', '32,40,48,64').split(',')]
+for c in cs:
+    for chunk in chunks:
         ctx.msm_config(c, chunk)
         ctx.set_precompute(-1)
         b = ctx.bases_upload(cid, grp, pts)
         got = ctx.msm(b, sb)
         ok = np.array_equal(co.to_affine(cid, grp, got)[0], want)
         best = None
-        for _ in range(5):
+        for _ in range(7):
             ctx.msm(b, sb)
             tm = ctx.msm_last_timings()
             if best is None or tm["total"] < best["total"]:
