@@ -260,6 +260,7 @@ def main():
                            "one_at_a_time": {"ms_per_step": round(elapsed_sync / args.steps * 1e3, 4),
                                              "value": round(world * n_local * args.steps / elapsed_sync / 1e6, 3)}},
             "msm_stage_ms": {k: round(float(v), 4) for k, v in stages.items()},
+            "whole_step_upstream_work_rate": round(contract / (ms_per_step * 1e-3) / MAD_PEAK, 4),   # VERDICT r01's "whole step" figure: contract mads over the WHOLE step's time
             "whole_step_int_frac": round(executed / (ms_per_step * 1e-3) / MAD_PEAK, 4),   # per GPU: executed mads of the accumulate stage over the WHOLE step's time
             "cpu_baseline": cpu,
         }

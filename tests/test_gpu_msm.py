@@ -229,6 +229,18 @@ def test_submit_collect_pipelined(co, gpu_ctx):
         for (b, off, cnt), g, w in zip(jobs, got, want):
             a = co.to_affine(b.curve, b.group, g)
             assert np.array_equal(a[0], w[0]) and np.array_equal(a[1], w[1]), (off, cnt, rounds)
+    # a proof may not start while tickets are outstanding (it uses the same side streams and workspaces)
+    r = co.synthetic_r1cs(fr, 200, 2, seed=1510)
+    keys = co.groth16_setup(0, r, co.gen_field(fr, 5, seed=1511), nthreads=4)
+    rs = co.gen_field(fr, 2, seed=1512)
+    pk = ctx.g16_pk_upload(keys.host_struct(), 0)
+    t = ctx.msm_submit(b1, sb, n=1000)
+    with pytest.raises(Exception):
+        ctx.groth16_prove(pk, r, rs[0], rs[1])
+    ctx.msm_collect(t)
+    proof, _ = ctx.groth16_prove(pk, r, rs[0], rs[1])
+    assert np.array_equal(proof, co.groth16_prove(keys, r, rs[0], rs[1], nthreads=4)[0])
+    pk.free()
     bad = sc[:64].copy(); bad[3, -1] = 1 << 60
     bb = ctx.buf_upload(fr, bad)
     t = ctx.msm_submit(b1, bb, n=64)
