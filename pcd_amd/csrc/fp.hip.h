@@ -103,17 +103,74 @@ struct Fp {
     }
     return ((int32_t)d.v[N - 1] < 0) ? s : d;
   }
+  // a + b and a - b, back in [0, 2p).  Whether 2p has to come off (go on) is read from the two top limbs of the limb-wise sum
+  // (difference): with E = t[N-1] 2^28 + t[N-2] the integer is E B^(N-2) + L, 0 <= L < 2 B^(N-2) for a sum and |L| < B^(N-2) for a
+  // difference (B = 2^28), so only E in {P2 - 1, P2} (P2 = the same two limbs of 2p) resp. E = 0 leave the question open -- one pair in
+  // 2^55 for random operands, and equal operands of a subtraction -- and take the exact carry chain in a branch that is normally
+  // skipped.  One carry chain with the masked constant then normalises: 5 instructions per limb against 9 for the two parallel chains
+  // of norm_reduce (tools/isa_mix.py: 27-limb additions were 243 instructions each, 16 % of the 753-bit accumulation loop).
+  // Used for the 27-limb fields only.  Same-box A/B on MI355X (two chains -> estimate): G1-753 accumulation 12.4 -> 11.3 ms (2^18),
+  // split Fq2-753 / Fq3-753 MSMs 15.1 -> 14.5 / 30.9 -> 29.2 ms (2^15); for the inlined 11-limb code the skipped branches cost more
+  // than the shorter chains save (G1-298 unchanged, split Fq3-298 accumulation 3.90 -> 4.16 ms at 2^18), so it keeps norm_reduce.
+  static constexpr bool ESTIMATE_ADDSUB = N > 11;
+  PCD_HD static uint64_t mod2_top2() { return ((uint64_t)P::mod2(N - 1) << 28) + P::mod2(N - 2); }
   PCD_HD Fp operator+(const Fp& b) const {
-    int32_t t[N];
+    if constexpr (!ESTIMATE_ADDSUB) {
+      int32_t s[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) t[i] = (int32_t)(v[i] + b.v[i]);
-    return norm_reduce<false>(t);
+      for (int i = 0; i < N; i++) s[i] = (int32_t)(v[i] + b.v[i]);
+      return norm_reduce<false>(s);
+    }
+    uint32_t t[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = v[i] + b.v[i];
+    const uint64_t E = ((uint64_t)t[N - 1] << 28) + t[N - 2];
+    bool off = E > mod2_top2();
+    if (__builtin_expect(E + 1 - mod2_top2() < 2, 0)) {  // E in {P2 - 1, P2}: the sign of (a + b) - 2p, exactly
+      int32_t x = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++) x = (int32_t)t[i] - (int32_t)P::mod2(i) + (x >> 28);
+      off = x >= 0;
+    }
+    const uint32_t m = off ? 0xFFFFFFFFu : 0u;
+    Fp r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+      const int32_t x = (int32_t)t[i] + (int32_t)((0u - P::mod2(i)) & m) + c;
+      r.v[i] = (uint32_t)x & MASK; c = x >> 28;
+    }
+    r.v[N - 1] = t[N - 1] + ((0u - P::mod2(N - 1)) & m) + (uint32_t)c;
+    return r;
   }
-  PCD_HD Fp operator-(const Fp& b) const {  // a - b + 2p in (0, 4p)
+  PCD_HD Fp operator-(const Fp& b) const {
+    if constexpr (!ESTIMATE_ADDSUB) {  // a - b + 2p in (0, 4p)
+      int32_t s[N];
+#pragma unroll
+      for (int i = 0; i < N; i++) s[i] = (int32_t)v[i] - (int32_t)b.v[i] + (int32_t)P::mod2(i);
+      return norm_reduce<false>(s);
+    }
     int32_t t[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) t[i] = (int32_t)v[i] - (int32_t)b.v[i] + (int32_t)P::mod2(i);
-    return norm_reduce<false>(t);
+    for (int i = 0; i < N; i++) t[i] = (int32_t)v[i] - (int32_t)b.v[i];
+    const int64_t E = (int64_t)t[N - 1] * ((int64_t)1 << 28) + t[N - 2];
+    bool on = E < 0;
+    if (__builtin_expect(E == 0, 0)) {  // the sign of a - b is the carry out of the limbs below
+      int32_t c = 0;
+#pragma unroll
+      for (int i = 0; i < N - 2; i++) c = (t[i] + c) >> 28;
+      on = c < 0;
+    }
+    const uint32_t m = on ? 0xFFFFFFFFu : 0u;
+    Fp r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+      const int32_t x = t[i] + (int32_t)(P::mod2(i) & m) + c;
+      r.v[i] = (uint32_t)x & MASK; c = x >> 28;
+    }
+    r.v[N - 1] = (uint32_t)(t[N - 1] + (int32_t)(P::mod2(N - 1) & m) + c);
+    return r;
   }
   PCD_HD Fp neg() const { return zero() - *this; }
   PCD_HD Fp dbl() const { return *this + *this; }

@@ -47,6 +47,28 @@ extern "C" int hc_field_ops(int field, const uint32_t* a, const uint32_t* b, uin
   return 0;
 }
 
+// raw 28-bit-limb images (N words each, values in [0, 2p)): out = (a + b) || (a - b) for n pairs -- the operands are NOT converted,
+// so the cases the two-limb estimate of Fp::operator+ / operator- cannot decide can be hit on purpose
+template <class P_>
+static void addsub_raw(const uint32_t* a, const uint32_t* b, int n, uint32_t* out) {
+  typedef Fp<P_> F;
+  for (int k = 0; k < n; k++) {
+    const F x = F::load(a + (size_t)k * F::N), y = F::load(b + (size_t)k * F::N);
+    (x + y).store(out + (size_t)(2 * k) * F::N);
+    (x - y).store(out + (size_t)(2 * k + 1) * F::N);
+  }
+}
+extern "C" int hc_addsub_raw(int field, const uint32_t* a, const uint32_t* b, int n, uint32_t* out) {
+  switch (field) {
+    case 0: addsub_raw<F298A>(a, b, n, out); break;
+    case 1: addsub_raw<F298B>(a, b, n, out); break;
+    case 2: addsub_raw<F753A>(a, b, n, out); break;
+    case 3: addsub_raw<F753B>(a, b, n, out); break;
+    default: return -1;
+  }
+  return 0;
+}
+
 extern "C" int hc_msm_naive(int group_idx, const uint32_t* bases, const uint32_t* scalars, int n, uint32_t* out) {
   switch (group_idx) {
     case 0: msm_naive<G1_MNT4_298>(bases, scalars, n, out); break;

@@ -46,6 +46,44 @@ def test_field_ops_and_abi_conversion(hc, fid):
         assert O.unpack_fp(f, got[6:7])[0] == ((-(2 * ((a + b + b - a - a) % f.p))) * 121 * a) % f.p
 
 
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+def test_add_sub_on_every_representative(hc, fid):
+    """Fp::operator+ / operator- decide from the two top limbs whether 2p comes off / goes on and fall back to an exact carry chain
+    when those cannot tell: operands are raw device images (any representative in [0, 2p)), aimed at the undecidable band."""
+    from oracle import pyoracle as O
+    f = O.FIELDS[fid]
+    p, N, B = f.p, (11 if fid < 2 else 27), 1 << 28
+    rnd = random.Random(77 + fid)
+    lo = B ** (N - 2)                      # weight of the second limb from the top
+    pairs = []
+    def both(a, b):
+        if 0 <= a < 2 * p and 0 <= b < 2 * p:
+            pairs.append((a, b))
+    for _ in range(2000):
+        both(rnd.randrange(2 * p), rnd.randrange(2 * p))
+    for a in [0, 1, p - 1, p, p + 1, 2 * p - 1] + [rnd.randrange(2 * p) for _ in range(40)]:
+        for d in (-2 * lo, -lo - 1, -lo, -lo + 1, -3, -2, -1, 0, 1, 2, 3, lo - 1, lo, lo + 1, 2 * lo):
+            both(a, 2 * p - a + d)         # sums around 2p: the band the estimate leaves open
+            both(a, a + d)                 # differences around 0
+            both(a + d, a)
+        both(a, a); both(a, 0); both(0, a); both(a, 2 * p - 1); both(2 * p - 1, a)
+    for _ in range(300):                   # differences whose two top limbs cancel
+        a = rnd.randrange(2 * p)
+        both(a, a - (a % lo) + rnd.randrange(lo))
+        both(a, (2 * p - a) - ((2 * p - a) % lo) + rnd.randrange(lo))
+    def limbs(x):
+        return [(x >> (28 * i)) & (B - 1) for i in range(N - 1)] + [x >> (28 * (N - 1))]
+    A = np.array([limbs(a) for a, _ in pairs], dtype=np.uint32)
+    Bv = np.array([limbs(b) for _, b in pairs], dtype=np.uint32)
+    out = np.zeros((len(pairs), 2, N), dtype=np.uint32)
+    assert hc.hc_addsub_raw(fid, P(A), P(Bv), len(pairs), P(out)) == 0
+    for k, (a, b) in enumerate(pairs):
+        for j, want in enumerate((a + b - 2 * p if a + b >= 2 * p else a + b, a - b + 2 * p if a < b else a - b)):
+            got = [int(w) for w in out[k, j]]
+            assert all(w < B for w in got[:-1]), (a, b, j)
+            assert sum(w << (28 * i) for i, w in enumerate(got)) == want, (a, b, j)
+
+
 @pytest.mark.parametrize("cid", [0, 1, 2, 3])
 @pytest.mark.parametrize("grp", [1, 2])
 def test_group_law(hc, co, cid, grp):
