@@ -10,6 +10,7 @@
 // (b != 0), and pcdhip_bases_upload rewrites flagged points to it.  Coordinates live in the device-internal
 // field image (fp.hip.h); from_abi / to_abi convert at the C-ABI.
 #pragma once
+#include <type_traits>
 #include "fp.hip.h"
 
 namespace pcd {
@@ -98,6 +99,48 @@ struct SplitOf<G2Cfg2<FQ, FRP, A, NR, CURVE, true>> { typedef G2Cfg2S<FQ, FRP, A
 #endif
 template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE, bool INL>
 struct SplitOf<G2Cfg3<FQ, FRP, A, NR, CURVE, INL>> { typedef G2Cfg3S<FQ, FRP, A, NR, CURVE, INL> type; static constexpr int LANES = 3; };
+// AccOf<G>: the configuration msm_accumulate computes in -- SplitOf<G>, with the LDS-mailbox field variant (fp.hip.h, MB) where the
+// products are calls on 27-word operands (64-lane workgroups: the mailbox is per lane of ONE wave)
+#ifndef PCD_MAILBOX
+#define PCD_MAILBOX 1
+#endif
+template <class FQ, class FRP, unsigned A, int CURVE>
+struct G1CfgMB {
+  typedef Fp<FQ, false, true> F;
+  typedef FRP FR;
+  static constexpr int CURVE_ID = CURVE;
+  static constexpr int GROUP = 1;
+  PCD_HD static F mul_by_a(const F& x) { return x.mul_small(A); }
+};
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+struct G2Cfg2SMB {
+  typedef Fp2S<Fp<FQ, false, true>, NR> F;
+  typedef FRP FR;
+  static constexpr int CURVE_ID = CURVE;
+  static constexpr int GROUP = 2;
+  PCD_DEV static F mul_by_a(const F& x) { return x.mul_small(A * NR); }
+};
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+struct G2Cfg3SMB {
+  typedef Fp3S<Fp<FQ, false, true>, NR> F;
+  typedef FRP FR;
+  static constexpr int CURVE_ID = CURVE;
+  static constexpr int GROUP = 2;
+  PCD_DEV static F mul_by_a(const F& x) { return x.mul_by_au2(A); }
+};
+template <class G> struct AccOf { typedef typename SplitOf<G>::type type; };
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+struct AccOf<G2Cfg2<FQ, FRP, A, NR, CURVE, false>> {
+  typedef typename std::conditional<(PCD_MAILBOX && FQ::N > 11), G2Cfg2SMB<FQ, FRP, A, NR, CURVE>, G2Cfg2S<FQ, FRP, A, NR, CURVE, false>>::type type;
+};
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+struct AccOf<G2Cfg3<FQ, FRP, A, NR, CURVE, false>> {
+  typedef typename std::conditional<(PCD_MAILBOX && FQ::N > 11), G2Cfg3SMB<FQ, FRP, A, NR, CURVE>, G2Cfg3S<FQ, FRP, A, NR, CURVE, false>>::type type;
+};
+template <class FQ, class FRP, unsigned A, int CURVE>
+struct AccOf<G1Cfg<FQ, FRP, A, CURVE, false>> {
+  typedef typename std::conditional<(PCD_MAILBOX && FQ::N > 11), G1CfgMB<FQ, FRP, A, CURVE>, G1Cfg<FQ, FRP, A, CURVE, false>>::type type;
+};
 // SplitOfTail<G>: the same choice for the latency-bound kernels behind the accumulation (pieces, bucket reduction, combine): there
 // two lanes per point halve the latency of every level, so the inlined 298-bit Fq2 group is split as well
 template <class G> struct SplitOfTail : SplitOf<G> {};

@@ -55,16 +55,23 @@ PCD_DEF_FIELD(F753B, PCD_F753B, PCD28_F753B)
 // INL: inline the product / square into every caller (throughput kernels of the 298-bit fields) or keep ONE
 // non-inlined copy per code object (753-bit fields; and the latency-bound single-lane kernels -- proof assembly,
 // pairing -- whose loop bodies must fit the instruction cache).
-template <class P, bool INL = (P::N <= 11)>
+// MB ("mailbox", device code of 64-lane workgroups only; non-inlined variant): the operands and the result of the product / square
+// calls travel through per-lane LDS slots instead of the stack.  hipcc passes a 27-word struct argument and returns one through
+// scratch memory -- 54 words stored by the caller and loaded by the callee, 27 back -- two dependent round trips on the vector-memory
+// path per product, at one wave per SIMD with nothing to hide them behind (tools/isa_mix.py: 231 of the 301 scratch instructions
+// of the 753-bit accumulation loop were this traffic).  Through LDS the same words move with a ~100-cycle round trip and stay off
+// the counter the global loads use.  Same memory image as the plain variant.
+template <class P, bool INL = (P::N <= 11), bool MB = false>
 struct Fp {
   typedef P Params;
-  typedef Fp<P, INL> Base;
+  typedef Fp<P, INL, MB> Base;
   static constexpr int N = P::N;
   static constexpr int DEG = 1;
   static constexpr int WORDS = N;           // u32 words per element in device memory
   static constexpr int ABI_WORDS = P::N32;  // u32 words per element at the C-ABI
   static constexpr uint32_t MASK = 0x0FFFFFFFu;
   static constexpr bool INLINE_ARITH = INL;
+  static constexpr bool MAILBOX = MB;
   uint32_t v[N];
   PCD_HD static Fp zero() { Fp r; for (int i = 0; i < N; i++) r.v[i] = 0; return r; }
   PCD_HD static Fp one() { Fp r; for (int i = 0; i < N; i++) r.v[i] = P::one(i); return r; }
@@ -188,7 +195,57 @@ struct Fp {
   //  same-box A/B -- the caller then keeps every operand addressable in its frame (2 064 B against 1 408 B of scratch per lane))
   __host__ __device__ __noinline__ static Fp mul_call(Fp a, Fp b) { return mul_impl(a, b); }
   PCD_HD static Fp mul(const Fp& a, const Fp& b) {
-    if constexpr (INLINE_ARITH) return mul_impl(a, b); else return mul_call(a, b);
+    if constexpr (INLINE_ARITH) return mul_impl(a, b);
+    else {
+#if defined(__HIP_DEVICE_COMPILE__)
+      if constexpr (MB) return mb_mul(a, b);
+#endif
+      return mul_call(a, b);
+    }
+  }
+  // ---- LDS mailbox of the MB variant: 2 slots per lane, an element as MB_CH 16-byte pieces, lane-linear ([slot][piece][lane])
+  typedef uint32_t MbVec __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) MbVec* MbPtr;
+  static constexpr int MB_CH = (N + 3) / 4, MB_LANES = 64;
+  PCD_DEV static MbPtr mb_base() { __shared__ MbVec box[2 * MB_CH * MB_LANES]; return (MbPtr)box; }
+  PCD_DEV static void mb_put(MbPtr mb, int slot, const Fp& a) {
+    const unsigned l = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < MB_CH; k++) {
+      MbVec w;
+      w.x = a.v[4 * k];
+      w.y = 4 * k + 1 < N ? a.v[4 * k + 1] : 0u;
+      w.z = 4 * k + 2 < N ? a.v[4 * k + 2] : 0u;
+      w.w = 4 * k + 3 < N ? a.v[4 * k + 3] : 0u;
+      mb[(slot * MB_CH + k) * MB_LANES + l] = w;
+    }
+  }
+  PCD_DEV static Fp mb_get(MbPtr mb, int slot) { return mb_get_lane(mb, slot, threadIdx.x); }
+  PCD_DEV static Fp mb_get_lane(MbPtr mb, int slot, unsigned l) {  // the slot of another lane of the wave (lane-split extension fields)
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < MB_CH; k++) {
+      const MbVec w = mb[(slot * MB_CH + k) * MB_LANES + l];
+      r.v[4 * k] = w.x;
+      if (4 * k + 1 < N) r.v[4 * k + 1] = w.y;
+      if (4 * k + 2 < N) r.v[4 * k + 2] = w.z;
+      if (4 * k + 3 < N) r.v[4 * k + 3] = w.w;
+    }
+    return r;
+  }
+  __device__ __noinline__ static void mb_mul_call(MbPtr mb) { mb_put(mb, 0, mul_impl(mb_get(mb, 0), mb_get(mb, 1))); }
+  __device__ __noinline__ static void mb_sqr_call(MbPtr mb) { mb_put(mb, 0, sqr_impl(mb_get(mb, 0))); }
+  PCD_DEV static Fp mb_mul(const Fp& a, const Fp& b) {
+    const MbPtr mb = mb_base();
+    mb_put(mb, 0, a); mb_put(mb, 1, b);
+    mb_mul_call(mb);
+    return mb_get(mb, 0);
+  }
+  PCD_DEV static Fp mb_sqr(const Fp& a) {
+    const MbPtr mb = mb_base();
+    mb_put(mb, 0, a);
+    mb_sqr_call(mb);
+    return mb_get(mb, 0);
   }
   PCD_HD static Fp mul_impl(const Fp& a, const Fp& b) {
     uint32_t m[N];
@@ -220,7 +277,13 @@ struct Fp {
   // sums still < 2^62): N(N+1)/2 + N^2 mads instead of 2 N^2.
   __host__ __device__ __noinline__ static Fp sqr_call(Fp a) { return sqr_impl(a); }
   PCD_HD static Fp sqr_(const Fp& a) {
-    if constexpr (INLINE_ARITH) return sqr_impl(a); else return sqr_call(a);
+    if constexpr (INLINE_ARITH) return sqr_impl(a);
+    else {
+#if defined(__HIP_DEVICE_COMPILE__)
+      if constexpr (MB) return mb_sqr(a);
+#endif
+      return sqr_call(a);
+    }
   }
   PCD_HD static Fp sqr_impl(const Fp& a) {
     uint32_t m[N], a2[N];
@@ -631,6 +694,7 @@ struct Fp2S {
   PCD_DEV Fp2S dbl() const { return {c.dbl()}; }
   PCD_DEV Fp2S mul_small(unsigned k) const { return {c.mul_small(k)}; }
   PCD_DEV Fp2S operator*(const Fp2S& b) const {
+    if constexpr (F::MAILBOX) return mb_mul(b);
     const F pa = partner(c), pb = partner(b.c);
     const F npa = pa.mul_small(NR);
     const bool odd = parity() != 0;
@@ -640,6 +704,24 @@ struct Fp2S {
     return {F::dot2(x, b.c, y, pb)};
   }
   PCD_DEV Fp2S sqr() const { return *this * *this; }
+  // Mailbox form (F = the MB variant of Fp): every lane posts its coefficient of a and of b in its LDS slots; the non-inlined body
+  // reads its own and its partner's (the exchange that is 54 DPP moves above costs nothing extra here) and posts the result.
+  __device__ __noinline__ static void mb_mul_call(typename F::MbPtr mb) {
+    const unsigned l = threadIdx.x, pl = l ^ 1u;
+    const bool odd = (l & 1u) != 0;
+    const F a0 = F::mb_get_lane(mb, 0, odd ? pl : l), a1 = F::mb_get_lane(mb, 0, odd ? l : pl);
+    const F b = F::mb_get_lane(mb, 1, l), pb = F::mb_get_lane(mb, 1, pl);
+    const F y = a1.mul_small_var(odd ? 1u : NR);  // lane 0: nr a1;  lane 1: a1
+    F o;
+    F::template dot_impl<2>(o, a0, b, y, pb, a0, a0);
+    F::mb_put(mb, 0, o);
+  }
+  PCD_DEV Fp2S mb_mul(const Fp2S& b) const {
+    const typename F::MbPtr mb = F::mb_base();
+    F::mb_put(mb, 0, c); F::mb_put(mb, 1, b.c);
+    mb_mul_call(mb);
+    return {F::mb_get(mb, 0)};
+  }
   PCD_DEV static Fp2S load(const uint32_t* p) { return {F::load(p + parity() * F::WORDS)}; }
   PCD_DEV void store(uint32_t* p) const { c.store(p + parity() * F::WORDS); }
   PCD_DEV static Fp2S from_abi(const uint32_t* w) { return {F::from_abi(w + parity() * F::ABI_WORDS)}; }
@@ -754,6 +836,7 @@ struct Fp3S {
   //   own * y1 + x2 * y2 + x3 * y3   with   (y1, y2, y3) = (b_k, b_(k+2), b_(k+1)) rotated by the role,
   //   x2 = an (times nr on lanes 0, 1),  x3 = an2 (times nr on lane 0)
   PCD_DEV Fp3S operator*(const Fp3S& b) const {
+    if constexpr (F::MAILBOX) return mb_mul(b);
     const int ln = lane_next(), ln2 = lane_next2();
     const unsigned k = role();
     const F an = from_lane(c, ln), an2 = from_lane(c, ln2), bn = from_lane(b.c, ln), bn2 = from_lane(b.c, ln2);
@@ -764,7 +847,46 @@ struct Fp3S {
     return {F::dot3(c, y1, x2, y2, x3, y3)};
   }
   //   lane 0:  a0 a0 + (2 nr a1) a2      lane 1:  (2 a0) a1 + (nr a2) a2      lane 2:  a1 a1 + (2 a0) a2
+  // Mailbox forms: coefficients are posted in the lanes' LDS slots and the non-inlined bodies read the partners' directly (no
+  // ds_bpermute exchange, no data selects -- the role picks addresses)
+  __device__ __noinline__ static void mb_mul_call(typename F::MbPtr mb) {
+    const unsigned l = threadIdx.x & 63u, k = l % 3u, l0 = l - k;       // l0: the lane holding coefficient 0 of this triple
+    const unsigned k1 = k == 2 ? 0 : k + 1, k2 = k == 0 ? 2 : k - 1;    // (k + 1) mod 3, (k + 2) mod 3
+    const F a = F::mb_get_lane(mb, 0, l), an = F::mb_get_lane(mb, 0, l0 + k1), an2 = F::mb_get_lane(mb, 0, l0 + k2);
+    // own a_k meets b_0, a_(k+1) meets b_2, a_(k+2) meets b_1 on every lane (the lane formulas above)
+    const F y1 = F::mb_get_lane(mb, 1, l0), y2 = F::mb_get_lane(mb, 1, l0 + 2), y3 = F::mb_get_lane(mb, 1, l0 + 1);
+    const F x2 = an.mul_small_var(k < 2 ? NR : 1u), x3 = an2.mul_small_var(k == 0 ? NR : 1u);
+    F o;
+    F::template dot_impl<3>(o, a, y1, x2, y2, x3, y3);
+    F::mb_put(mb, 0, o);
+  }
+  __device__ __noinline__ static void mb_sqr_call(typename F::MbPtr mb) {
+    const unsigned l = threadIdx.x & 63u, k = l % 3u, l0 = l - k;
+    const unsigned k1 = k == 2 ? 0 : k + 1, k2 = k == 0 ? 2 : k - 1;
+    const F a = F::mb_get_lane(mb, 0, l), an = F::mb_get_lane(mb, 0, l0 + k1), an2 = F::mb_get_lane(mb, 0, l0 + k2);
+    //   lane 0:  a0 a0 + (2 nr a1) a2      lane 1:  (2 a0) a1 + (nr a2) a2      lane 2:  a1 a1 + (2 a0) a2
+    const F x1 = sel(k == 0, a, an2).mul_small_var(k == 1 ? 2u : 1u);
+    const F y1 = sel(k == 2, an2, a);
+    const F x2 = an.mul_small_var(k == 0 ? 2 * NR : (k == 1 ? NR : 2));
+    const F y2 = sel(k == 0, an2, sel(k == 1, an, a));
+    F o;
+    F::template dot_impl<2>(o, x1, y1, x2, y2, x1, x1);
+    F::mb_put(mb, 0, o);
+  }
+  PCD_DEV Fp3S mb_mul(const Fp3S& b) const {
+    const typename F::MbPtr mb = F::mb_base();
+    F::mb_put(mb, 0, c); F::mb_put(mb, 1, b.c);
+    mb_mul_call(mb);
+    return {F::mb_get(mb, 0)};
+  }
+  PCD_DEV Fp3S mb_sqr() const {
+    const typename F::MbPtr mb = F::mb_base();
+    F::mb_put(mb, 0, c);
+    mb_sqr_call(mb);
+    return {F::mb_get(mb, 0)};
+  }
   PCD_DEV Fp3S sqr() const {
+    if constexpr (F::MAILBOX) return mb_sqr();
     const int ln = lane_next(), ln2 = lane_next2();
     const unsigned k = role();
     const F an = from_lane(c, ln), an2 = from_lane(c, ln2);

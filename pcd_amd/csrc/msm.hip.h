@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
                                                             uint32_t* __restrict__ piece_first, uint32_t* __restrict__ piece_last) {
   // GA: the configuration the arithmetic runs in -- G itself, or its lane-split form (Fq2 over lane pairs, Fq3 over lane triples:
   // the lanes of a group share one chunk, each holding one coefficient of every coordinate; memory images are the same)
-  typedef typename SplitOf<G>::type GA;
+  typedef typename AccOf<G>::type GA;
   typedef typename GA::F F;
   typedef EC<GA> E;
   constexpr int RW = MsmStored<GA>::WORDS;  // u32 words of a flushed record (`buckets` here = the array the flushes go to)
