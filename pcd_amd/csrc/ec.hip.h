@@ -143,7 +143,19 @@ struct AccOf<G1Cfg<FQ, FRP, A, CURVE, false>> {
 };
 // SplitOfTail<G>: the same choice for the latency-bound kernels behind the accumulation (pieces, bucket reduction, combine): there
 // two lanes per point halve the latency of every level, so the inlined 298-bit Fq2 group is split as well
-template <class G> struct SplitOfTail : SplitOf<G> {};
+// (and the 753-bit groups compute in their mailbox variants there too: all of these kernels run 64-lane workgroups)
+#ifndef PCD_MAILBOX_TAIL
+#define PCD_MAILBOX_TAIL 1
+#endif
+template <class G> struct SplitOfTail { typedef typename std::conditional<(PCD_MAILBOX_TAIL != 0), typename AccOf<G>::type, typename SplitOf<G>::type>::type type;
+                                        static constexpr int LANES = SplitOf<G>::LANES; };
+#ifndef PCD_MAILBOX_TAIL_FQ3
+#define PCD_MAILBOX_TAIL_FQ3 0
+#endif
+#if !PCD_MAILBOX_TAIL_FQ3
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE, bool INL>
+struct SplitOfTail<G2Cfg3<FQ, FRP, A, NR, CURVE, INL>> : SplitOf<G2Cfg3<FQ, FRP, A, NR, CURVE, INL>> {};
+#endif
 template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
 struct SplitOfTail<G2Cfg2<FQ, FRP, A, NR, CURVE, true>> { typedef G2Cfg2S<FQ, FRP, A, NR, CURVE, true> type; static constexpr int LANES = 2; };
 

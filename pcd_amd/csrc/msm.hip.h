@@ -727,10 +727,10 @@ struct MsmPairOps {
 };
 template <class G>
 struct MsmPairOps<G, true> {
-  typedef G GA;
-  typedef Jac<typename G::F> J;
-  PCD_DEV static J add(const J& a, const J& b) { return EC2<G>::add2(a, b); }
-  PCD_DEV static J dbl(const J& a) { return EC2<G>::dbl2(a); }
+  typedef typename SplitOfTail<G>::type GA;  // G itself, or its mailbox variant (753-bit)
+  typedef Jac<typename GA::F> J;
+  PCD_DEV static J add(const J& a, const J& b) { return EC2<GA>::add2(a, b); }
+  PCD_DEV static J dbl(const J& a) { return EC2<GA>::dbl2(a); }
 };
 // Big buckets, two levels (all counts live on the device; grid-stride loops):
 //   A: one workgroup per segment of <= seg_len pieces -> partial[segment]      B: one workgroup per big bucket sums its partials.
