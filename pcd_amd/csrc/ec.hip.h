@@ -128,18 +128,30 @@ struct G2Cfg3SMB {
   static constexpr int GROUP = 2;
   PCD_DEV static F mul_by_a(const F& x) { return x.mul_by_au2(A); }
 };
-template <class G> struct AccOf { typedef typename SplitOf<G>::type type; };
+template <class G> struct AccOf { typedef typename SplitOf<G>::type type; static constexpr int LANES = SplitOf<G>::LANES; };
+// (tried and left off: the 298-bit Fq2 twist accumulated in the split mailbox form at 2 / 3 waves per SIMD instead of inlined at one --
+//  same-box A/B at 2^20: accumulation 6.33 -> 7.21 / 7.75 ms; an 11-limb product is too short to carry a call and six LDS posts)
+#ifndef PCD_FQ2_298_MB
+#define PCD_FQ2_298_MB 0
+#endif
+#if PCD_FQ2_298_MB
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
+struct AccOf<G2Cfg2<FQ, FRP, A, NR, CURVE, true>> { typedef G2Cfg2SMB<FQ, FRP, A, NR, CURVE> type; static constexpr int LANES = 2; };
+#endif
 template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
 struct AccOf<G2Cfg2<FQ, FRP, A, NR, CURVE, false>> {
   typedef typename std::conditional<(PCD_MAILBOX && FQ::N > 11), G2Cfg2SMB<FQ, FRP, A, NR, CURVE>, G2Cfg2S<FQ, FRP, A, NR, CURVE, false>>::type type;
+  static constexpr int LANES = 2;
 };
 template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE>
 struct AccOf<G2Cfg3<FQ, FRP, A, NR, CURVE, false>> {
   typedef typename std::conditional<(PCD_MAILBOX && FQ::N > 11), G2Cfg3SMB<FQ, FRP, A, NR, CURVE>, G2Cfg3S<FQ, FRP, A, NR, CURVE, false>>::type type;
+  static constexpr int LANES = 3;
 };
 template <class FQ, class FRP, unsigned A, int CURVE>
 struct AccOf<G1Cfg<FQ, FRP, A, CURVE, false>> {
   typedef typename std::conditional<(PCD_MAILBOX && FQ::N > 11), G1CfgMB<FQ, FRP, A, CURVE>, G1Cfg<FQ, FRP, A, CURVE, false>>::type type;
+  static constexpr int LANES = 1;
 };
 // SplitOfTail<G>: the same choice for the latency-bound kernels behind the accumulation (pieces, bucket reduction, combine): there
 // two lanes per point halve the latency of every level, so the inlined 298-bit Fq2 group is split as well
@@ -147,8 +159,10 @@ struct AccOf<G1Cfg<FQ, FRP, A, CURVE, false>> {
 #ifndef PCD_MAILBOX_TAIL
 #define PCD_MAILBOX_TAIL 1
 #endif
-template <class G> struct SplitOfTail { typedef typename std::conditional<(PCD_MAILBOX_TAIL != 0), typename AccOf<G>::type, typename SplitOf<G>::type>::type type;
-                                        static constexpr int LANES = SplitOf<G>::LANES; };
+template <class G> struct SplitOfTail {
+  typedef typename std::conditional<(PCD_MAILBOX_TAIL != 0 && AccOf<G>::LANES == SplitOf<G>::LANES), typename AccOf<G>::type, typename SplitOf<G>::type>::type type;
+  static constexpr int LANES = SplitOf<G>::LANES;
+};
 #ifndef PCD_MAILBOX_TAIL_FQ3
 #define PCD_MAILBOX_TAIL_FQ3 0
 #endif

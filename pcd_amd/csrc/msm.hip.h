@@ -537,14 +537,18 @@ struct MsmStored<G, true> {
 // split Fq2-753 34.9 -> 31.3 ms (2^17), Fq3-298 29.9 -> 25.2 ms (2^20), Fq2-298 7.85 -> 7.44 ms (2^20).
 template <class G>
 struct MsmAccWaves {
-  typedef typename SplitOf<G>::type::F FA;
+  typedef typename AccOf<G>::type::F FA;
 #ifndef PCD_ACC_WAVES_SPLIT
 #define PCD_ACC_WAVES_SPLIT 2
 #endif
 #ifndef PCD_ACC_WAVES_G1
 #define PCD_ACC_WAVES_G1 2
 #endif
-  static constexpr int value = !FA::Base::INLINE_ARITH ? 1 : FA::DEG == 1 ? PCD_ACC_WAVES_G1 : SplitOf<G>::LANES > 1 ? PCD_ACC_WAVES_SPLIT : 1;
+#ifndef PCD_ACC_WAVES_MB298
+#define PCD_ACC_WAVES_MB298 2
+#endif
+  static constexpr int value = !FA::Base::INLINE_ARITH ? (FA::Base::N <= 11 ? PCD_ACC_WAVES_MB298 : 1)
+                             : FA::DEG == 1 ? PCD_ACC_WAVES_G1 : AccOf<G>::LANES > 1 ? PCD_ACC_WAVES_SPLIT : 1;
 };
 
 // COMPACT: the entries form one list (`sorted_idx`, the scalars equal to one possibly in their own list `ones_idx` behind it), so
@@ -561,7 +565,7 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
   typedef typename GA::F F;
   typedef EC<GA> E;
   constexpr int RW = MsmStored<GA>::WORDS;  // u32 words of a flushed record (`buckets` here = the array the flushes go to)
-  constexpr uint32_t LANES = SplitOf<G>::LANES, PER_WAVE = 64 / LANES;  // chunks per 64-lane workgroup (three lanes per point: 21, lane 63 idles)
+  constexpr uint32_t LANES = AccOf<G>::LANES, PER_WAVE = 64 / LANES;  // chunks per 64-lane workgroup (three lanes per point: 21, lane 63 idles)
   if (threadIdx.x >= PER_WAVE * LANES) return;
   uint32_t t = blockIdx.x * PER_WAVE + threadIdx.x / LANES;
   const uint32_t M = off[nkeys];  // total sorted entries: read on the device, the host never waits for it
@@ -930,8 +934,10 @@ __global__ void __launch_bounds__(64) jac_internal_to_abi_kernel(const uint32_t*
 // between two copies; key upload of BASELINE configs[2] 20.7 s).
 template <class G>
 __global__ void __launch_bounds__(64) msm_precompute_kernel(uint32_t* __restrict__ pts, uint32_t n, int groups, int shift) {
-  typedef typename G::F F;
-  typedef EC<G> E;
+  // (one lane per point here: the 753-bit G1 computes in its mailbox variant, the extension-field groups in their plain form)
+  typedef typename std::conditional<AccOf<G>::LANES == 1, typename AccOf<G>::type, G>::type GP;
+  typedef typename GP::F F;
+  typedef EC<GP> E;
   constexpr int BLK = (F::Base::N > 11 || F::DEG > 1) ? 4 : 8;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1065,7 +1071,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
       int dev = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
-    const double slots = (double)cus * 4 * MsmAccWaves<G>::value, per_wave = 64 / SplitOf<G>::LANES;
+    const double slots = (double)cus * 4 * MsmAccWaves<G>::value, per_wave = 64 / AccOf<G>::LANES;
     double best = 1e300;
     for (uint32_t ch = 40; ch <= 56; ch += 2) {
       const double x = ceil(ceil((double)maxM / ch) / per_wave) / slots;
@@ -1217,7 +1223,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   PCD_HIP_TRY(hipMemsetAsync(big_count, 0, 8, st));
   PCD_HIP_TRY(mark(8));  // the accumulate stage time is the kernel alone (mark 8 -> mark 4)
   {
-    constexpr uint32_t per_wave = 64 / SplitOf<G>::LANES;  // chunks per workgroup
+    constexpr uint32_t per_wave = 64 / AccOf<G>::LANES;  // chunks per workgroup
     const dim3 acc_grid((nchunks + per_wave - 1) / per_wave);
     // (with per-bucket slots both instantiations are queued: the device's overflow flag decides which of them does the work)
     if (src.slots) hipLaunchKernelGGL((msm_accumulate_kernel<G, false>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast);
