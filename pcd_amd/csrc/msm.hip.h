@@ -454,7 +454,13 @@ struct MsmBaseStride {
 template <class G>
 struct MsmUseXyzz {
   typedef typename G::F F;
-  static constexpr bool value = F::Base::INLINE_ARITH || F::DEG == 2;
+// (PCD_XYZZ_753: XYZZ for the 27-limb G1 / Fq3 groups as well.  Re-measured after the LDS mailbox, same-box A/B: G1-753 accumulation
+//  27.2 -> 26.2 ms at 2^20 but the fix-up pass 1.29 -> 1.73 ms (four-coordinate records to convert): MSM 33.6 -> 33.1 ms; split Fq3-753
+//  at 2^16 16.0 -> 15.0 ms and 2.3 -> 3.5 ms: 28.5 -> 28.7 ms.  Left off.)
+#ifndef PCD_XYZZ_753
+#define PCD_XYZZ_753 0
+#endif
+  static constexpr bool value = F::Base::INLINE_ARITH || F::DEG == 2 || (PCD_XYZZ_753 && F::Base::N > 11);
 };
 // the running sum of a bucket run, flushed as it is: XYZZ (X || Y || ZZ || ZZZ, the identity as ZZ = 0) or Jacobian
 template <class G, bool XYZZ = MsmUseXyzz<G>::value>
