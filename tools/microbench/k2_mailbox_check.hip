@@ -47,6 +47,37 @@ __global__ void __launch_bounds__(64) check(uint32_t* bad, int rounds, int lanes
   }
 }
 
+// msm_merge_ones_kernel verbatim, on a given configuration: bucket[1] += bucket[key]
+template <class GA, bool CANON>
+__global__ void __launch_bounds__(64) merge_like(uint32_t* __restrict__ buckets, uint32_t key) {
+  typedef typename GA::F F;
+  if (blockIdx.x != 0 || threadIdx.x >= F::LANES) return;
+  Jac<F> a = Jac<F>::load(buckets + (size_t)1 * Jac<F>::WORDS);
+  Jac<F> b = Jac<F>::load(buckets + (size_t)key * Jac<F>::WORDS);
+  Jac<F> r = EC<GA>::add(a, b);
+  if (CANON) { r.X = F{r.X.c.canonical()}; r.Y = F{r.Y.c.canonical()}; r.Z = F{r.Z.c.canonical()}; }  // (values, not representatives)
+  r.store(buckets + (size_t)1 * Jac<F>::WORDS);
+}
+template <class GS, class GM, bool CANON> static void run_merge(const char* name) {
+  typedef typename GS::F FS;
+  constexpr int PW = Jac<FS>::WORDS;
+  std::vector<uint32_t> h(8 * PW);
+  uint32_t s = 4242u;
+  for (auto& w : h) { s = s * 1664525u + 1013904223u; w = (s >> 4) & 0x0FFFFFFFu; }
+  for (int i = 0; i < 8 * PW; i += FS::Base::N) h[i + FS::Base::N - 1] &= 0xFFFFu;
+  uint32_t *d1, *d2; (void)hipMalloc(&d1, h.size() * 4); (void)hipMalloc(&d2, h.size() * 4);
+  (void)hipMemcpy(d1, h.data(), h.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(d2, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL((merge_like<GS, CANON>), dim3(1), dim3(64), 0, 0, d1, 5u);
+  hipLaunchKernelGGL((merge_like<GM, CANON>), dim3(1), dim3(64), 0, 0, d2, 5u);
+  std::vector<uint32_t> r1(h.size()), r2(h.size());
+  (void)hipMemcpy(r1.data(), d1, h.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(r2.data(), d2, h.size() * 4, hipMemcpyDeviceToHost);
+  int diff = 0; for (size_t i = 0; i < h.size(); i++) diff += r1[i] != r2[i];
+  printf("%s merge-like kernel: %d differing words of %d (plain vs mailbox)\n", name, diff, PW);
+  for (int c = 0; c < 3 * FS::DEG; c++) { int dd = 0; for (int i = 0; i < FS::Base::N; i++) dd += r1[PW + c * FS::Base::N + i] != r2[PW + c * FS::Base::N + i]; printf("  element %d: %d", c, dd);
+    if (dd && dd <= 3) for (int i = 0; i < FS::Base::N; i++) if (r1[PW + c * FS::Base::N + i] != r2[PW + c * FS::Base::N + i]) printf("   limb %d: %08x vs %08x", i, r1[PW + c * FS::Base::N + i], r2[PW + c * FS::Base::N + i]);
+    printf("\n"); }
+  (void)hipFree(d1); (void)hipFree(d2);
+}
 template <class GS, class GM> static void run(const char* name, int lanes_used) {
   uint32_t* bad; (void)hipMalloc(&bad, 32); (void)hipMemset(bad, 0, 32);
   hipLaunchKernelGGL((check<GS, GM>), dim3(8), dim3(64), 0, 0, bad, 8, lanes_used);
@@ -56,6 +87,11 @@ template <class GS, class GM> static void run(const char* name, int lanes_used) 
 }
 int main() {
   run<G2Cfg3S<F753B, F753A, PCD_MNT6_753_A_SMALL, PCD_MNT6_753_NR_SMALL, 3, false>, G2Cfg3SMB<F753B, F753A, PCD_MNT6_753_A_SMALL, PCD_MNT6_753_NR_SMALL, 3>>("Fq3-753 split", 63);
+  run<G2Cfg3S<F753B, F753A, PCD_MNT6_753_A_SMALL, PCD_MNT6_753_NR_SMALL, 3, false>, G2Cfg3SMB<F753B, F753A, PCD_MNT6_753_A_SMALL, PCD_MNT6_753_NR_SMALL, 3>>("Fq3-753 split, one item", 3);
+  run<G2Cfg3S<F753B, F753A, PCD_MNT6_753_A_SMALL, PCD_MNT6_753_NR_SMALL, 3, false>, G2Cfg3SMB<F753B, F753A, PCD_MNT6_753_A_SMALL, PCD_MNT6_753_NR_SMALL, 3>>("Fq3-753 split, ten items", 30);
   run<G2Cfg2S<F753A, F753B, PCD_MNT4_753_A_SMALL, PCD_MNT4_753_NR_SMALL, 2, false>, G2Cfg2SMB<F753A, F753B, PCD_MNT4_753_A_SMALL, PCD_MNT4_753_NR_SMALL, 2>>("Fq2-753 split", 64);
+  run_merge<G2Cfg3S<F753B, F753A, PCD_MNT6_753_A_SMALL, PCD_MNT6_753_NR_SMALL, 3, false>, G2Cfg3SMB<F753B, F753A, PCD_MNT6_753_A_SMALL, PCD_MNT6_753_NR_SMALL, 3>, true>("Fq3-753 canonical");
+  run_merge<G2Cfg3S<F753B, F753A, PCD_MNT6_753_A_SMALL, PCD_MNT6_753_NR_SMALL, 3, false>, G2Cfg3SMB<F753B, F753A, PCD_MNT6_753_A_SMALL, PCD_MNT6_753_NR_SMALL, 3>, false>("Fq3-753 as stored");
+  run_merge<G2Cfg2S<F753A, F753B, PCD_MNT4_753_A_SMALL, PCD_MNT4_753_NR_SMALL, 2, false>, G2Cfg2SMB<F753A, F753B, PCD_MNT4_753_A_SMALL, PCD_MNT4_753_NR_SMALL, 2>, false>("Fq2-753 as stored");
   return 0;
 }
