@@ -76,6 +76,9 @@ template <class GS, class GM, bool CANON> static void run_merge(const char* name
   for (int c = 0; c < 3 * FS::DEG; c++) { int dd = 0; for (int i = 0; i < FS::Base::N; i++) dd += r1[PW + c * FS::Base::N + i] != r2[PW + c * FS::Base::N + i]; printf("  element %d: %d", c, dd);
     if (dd && dd <= 3) for (int i = 0; i < FS::Base::N; i++) if (r1[PW + c * FS::Base::N + i] != r2[PW + c * FS::Base::N + i]) printf("   limb %d: %08x vs %08x", i, r1[PW + c * FS::Base::N + i], r2[PW + c * FS::Base::N + i]);
     printf("\n"); }
+  // the limbs of the first Y coefficient in both forms (to be checked against each other mod p off line)
+  printf("  Y.c0 plain  :"); for (int i = 0; i < FS::Base::N; i++) printf(" %08x", r1[PW + 3 * FS::Base::N + i]); printf("\n");
+  printf("  Y.c0 mailbox:"); for (int i = 0; i < FS::Base::N; i++) printf(" %08x", r2[PW + 3 * FS::Base::N + i]); printf("\n");
   (void)hipFree(d1); (void)hipFree(d2);
 }
 template <class GS, class GM> static void run(const char* name, int lanes_used) {
