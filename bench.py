@@ -11,9 +11,13 @@ Every prove is timed as the median of 5 and its proof bytes are compared with th
 One "step" = one variable-base MSM with bases AND scalars already resident in HBM (pcdhip_msm_dev); the Jacobian result
 returns to the host.  With N GPUs (one process per GPU, RCCL) the pairs are sharded by point range and the only exchange is an
 all-gather of one Jacobian point per rank + a local EC-add kernel:
-  default   weak scaling: 2^20 pairs PER GPU (`scaling: weak`; on one GPU four independent steps are in flight at a time through
-            pcdhip_msm_submit / collect, and the same steps one at a time are reported next to it); the line also carries `strong` -- the same exchange with a
-            fixed TOTAL of 2^20 and of 2^22 pairs split over the N ranks
+  default   weak scaling: 2^20 pairs PER GPU (`scaling: weak`; at EVERY world size four independent steps are in flight at a time --
+            pcdhip_msm_submit / collect on one GPU, pcdhip_msm_submit_partial + the RCCL exchange of earlier steps on N -- and the
+            same steps one at a time are reported next to it); the line also carries `strong` -- the same exchange with a
+            fixed TOTAL of 2^20 and of 2^22 pairs split over the N ranks, for MNT4-298 G1 and (BASELINE configs[4]) MNT4-753 G1
+  also in the line (N = 1): `fft` (per-pass HBM GB/s and multiply-add fraction of the radix-2 passes at 2^20, both scalar fields), `pairing`
+            (Groth16 verification latency, single and batch of 8, beside the CPU oracle on 1 and 8 cores), the witness map alone, and
+            the G2 / whole-step multiply-add fractions of the 753-bit step
   --strong  the fixed-total run (2^--log-n pairs, default 2^20) is the headline value (`scaling: strong`)
 
     python bench.py --gpus 1 --steps 20 --warmup 3
@@ -117,22 +121,24 @@ def main():
         to the host inside the timed region; the bucket reduction of one step overlaps the accumulation of the next."""
         ctx.msm_profile(False)
         step = (lambda: exchange.msm(bases, sbuf)) if use_dist else (lambda: ctx.msm(bases, sbuf))
+        submit = (lambda: exchange.submit(bases, sbuf)) if use_dist else (lambda: ctx.msm_submit(bases, sbuf))
+        collect = exchange.collect if use_dist else ctx.msm_collect
         res = None
         for _ in range(warmup):
             res = step()
-        if depth > 1 and not use_dist:   # the side streams' workspaces are allocated on first use: outside the timed region
-            for t in [ctx.msm_submit(bases, sbuf) for _ in range(depth)]:
-                res = ctx.msm_collect(t)
+        if depth > 1:   # the side streams' workspaces are allocated on first use: outside the timed region
+            for t in [submit() for _ in range(depth)]:
+                res = collect(t)
         barrier()
         t0 = time.perf_counter()
-        if depth > 1 and not use_dist:
+        if depth > 1:
             pending = []
             for _ in range(steps):
-                pending.append(ctx.msm_submit(bases, sbuf))
+                pending.append(submit())
                 if len(pending) >= depth:
-                    res = ctx.msm_collect(pending.pop(0))
+                    res = collect(pending.pop(0))
             while pending:
-                res = ctx.msm_collect(pending.pop(0))
+                res = collect(pending.pop(0))
         else:
             for _ in range(steps):
                 res = step()
@@ -154,18 +160,36 @@ def main():
         ctx.msm_profile(False)
         return {k: float(np.mean([a[k] for a in acc])) for k in acc[0]}
 
-    def strong_run(log_total, steps, warmup):
-        """fixed TOTAL of 2^log_total pairs, rank r holding the point range [r n / N, (r + 1) n / N) of the key"""
+    strong_cache = {}
+
+    def strong_run(log_total, steps, warmup, curve=CURVE):
+        """fixed TOTAL of 2^log_total pairs, rank r holding the point range [r n / N, (r + 1) n / N) of the key; one MSM at a time
+        (the latency of ONE large MSM is what splitting it over the GPUs is for).  curve 2 = MNT4-753 G1: BASELINE configs[4]."""
+        nonlocal exchange
         per = (1 << log_total) // world
-        p = pts[:per] if per <= n else co.gen_points(CURVE, GROUP, per, seed=SEED + 77 + rank)
-        s = sc[:per] if per <= n else co.gen_scalars(fr, per, seed=SEED + 1077 + rank, dist=args.dist)
-        b = ctx.bases_upload(CURVE, GROUP, p)
-        sb = ctx.buf_upload(fr, s)
+        cfr = co.CURVE_FR[curve]
+        if curve == CURVE and per <= n:
+            p, s = pts[:per], sc[:per]
+        else:
+            big = strong_cache.get(curve)
+            if big is None or big[0].shape[0] < per:   # (the 2^20 run takes a prefix of the 2^22 run's inputs)
+                big = (co.gen_points_mt(curve, GROUP, per, seed=SEED + 77 + 1000 * curve + rank),
+                       co.gen_scalars(cfr, per, seed=SEED + 1077 + 1000 * curve + rank, dist=args.dist))
+                strong_cache[curve] = big
+            p, s = big[0][:per], big[1][:per]
+        b = ctx.bases_upload(curve, GROUP, p)
+        sb = ctx.buf_upload(cfr, s)
+        saved = exchange
+        if use_dist and curve != CURVE:
+            from pcd_amd.dist import DeviceExchange
+            exchange = DeviceExchange(ctx, curve, GROUP, device)
         el, _ = timed_msm(b, sb, steps, warmup)
+        exchange = saved
         plan = ctx.bases_info(b)
         b.free(); sb.free()
-        return {"total_pairs": 1 << log_total, "pairs_per_gpu": per, "ms_per_step": round(el / steps * 1e3, 4),
-                "value": round((per * world) * steps / el / 1e6, 3), "unit": "Mscalar-mul/s", "window_bits": plan[0], "windows": plan[1]}
+        return {"curve": "MNT4-298" if curve == 0 else "MNT4-753", "total_pairs": 1 << log_total, "pairs_per_gpu": per,
+                "ms_per_step": round(el / steps * 1e3, 4), "value": round((per * world) * steps / el / 1e6, 3), "unit": "Mscalar-mul/s",
+                "window_bits": plan[0], "windows": plan[1]}
 
     headline_strong = args.strong
     if headline_strong:
@@ -180,7 +204,7 @@ def main():
     bases = ctx.bases_upload(CURVE, GROUP, pts)       # includes the one-time window-shifted precomputation
     upload_s = time.time() - t0
     sbuf = ctx.buf_upload(fr, sc)
-    depth = 1 if use_dist or args.no_pipeline else int(os.environ.get("PCD_BENCH_DEPTH", "4"))
+    depth = 1 if args.no_pipeline else int(os.environ.get("PCD_BENCH_DEPTH", "4"))   # the same at every world size
     for _ in range(10):   # let the clocks settle before the first timed region (the W warm-up steps of each region follow)
         ctx.msm(bases, sbuf)
     elapsed_sync, res = timed_msm(bases, sbuf, args.steps, args.warmup)                 # one MSM at a time: the latency view
@@ -207,11 +231,17 @@ def main():
     if not headline_strong and not args.no_strong:
         k = max(5, args.steps // 2)
         strong = {f"2^{lt}": strong_run(lt, k, 2) for lt in (20, 22)}
+        if not args.no_753:   # BASELINE configs[4]: the merge node's G1 MSM, MNT4-753, fixed totals of 2^22 and 2^20 pairs over the ranks
+            for lt in (22, 20):
+                strong[f"753_2^{lt}"] = strong_run(lt, 5, 2, curve=2)
+            strong_cache.clear()
 
     # ---- PCD step (prover arithmetic of main + help Groth16 proofs), N = 1 only
-    step_info = step_753 = None
+    step_info = step_753 = fft_info = pairing_info = None
     if rank == 0 and world == 1 and not args.no_step:
         bases.free(); sbuf.free()
+        fft_info = fft_section(ctx, co)
+        pairing_info = pairing_section(ctx, co, (0,) if args.no_753 else (0, 2))
         step_info = pcd_step(ctx, co, (("main_mnt4_298", 0, (1 << 20) - 8), ("help_mnt6_298", 1, (1 << 16) - 8)), 32)
         if not args.no_753:
             step_753 = pcd_step(ctx, co, (("main_mnt4_753", 2, (1 << 20) - 8), ("help_mnt6_753", 3, (1 << 15) + 20000)), 64, roofline_curve=2)
@@ -222,10 +252,7 @@ def main():
         acc = stages["accumulate"]
         mm, mpm, bpp = CONTRACT[CURVE]
         ach_gbs = n_local * bpp / (acc * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_msm_accumulate.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        traffic, traffic_note = traffic_from_profile()
         executed = n_local * W * madd_mads(CURVE)
         contract = n_local * mm * mpm
         out = {
@@ -241,7 +268,7 @@ def main():
                        "window_bits": c_bits, "windows": W, "upload_precompute_s": round(upload_s, 3)},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "msm_accumulate_kernel", "kernel_ms": round(acc, 4),
+                         "traffic_source": traffic_note, "kernel": "msm_accumulate_kernel", "kernel_ms": round(acc, 4),
                          "note": "algorithmic bytes = n x (40 B scalar + 80 B affine base); this kernel is integer-VALU-bound, "
                                  "not HBM-bound: see roofline_int"},
             "roofline_int": {"bound": "valu_int32_mad", "achieved": round(executed / (acc * 1e-3) / 1e12, 3),
@@ -255,8 +282,10 @@ def main():
                                                             "second over the same peak -- a speed in units of the upstream algorithm's work, "
                                                             "not a utilisation (signed digits and wider windows do less work per pair)"}},
             "pipelining": {"msms_in_flight": depth,
-                           "note": "K independent MSMs, `msms_in_flight` submitted at a time (pcdhip_msm_submit / collect); every result is read "
-                                   "back inside the timed region.  `one_at_a_time` is the same K steps with no overlap: the latency of one MSM",
+                           "note": "K independent MSMs, `msms_in_flight` submitted at a time at every world size (pcdhip_msm_submit / collect; with "
+                                   "N > 1 pcdhip_msm_submit_partial and the RCCL exchange of earlier steps); every result is read back inside the "
+                                   "timed region.  `one_at_a_time` is the same K steps with no overlap: the latency of one MSM -- the figure to "
+                                   "set beside cpu_baseline (one MSM at a time as well) and `strong`",
                            "one_at_a_time": {"ms_per_step": round(elapsed_sync / args.steps * 1e3, 4),
                                              "value": round(world * n_local * args.steps / elapsed_sync / 1e6, 3)}},
             "msm_stage_ms": {k: round(float(v), 4) for k, v in stages.items()},
@@ -266,6 +295,10 @@ def main():
         }
         if strong:
             out["strong"] = strong
+        if fft_info:
+            out["fft"] = fft_info
+        if pairing_info:
+            out["pairing"] = pairing_info
         if step_info:
             out["pcd_step"] = step_info
         if step_753:
@@ -276,6 +309,114 @@ def main():
         os.dup2(2, 1)
     if use_dist:
         dist.destroy_process_group()
+
+
+def source_sha16():
+    """identity of the kernel sources the accumulate kernel is made of (the PMC traffic figure is only valid for them)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("msm.hip.h", "ec.hip.h", "fp.hip.h"):
+        h.update(open(os.path.join(ROOT, "pcd_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_from_profile():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside this process).  The
+    file records the hash of the kernel sources it was measured on: a figure taken on other sources is NOT reported."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_msm_accumulate.json")
+    if not os.path.exists(tpath):
+        return None, "profiles/traffic_msm_accumulate.json is missing"
+    t = json.load(open(tpath))
+    if t.get("source_sha16") != source_sha16():
+        return None, (f"profiles/traffic_msm_accumulate.json was measured on kernel sources {t.get('source_sha16')}, this build is "
+                      f"{source_sha16()}: stale, not reported (re-run tools/profile.sh + tools/traffic_json.py)")
+    return t.get("hbm_bytes_per_launch"), "profiles/traffic_msm_accumulate.json (PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; same kernel sources)"
+
+
+def fft_section(ctx, co, log_n=20):
+    """Radix-2 transform passes at n = 2^20 over the two main scalar fields, resident vector, per pass: device ms (HIP events around
+    each pass), achieved HBM GB/s = 2 n s / t (one read and one write of the vector; s = 44 / 108 B device image) and the fraction
+    of the multiply-add peak its field products amount to (per element: d / 2 butterfly products of a radix-2^d pass + the
+    inter-pass twiddle + the coset factor in the first pass; 2 N^2 mads each, N = 11 / 27)."""
+    out = {"n": 1 << log_n, "transform": "coset_fft (three passes: 7 + 7 + 6 layers)", "hbm_peak_GBs": HBM_PEAK_GBS}
+    n = 1 << log_n
+    for fid, name, eb, N in ((1, "F298B (MNT4-298 Fr)", 44, 11), (3, "F753B (MNT4-753 Fr)", 108, 27)):
+        x = ctx.buf_upload(fid, co.gen_field(fid, n, seed=SEED + 40 + fid))
+        ctx.fft(fid, x)
+        runs = []
+        for _ in range(5):
+            ctx.fft(fid, x, coset=True)
+            runs.append(ctx.fft_last_timings())
+        x.free()
+        passes = [float(np.median([r[i] for r in runs])) for i in range(len(runs[0]))]
+        layers = [log_n // len(passes) + (1 if i < log_n % len(passes) else 0) for i in range(len(passes))]
+        prods = [d / 2 + 1 + (1 if i == 0 else 0) for i, d in enumerate(layers)]
+        out[name] = {"pass_ms": [round(p, 4) for p in passes], "transform_ms": round(sum(passes), 4),
+                     "pass_GBs": [round(2 * n * eb / (p * 1e-3) / 1e9, 1) for p in passes],
+                     "pass_hbm_frac": [round(2 * n * eb / (p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for p in passes],
+                     "pass_mad_frac": [round(n * k * 2 * N * N / (p * 1e-3) / MAD_PEAK, 3) for p, k in zip(passes, prods)]}
+    return out
+
+
+def pairing_section(ctx, co, curves):
+    """K6: Groth16 verification (reference call site src/ec_cycle_pcd/mod.rs:239) through process_vk + the prepared verification:
+    latency of ONE verification and of a batch of 8 (the prior messages of an arity-8 merge node), wall clock around the C-ABI
+    call (host buffers in, answers out), median of 5; beside it the CPU oracle's verify on one core and 8 proofs on 8 cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    out = {"unit": "ms", "timing": "median of 5 calls, wall clock around the C-ABI call"}
+    for cid in curves:
+        fr = co.CURVE_FR[cid]
+        r = co.synthetic_r1cs(fr, 60, 3, seed=SEED + 50 + cid)
+        keys = co.groth16_setup(cid, r, co.gen_field(fr, 5, seed=SEED + 51), nthreads=16)
+        pk = ctx.g16_pk_upload(keys.host_struct(), cid)
+        proofs = []
+        for i in range(8):
+            rs = co.gen_field(fr, 2, seed=SEED + 60 + i)
+            proofs.append(ctx.groth16_prove(pk, r, rs[0], rs[1])[0])
+        pk.free()
+        pub_m = np.ascontiguousarray(r.z[1:r.num_inputs])
+        pub = co.fp_op(fr, "to_canonical", pub_m)
+        pubs, proofs = np.stack([pub] * 8), np.stack(proofs)
+        t0 = time.perf_counter()
+        pvk = ctx.process_vk(cid, keys.alpha_g1, keys.beta_g2, keys.gamma_g2, keys.delta_g2, keys.gamma_abc_g1)
+        pvk_ms = (time.perf_counter() - t0) * 1e3
+        rho = np.random.default_rng(5).integers(1, 1 << 62, size=(8, 2), dtype=np.uint64)
+
+        def med(fn):
+            fn()
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                ok = fn()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            if not np.all(ok):
+                raise SystemExit("GPU Groth16 verification rejected a valid proof")
+            return float(np.median(ts))
+        one = med(lambda: ctx.groth16_verify_prepared(pvk, pubs[:1], proofs[:1]))
+        eight = med(lambda: ctx.groth16_verify_prepared(pvk, pubs, proofs))
+        rlc = med(lambda: ctx.groth16_verify_batch_rlc(pvk, pubs, proofs, rho))
+        bad = pubs.copy(); bad[3, 0, 0] ^= 1
+        if ctx.groth16_verify_prepared(pvk, bad, proofs)[3] or ctx.groth16_verify_batch_rlc(pvk, bad, proofs, rho):
+            raise SystemExit("GPU Groth16 verification accepted a wrong public input")
+        pvk.free()
+        cv = lambda i: co.groth16_verify(keys, pub_m, proofs[i])
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); ok1 = cv(0); ts.append((time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=8) as ex:
+            ok8 = list(ex.map(cv, range(8)))
+        cpu8 = (time.perf_counter() - t0) * 1e3
+        if not (ok1 and all(ok8)):
+            raise SystemExit("CPU oracle rejected a GPU-made proof")
+        out[co.CURVE_NAMES[cid]] = {
+            "verify_1_ms": round(one, 3), "verify_batch8_ms": round(eight, 3), "verify_batch8_shared_final_exp_ms": round(rlc, 3),
+            "process_vk_ms": round(pvk_ms, 2),
+            "cpu_baseline": {"verify_1_ms_1_core": round(float(np.median(ts)), 3), "verify_batch8_ms_8_cores": round(cpu8, 3), "kind": "port",
+                             "sample": "the oracle's Groth16 verify (3 Miller loops with e(alpha, beta) recomputed: 4 pairings' worth + 1 final "
+                                       "exponentiation) on the same proofs; 8 proofs on 8 threads, one each"},
+            "gpu_over_cpu8_batch8": round(cpu8 / eight, 2)}
+    return out
 
 
 def median_prove(ctx, pk, r, rs, reps=5):
@@ -315,6 +456,8 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None):
         r.z = capi.pinned_like(r.z)                             # the assignment is handed over in page-locked host memory
         ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)   # warm-up (FFT tables, workspaces)
         wall, proof, tm, walls = median_prove(ctx, pk, r, rs)
+        wm = [ctx.witness_map_resident(pk, r, want_h=False)[1] for _ in range(4)][1:]   # the witness map ALONE (nothing else on the device)
+        wm = {k: round(float(np.median([w[k] for w in wm])), 3) for k in wm[0]}
         forms = {}
         for mode, label in ((1, "folded"), (2, "chained")):    # the two explicit assembly forms, for the record (the default picks one)
             ctx.groth16_set_assembly(mode)
@@ -331,6 +474,7 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None):
                       "gpu_wall_ms_folded_assembly": round(forms["folded"][0], 2),
                       "gpu_wall_ms_chained_assembly": round(forms["chained"][0], 2),
                       "gpu_device_ms": {k: round(float(v), 3) for k, v in tm.items()},
+                      "witness_map_alone_ms": wm,   # standalone: inside a prove it shares the device with four MSMs (gpu_device_ms.witness_map)
                       "cpu_port_ms": round(cpu_ms, 1), "cpu_threads": threads, "domain": int(keys.domain_size),
                       "key_upload_precompute_s": round(up_s, 2), "input_gen_s": round(gen_s, 2)}
         total_gpu += wall
@@ -362,6 +506,35 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None):
                                     "executed_mads_per_pair": W * madd_mads(curve),
                                     "upstream_work_rate": round((n - 1) * mm * mpm / (acc * 1e-3) / MAD_PEAK, 4),
                                     "hbm_algorithmic_GBs": round((n - 1) * bpp / (acc * 1e-3) / 1e9, 2)}
+            # the G2 MSM of the same proof (Fq2 twist, points split over lane pairs, XYZZ running sum): 8 products + 2 squares per mixed
+            # addition, each ONE fused two-term product of 3 N^2 mads in each of the two lanes -> 60 N^2 executed mads; standalone MSM
+            # over the first 2^18 points of the key's own b_g2 query
+            n2 = 1 << 18
+            b = ctx.bases_upload(curve, 2, np.ascontiguousarray(keys.b_g2_query[:n2]))
+            sb = ctx.buf_upload(fr, co.gen_scalars(fr, n2, seed=SEED + 31))
+            ctx.msm_profile(True)
+            accs2, tots2 = [], []
+            for _ in range(4):
+                ctx.msm(b, sb)
+                t = ctx.msm_last_timings()
+                accs2.append(t["accumulate"]); tots2.append(t["total"])
+            ctx.msm_profile(False)
+            c2, W2, _ = ctx.bases_info(b)
+            b.free(); sb.free()
+            acc2 = float(np.median(accs2[1:]))
+            g2_mads = 60 * 27 * 27
+            info["roofline_int_g2"] = {"kernel": "msm_accumulate_kernel (G2 over Fq2, MNT4-753, lane-split)", "n": n2, "kernel_ms": round(acc2, 3),
+                                       "msm_total_ms": round(float(np.median(tots2[1:])), 3), "bound": "valu_int32_mad",
+                                       "achieved": round(n2 * W2 * g2_mads / (acc2 * 1e-3) / 1e12, 3), "peak": round(MAD_PEAK / 1e12, 2), "unit": "T mad/s",
+                                       "frac": round(n2 * W2 * g2_mads / (acc2 * 1e-3) / MAD_PEAK, 4), "window_bits": c2, "windows": W2,
+                                       "executed_mads_per_pair": W2 * g2_mads}
+            # the whole main proof against the same peak: executed multiply-adds of its five accumulations (h: n - 1 pairs; l', A, B1 on G1 and
+            # B on G2: m + 4 pairs each, W windows of the 2^20 plan) + the 7 transforms (3 passes each, ~5 products per element and pass),
+            # over the proof's wall time -- fix-up, bucket reduction, sorts and the assembly count as zero work
+            m4 = int(keys.a_query.shape[0]) + 4
+            work = ((n - 1) + 3 * m4) * W * madd_mads(curve) + m4 * W * g2_mads + 7 * 3 * n * 5 * 2 * 27 * 27
+            info["whole_step_int_frac"] = {"main_mnt4_753": round(work / (info[name]["gpu_wall_ms"] * 1e-3) / MAD_PEAK, 4),
+                                           "executed_mads": work, "note": "accumulations + transforms only; everything else counted as zero work"}
         if pk is not None:
             pk.free()
         del keys, r

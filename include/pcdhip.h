@@ -107,6 +107,16 @@ int pcdhip_msm_dev(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, co
 int pcdhip_msm_submit(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset, size_t n,
                       int* ticket);
 int pcdhip_msm_collect(pcdhip_ctx* ctx, int ticket, uint64_t* out_xyz_mont);
+/* The same for the shard of a process-per-GPU run: the Jacobian partial is left in device memory of the caller
+ * -- slot `*ticket` (0..3) of `out_xyz_device_slots`, four slots `slot_stride_bytes` apart: the send buffers of the RCCL
+ * all-gather -- instead of coming back to the host, and pcdhip_msm_ticket_wait makes `other_stream` (a hipStream_t: the stream the
+ * collective is enqueued on) wait for that MSM -- no host wait -- and frees the ticket.  Before a slot is written again its reader
+ * must have been ordered in front of the context's stream (pcdhip_stream_wait direction 0), which every submission follows.
+ * Several shard MSMs then overlap each other and the exchange of earlier ones, like pcdhip_msm_submit / collect on one GPU.
+ * An unreduced scalar is not reported on this path. */
+int pcdhip_msm_submit_partial(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset,
+                              size_t n, uint64_t* out_xyz_device_slots, size_t slot_stride_bytes, int* ticket);
+int pcdhip_msm_ticket_wait(pcdhip_ctx* ctx, int ticket, void* other_stream);
 /* Precomputed window-shifted copies of bases uploaded AFTER this call through this context
  * (HBM capacity traded against the serial window combine; the proving key of a PCD is fixed for the whole
  * computation, so the one-time cost amortises over every step):
@@ -115,6 +125,11 @@ int pcdhip_msm_collect(pcdhip_ctx* ctx, int ticket, uint64_t* out_xyz_mont);
  * Falls back to fewer copies when device memory does not suffice (the Horner combine comes back for the windows that share a
  * copy); pcdhip_bases_info reports the number of copies a handle actually holds, so the fallback is never silent. */
 int pcdhip_set_precompute(pcdhip_ctx* ctx, int mode);
+/* Upper bound, in bytes, on what ONE base vector uploaded afterwards through this context may occupy with its copies (0, the
+ * default: no bound other than the device's free memory).  A vector whose copies would exceed it gets fewer copies exactly as if
+ * hipMalloc had failed (halving until it fits; at worst the plain vector, which is always accepted).  For hosts that keep several
+ * proving keys resident: the full set of copies of ONE MNT4-753 key at 2^22 constraints is ~195 GB (BASELINE configs[4]). */
+int pcdhip_set_precompute_budget(pcdhip_ctx* ctx, size_t bytes_per_vector);
 /* The plan an MSM of n pairs over these bases runs with (n = 0: the whole vector): signed-digit window bits c, scalar
  * windows W = ceil((bits + 1) / c), and how many window-shifted copies of the vector are resident (1 = none).  bench.py
  * prices the accumulate kernel's executed multiply-adds from it. */
@@ -201,6 +216,11 @@ void pcdhip_g16_pk_free(pcdhip_ctx* ctx, pcdhip_g16_pk* pk);
  * the key) resident on the device; pcdhip_groth16_prove then accepts A = B = C = NULL and only the assignment
  * z crosses PCIe per proof. */
 int pcdhip_g16_pk_set_r1cs(pcdhip_ctx* ctx, pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C);
+/* `R1CSToQAP::witness_map` alone over the matrices resident with `pk`, with nothing else on the device: h_out (nullable) =
+ * the n coefficients of h as from pcdhip_groth16_witness_map; out_ms (nullable) = device milliseconds of [the three mat-vecs,
+ * the seven transforms + the pointwise step, both].  pcdhip_groth16_prove overlaps the same work with four of its MSMs. */
+int pcdhip_g16_witness_map_resident(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const uint64_t* z_mont, uint64_t* h_out_mont,
+                                    float out_ms[3]);
 /* proof_out = A (G1 x||y) || B (G2 x||y) || C (G1 x||y), affine Montgomery; inf_out[3]. */
 int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B,
                          const pcdhip_csr* C, const uint64_t* z_mont, const uint64_t* r_mont, const uint64_t* s_mont,

@@ -131,6 +131,25 @@ def gen_points(curve, group, n, seed):
     return out
 
 
+def gen_points_mt(curve, group, n, seed, threads=None):
+    """n seeded on-curve points made as independent blocks of 2^16 (block k = gen_points(.., seed + k)) on a thread pool -- ctypes
+    releases the GIL, and the single walk of gen_points takes minutes for 2^22 points of a 753-bit group."""
+    from concurrent.futures import ThreadPoolExecutor
+    blk = 1 << 16
+    if n <= blk:
+        return gen_points(curve, group, n, seed)
+    out = np.zeros((n, point_words(curve, group)), dtype=np.uint64)
+    starts = list(range(0, n, blk))
+
+    def work(k):
+        lo = starts[k]
+        cnt = min(blk, n - lo)
+        assert lib().orc_gen_points(curve, group, C.c_size_t(cnt), C.c_uint64(seed + k), _p(out[lo:lo + cnt])) == 0
+    with ThreadPoolExecutor(max_workers=threads or min(64, os.cpu_count() or 1)) as ex:
+        list(ex.map(work, range(len(starts))))
+    return out
+
+
 def gen_scalars(field, n, seed, dist=0):
     """canonical scalars; dist 0 uniform, 1 witness-like (45% zero / 35% one / 20% uniform)."""
     out = np.zeros((n, FIELD_N64[field]), dtype=np.uint64)
@@ -260,14 +279,16 @@ class Keys:
         return s
 
 
-def synthetic_keys(curve, r, seed):
+def synthetic_keys(curve, r, seed, mt=False):
     """Groth16 key made of seeded on-curve points, sized for the domain `GeneralEvaluationDomain::new` picks (radix-2 or
     mixed radix).  A real trusted setup at 2^20 takes minutes on the CPU and the prover arithmetic does not depend on the
-    key being consistent; proofs made with such a key are compared bit for bit with this oracle's, not verified."""
+    key being consistent; proofs made with such a key are compared bit for bit with this oracle's, not verified.
+    mt: the points come from gen_points_mt (other points than with mt=False; for the 2^20+ keys of the 753-bit curves)."""
     m, ni = r.num_vars, r.num_inputs
     n = domain_size(r.field, r.num_constraints + ni)
-    g1 = gen_points(curve, 1, 2 * m + (n - 1) + (m - ni) + 3, seed=seed)
-    g2 = gen_points(curve, 2, m + 2, seed=seed + 1)
+    gen = gen_points_mt if mt else gen_points
+    g1 = gen(curve, 1, 2 * m + (n - 1) + (m - ni) + 3, seed=seed)
+    g2 = gen(curve, 2, m + 2, seed=seed + (1 << 20 if mt else 1))
     z8 = lambda k: np.zeros(k, dtype=np.uint8)
     o = [0]
 

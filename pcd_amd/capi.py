@@ -44,10 +44,10 @@ EXPORTS = [
     "pcdhip_strerror", "pcdhip_device_count", "pcdhip_init", "pcdhip_init_devices", "pcdhip_ctx_devices", "pcdhip_destroy", "pcdhip_sync", "pcdhip_host_alloc", "pcdhip_host_free", "pcdhip_last_hip_error",
     "pcdhip_field_limbs", "pcdhip_curve_base_field", "pcdhip_curve_scalar_field", "pcdhip_point_limbs",
     "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
-    "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config", "pcdhip_msm_submit", "pcdhip_msm_collect", "pcdhip_bases_info", "pcdhip_stream_wait",
-    "pcdhip_set_precompute", "pcdhip_msm_set_sort", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
+    "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config", "pcdhip_msm_submit", "pcdhip_msm_collect", "pcdhip_msm_submit_partial", "pcdhip_msm_ticket_wait", "pcdhip_bases_info", "pcdhip_stream_wait",
+    "pcdhip_set_precompute", "pcdhip_set_precompute_budget", "pcdhip_msm_set_sort", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
-    "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
+    "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_g16_witness_map_resident", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
     "pcdhip_serialized_size", "pcdhip_serialize_points", "pcdhip_deserialize_points", "pcdhip_proof_serialized_size", "pcdhip_proof_serialize",
     "pcdhip_proof_deserialize", "pcdhip_vk_serialized_size", "pcdhip_vk_serialize", "pcdhip_vk_deserialize",
     "pcdhip_process_vk", "pcdhip_pvk_free", "pcdhip_groth16_verify_prepared", "pcdhip_groth16_verify_batch_rlc",
@@ -167,6 +167,18 @@ class Context:
         self._check(lib().pcdhip_msm_collect(self._ctx, t, _p(out)))
         return out
 
+    def msm_submit_partial(self, bases, scalars, out_slots_device_ptr, slot_stride_bytes, offset=0, n=None):
+        """msm_submit with the Jacobian partial left in slot `ticket` of the caller's device buffer (four slots, `slot_stride_bytes`
+        apart) -> ticket number; release it with msm_ticket_wait(ticket, stream), which makes `stream` wait for the MSM."""
+        n = scalars.n if n is None else n
+        t = C.c_int(-1)
+        self._check(lib().pcdhip_msm_submit_partial(self._ctx, bases._h, C.c_size_t(offset), scalars._h, C.c_size_t(0), C.c_size_t(n),
+                                                    C.c_void_p(out_slots_device_ptr), C.c_size_t(slot_stride_bytes), C.byref(t)))
+        return t.value
+
+    def msm_ticket_wait(self, ticket, other_stream):
+        self._check(lib().pcdhip_msm_ticket_wait(self._ctx, int(ticket), C.c_void_p(other_stream)))
+
     def msm_partial_to_device(self, bases, scalars, out_device_ptr, offset=0, n=None):
         """The MSM of a shard with its Jacobian result left at `out_device_ptr` (device memory of the caller, e.g. a torch
         tensor's data_ptr(): the send buffer of the all-gather).  Asynchronous: call sync() before another stream reads it."""
@@ -196,6 +208,10 @@ class Context:
     def set_precompute(self, mode):
         """-1 full (default), 0 none, k >= 2 copies; applies to bases uploaded afterwards."""
         self._check(lib().pcdhip_set_precompute(self._ctx, int(mode)))
+
+    def set_precompute_budget(self, bytes_per_vector):
+        """bytes one base vector uploaded afterwards may occupy with its window-shifted copies (0: no bound); fewer copies otherwise."""
+        self._check(lib().pcdhip_set_precompute_budget(self._ctx, C.c_size_t(int(bytes_per_vector))))
 
     def msm_set_sort(self, mode):
         """0: LDS partition sort (default); 1: single-pass binning with on-device fallback; 2: two-pass counting sort."""
@@ -276,6 +292,14 @@ class Context:
         B = self._csr(r1cs.rp_b, r1cs.col_b, r1cs.coeff_b)
         Cm = self._csr(r1cs.rp_c, r1cs.col_c, r1cs.coeff_c)
         self._check(lib().pcdhip_g16_pk_set_r1cs(self._ctx, pk._h, C.byref(A), C.byref(B), C.byref(Cm)))
+
+    def witness_map_resident(self, pk, r1cs, want_h=True):
+        """witness map alone over the matrices resident with pk -> (h or None, {"spmv", "transforms", "total"} device ms)."""
+        n = lib().pcdhip_domain_size(CURVE_FR[pk.curve], C.c_size_t(r1cs.num_constraints + r1cs.num_inputs))
+        h = np.zeros((n, FIELD_LIMBS[CURVE_FR[pk.curve]]), dtype=np.uint64) if want_h else None
+        ms = (C.c_float * 3)()
+        self._check(lib().pcdhip_g16_witness_map_resident(self._ctx, pk._h, _p(r1cs.z), _p(h), ms))
+        return h, dict(zip(["spmv", "transforms", "total"], list(ms)))
 
     def groth16_prove(self, pk, r1cs, r_mont, s_mont, resident_r1cs=False):
         """create_proof after synthesis -> (proof A||B||C affine limbs, inf flags[3]).  With resident_r1cs the

@@ -388,7 +388,7 @@ int pcdhip_bases_upload(pcdhip_ctx* ctx, int curve_id, int group_id, const uint6
       shard_range(n, g, G, &lo, &hi);
       b->shard_lo[g] = lo; b->shard_lo[g + 1] = hi;
       pcdhip_ctx* C = ctx->peers[g];
-      C->precompute = ctx->precompute; C->msm_c = ctx->msm_c;
+      C->precompute = ctx->precompute; C->precompute_budget = ctx->precompute_budget; C->msm_c = ctx->msm_c;
       pcdhip_bases* sh = nullptr;
       int rc = bases_upload_single(C, curve_id, group_id, xy + lo * pl, inf ? inf + lo : nullptr, hi - lo, &sh);
       if (rc) { pcdhip_bases_free(ctx, b); return rc; }
@@ -416,7 +416,9 @@ static int bases_upload_single(pcdhip_ctx* ctx, int curve_id, int group_id, cons
   }
   hipError_t e = hipErrorOutOfMemory;
   while (true) {
-    e = hipMalloc(&b->dptr, std::max<size_t>(n, 1) * int_b * b->groups);
+    const size_t want = std::max<size_t>(n, 1) * int_b * b->groups;
+    // (the caller's budget for one vector counts like the device running out: a host that keeps several keys resident sets it)
+    e = (ctx->precompute_budget && want > ctx->precompute_budget && b->groups > 1) ? hipErrorOutOfMemory : hipMalloc(&b->dptr, want);
     if (e == hipSuccess || b->groups == 1) break;
     (void)hipGetLastError();
     b->groups = (b->groups + 1) / 2;  // not enough HBM for this many copies: fewer groups, more bucket windows
@@ -442,6 +444,11 @@ static int bases_upload_single(pcdhip_ctx* ctx, int curve_id, int group_id, cons
 int pcdhip_set_precompute(pcdhip_ctx* ctx, int mode) {
   if (!ctx || mode < -1 || mode == 1) return PCDHIP_E_ARG;
   ctx->precompute = mode;
+  return PCDHIP_OK;
+}
+int pcdhip_set_precompute_budget(pcdhip_ctx* ctx, size_t bytes_per_vector) {
+  if (!ctx) return PCDHIP_E_ARG;
+  ctx->precompute_budget = bytes_per_vector;
   return PCDHIP_OK;
 }
 void pcdhip_bases_free(pcdhip_ctx* ctx, pcdhip_bases* bases) {
@@ -537,8 +544,8 @@ static bool pipe_pending(const pcdhip_ctx* ctx) {
   return false;
 }
 
-int pcdhip_msm_submit(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset, size_t n,
-                      int* ticket) {
+static int msm_submit_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset, size_t n,
+                             uint64_t* out_xyz_device, size_t out_slot_stride, int* ticket) {
   if (!ctx || !bases || !scalars || !ticket || !bases->shards.empty()) return PCDHIP_E_ARG;
   if (offset + n > bases->n || scalar_offset + n > scalars->n || n >= (1ull << 31)) return PCDHIP_E_ARG;
   if (scalars->field_id != kCurveFr[bases->curve_id]) return PCDHIP_E_ARG;
@@ -560,8 +567,9 @@ int pcdhip_msm_submit(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset,
   hipStream_t sk = ctx->g16_streams[2 + slot];
   TRY(ws.ensure(WS_OUT, jac_b + jac_abi_b + 64));
   uint32_t* out_dev = (uint32_t*)ws.buf[WS_OUT];
-  uint32_t* out_abi = out_dev + jac_b / 4;
-  // ordered behind whatever the context's own stream has queued so far (uploads of the operands)
+  uint32_t* out_abi = out_xyz_device ? (uint32_t*)((char*)out_xyz_device + (size_t)slot * out_slot_stride) : out_dev + jac_b / 4;
+  // ordered behind whatever the context's own stream has queued so far (uploads of the operands; for the device-result form also
+  // the previous reader of `out_xyz_device`, which pcdhip_stream_wait put in front of the context's stream)
   TRY(hipEventRecord(ctx->g16_ready, ctx->stream));
   TRY(hipStreamWaitEvent(sk, ctx->g16_ready, 0));
   const size_t sw = (size_t)kFieldLimbs[scalars->field_id] * 2;
@@ -570,12 +578,28 @@ int pcdhip_msm_submit(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset,
   TRY(ge.jac_out(sk, out_dev, 1, out_abi));
   uint64_t* host = ctx->pipe_host + (size_t)slot * pcdhip_ctx::PIPE_HOST_WORDS;
   host[pcdhip_ctx::PIPE_HOST_WORDS - 1] = 0;
-  TRY(hipMemcpyAsync(host, out_abi, jac_abi_b, hipMemcpyDeviceToHost, sk));
+  if (!out_xyz_device) TRY(hipMemcpyAsync(host, out_abi, jac_abi_b, hipMemcpyDeviceToHost, sk));
   if (ws.last_err_dev) TRY(hipMemcpyAsync(&host[pcdhip_ctx::PIPE_HOST_WORDS - 1], ws.last_err_dev, 4, hipMemcpyDeviceToHost, sk));
   TRY(hipEventRecord(ctx->pipe_done[slot], sk));
   ctx->pipe_busy[slot] = true;
-  ctx->pipe_out_bytes[slot] = jac_abi_b;
+  ctx->pipe_out_bytes[slot] = out_xyz_device ? 0 : jac_abi_b;
   *ticket = slot;
+  return PCDHIP_OK;
+}
+int pcdhip_msm_submit(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset, size_t n,
+                      int* ticket) {
+  return msm_submit_common(ctx, bases, offset, scalars, scalar_offset, n, nullptr, 0, ticket);
+}
+int pcdhip_msm_submit_partial(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset, size_t n,
+                              uint64_t* out_xyz_device_slots, size_t slot_stride_bytes, int* ticket) {
+  if (!out_xyz_device_slots || (slot_stride_bytes & 7)) return PCDHIP_E_ARG;
+  return msm_submit_common(ctx, bases, offset, scalars, scalar_offset, n, out_xyz_device_slots, slot_stride_bytes, ticket);
+}
+int pcdhip_msm_ticket_wait(pcdhip_ctx* ctx, int ticket, void* other_stream) {
+  if (!ctx || ticket < 0 || ticket >= pcdhip_ctx::PIPE_SLOTS || !ctx->pipe_busy[ticket]) return PCDHIP_E_ARG;
+  BIND();
+  ctx->pipe_busy[ticket] = false;
+  TRY(hipStreamWaitEvent((hipStream_t)other_stream, ctx->pipe_done[ticket], 0));
   return PCDHIP_OK;
 }
 int pcdhip_msm_collect(pcdhip_ctx* ctx, int ticket, uint64_t* out_xyz) {
@@ -591,9 +615,25 @@ int pcdhip_msm_collect(pcdhip_ctx* ctx, int ticket, uint64_t* out_xyz) {
 // MSM over bases sharded across the devices of the context: every device runs the whole pipeline on the part of [offset, offset + n)
 // that falls into its point range (scalars: the matching slice of the host vector), the partial results travel device to device
 // into device 0's gather buffer and one wave sums them there.  No host synchronisation before the result is read back.
+// (every error exit drains the peer streams before the frames that outstanding copies point into -- the error words, the caller's
+//  scalars -- go away)
+static void drain_peers(pcdhip_ctx* ctx) {
+  for (pcdhip_ctx* C : ctx->peers) { if (hipSetDevice(C->device) == hipSuccess) (void)hipStreamSynchronize(C->stream); }
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+}
+static int msm_sharded_impl(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const uint64_t* scalars, size_t n, uint64_t* out_xyz,
+                            uint32_t* too_wide);
 static int msm_sharded(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const uint64_t* scalars, size_t n, uint64_t* out_xyz) {
+  if (ctx->peers.size() != bases->shards.size() || ctx->peers.size() > 64) return PCDHIP_E_ARG;
+  uint32_t too_wide[64] = {0};
+  const int rc = msm_sharded_impl(ctx, bases, offset, scalars, n, out_xyz, too_wide);
+  if (rc) drain_peers(ctx);
+  return rc;
+}
+static int msm_sharded_impl(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const uint64_t* scalars, size_t n, uint64_t* out_xyz,
+                            uint32_t* too_wide) {
   const size_t G = bases->shards.size();
-  if (ctx->peers.size() != G) return PCDHIP_E_ARG;
   const GroupEntry& ge = group_entry(bases->curve_id, bases->group_id);
   const size_t jb = (size_t)ge.point_abi_words / 2 * 3 * 4, ji = (size_t)ge.point_words / 2 * 3 * 4;
   const size_t sl = (size_t)kFieldLimbs[kCurveFr[bases->curve_id]];
@@ -602,7 +642,6 @@ static int msm_sharded(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset
   uint32_t* d = (uint32_t*)ctx->aux_ws.buf[AUX_MISC];  // result | gathered partials | tree scratch
   uint32_t* gather = d + jb / 4;
   uint32_t* scratch = d + (G + 1) * jb / 4;
-  uint32_t too_wide[64] = {0};
   for (size_t g = 0; g < G; g++) {
     const size_t lo = std::max(offset, bases->shard_lo[g]), hi = std::min(offset + n, bases->shard_lo[g + 1]);
     pcdhip_ctx* C = ctx->peers[g];
@@ -842,7 +881,8 @@ int upload_csr(pcdhip_ctx* ctx, int slot, const pcdhip_csr* m, const FieldEntry&
 }
 
 // h (d.n elements, device image) left in aux slot AUX_A; z_dev: m elements on device; mats: A, B, C on device
-int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const uint32_t* z_dev, size_t num_inputs, Dom* dom_out) {
+int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const uint32_t* z_dev, size_t num_inputs, Dom* dom_out,
+                    hipEvent_t after_spmv = nullptr) {
   const FieldEntry& fe = field_entry(field_id);
   if (mats[0].rows != mats[1].rows || mats[0].rows != mats[2].rows) return PCDHIP_E_ARG;
   Dom d;
@@ -860,6 +900,7 @@ int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const u
   uint32_t* vecs[3] = {a, b, c};
   for (int k = 0; k < 3; k++)
     TRY(fe.spmv(st, mats[k].rp, mats[k].col, mats[k].coeff, mats[k].rows, z_dev, (uint32_t)num_inputs, k == 0 ? 1 : 0, n, vecs[k]));
+  if (after_spmv) TRY(hipEventRecord(after_spmv, st));
   // 3 x (ifft, coset_fft), pointwise, coset_ifft
   for (uint32_t* v : vecs) {
     rc = domain_transform(ctx, field_id, d, v, tmp, 1, 0, nullptr, nullptr); if (rc) return rc;
@@ -912,6 +953,44 @@ int pcdhip_groth16_witness_map(pcdhip_ctx* ctx, int field_id, const pcdhip_csr* 
   return PCDHIP_OK;
 }
 
+// The witness map ALONE over the matrices resident with a key (pcdhip_g16_pk_set_r1cs), nothing else running: what
+// pcdhip_groth16_prove queues on the context's stream while its MSMs run on the side streams.  out_ms = device time of
+// [the three mat-vecs, the seven transforms + the pointwise step, both].  h_out may be null (timing only).
+int pcdhip_g16_witness_map_resident(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const uint64_t* z, uint64_t* h_out, float out_ms[3]) {
+  if (!ctx || !pk || !z) return PCDHIP_E_ARG;
+  if (!pk->shards.empty()) pk = pk->shards[0];
+  if (!pk->r1cs_dev) return PCDHIP_E_ARG;
+  BIND();
+  const int fr = kCurveFr[pk->curve_id];
+  const FieldEntry& fe = field_entry(fr);
+  const size_t m = pk->num_vars;
+  TRY(ctx->aux_ws.ensure(AUX_Z, m * fe.words * 4));
+  TRY(ctx->aux_ws.ensure(AUX_Z_CANON, m * fe.abi_words * 4));
+  TRY(hipMemcpyAsync(ctx->aux_ws.buf[AUX_Z_CANON], z, m * fe.abi_words * 4, hipMemcpyHostToDevice, ctx->stream));
+  TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_Z_CANON], (uint32_t*)ctx->aux_ws.buf[AUX_Z], (uint32_t)m, 0));
+  DevCsr mats[3];
+  for (int k = 0; k < 3; k++) mats[k] = {pk->rp[k], pk->col[k], pk->coeff[k], pk->rows};
+  EventSet<3> ev;
+  TRY(ev.create());
+  TRY(hipEventRecord(ev[0], ctx->stream));
+  Dom dom;
+  int rc = witness_map_dev(ctx, fr, mats, (const uint32_t*)ctx->aux_ws.buf[AUX_Z], pk->num_inputs, &dom, ev[1]);
+  if (rc) return rc;
+  TRY(hipEventRecord(ev[2], ctx->stream));
+  if (h_out) {
+    TRY(ctx->aux_ws.ensure(AUX_H_CANON, (size_t)dom.n * fe.abi_words * 4));
+    TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_A], (uint32_t*)ctx->aux_ws.buf[AUX_H_CANON], dom.n, 1));
+    TRY(hipMemcpyAsync(h_out, ctx->aux_ws.buf[AUX_H_CANON], (size_t)dom.n * fe.abi_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  TRY(hipStreamSynchronize(ctx->stream));
+  if (out_ms) {
+    (void)hipEventElapsedTime(&out_ms[0], ev[0], ev[1]);
+    (void)hipEventElapsedTime(&out_ms[1], ev[1], ev[2]);
+    (void)hipEventElapsedTime(&out_ms[2], ev[0], ev[2]);
+  }
+  return PCDHIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ Groth16
 int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g16_pk** out) {
   return guarded([&]() -> int {
@@ -960,7 +1039,7 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
   auto upload_range = [&](pcdhip_ctx* C, size_t lo, size_t hi, size_t hlo, size_t hhi, pcdhip_g16_pk** res) -> int {
     pcdhip_g16_pk* pk = new pcdhip_g16_pk();
     pk->curve_id = cid; pk->num_vars = m; pk->num_inputs = ni; pk->domain_size = h->domain_size; pk->h_len = h->h_len;
-    C->precompute = ctx->precompute; C->msm_c = ctx->msm_c;
+    C->precompute = ctx->precompute; C->precompute_budget = ctx->precompute_budget; C->msm_c = ctx->msm_c;
     auto up = [&](const HostQuery& q, pcdhip_bases** dst) -> int {
       const size_t pl = (size_t)pcdhip_point_limbs(cid, q.group);
       return bases_upload_single(C, cid, q.group, q.pts.data() + lo * pl, q.inf.data() + lo, hi - lo, dst);
@@ -1168,8 +1247,16 @@ int finish_proof(pcdhip_ctx* ctx, int cid, const uint32_t* proof_dev, uint64_t* 
 // up across devices; one-lane products of partial results would not); device 0 computes h and hands each device its slice over
 // xGMI; the partial results (six G1 points and one G2 point per device) travel to device 0, one lane per MSM sums them, and the
 // ordinary assembly kernel finishes.  No host synchronisation until the proof is read back.
+int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C, const uint64_t* z,
+                       const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out, uint8_t* inf_out);
 int prove_sharded(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C, const uint64_t* z,
                   const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out, uint8_t* inf_out) {
+  const int rc = prove_sharded_impl(ctx, pk, A, B, C, z, r_mont, s_mont, proof_out, inf_out);
+  if (rc) drain_peers(ctx);  // no device is left reading the caller's z / r / s, or writing into this call's buffers
+  return rc;
+}
+int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C, const uint64_t* z,
+                       const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out, uint8_t* inf_out) {
   const size_t G = pk->shards.size();
   if (ctx->peers.size() != G) return PCDHIP_E_ARG;
   const int cid = pk->curve_id, fr = kCurveFr[cid];
@@ -1265,6 +1352,7 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   return guarded([&]() -> int {
   if (!ctx || !pk || !z || !r_mont || !s_mont || !proof_out) return PCDHIP_E_ARG;
   if (A && B && C) { const pcdhip_csr* ms[3] = {A, B, C}; for (int k = 0; k < 3; k++) { int v = validate_csr(ms[k], pk->num_vars); if (v) return v; } }
+  if (pipe_pending(ctx)) return PCDHIP_E_ARG;  // submitted MSMs still own side-stream workspaces: collect them first (before anything is queued)
   if (!pk->shards.empty()) return prove_sharded(ctx, pk, A, B, C, z, r_mont, s_mont, proof_out, inf_out);
   if (!ctx->peers.empty() && ctx->peers.size() > 1) return PCDHIP_E_ARG;  // a whole-key handle belongs to an ordinary context
   BIND();

@@ -78,6 +78,7 @@ struct pcdhip_ctx {
   uint32_t msm_chunk = 0;
   int msm_sort = 0;     // 0 LDS partition sort, 1 single-pass binning, 2 two-pass counting sort
   int precompute = -1;  // bases uploaded through this context: -1 full (one bucket window), 0 none, k > 1 groups
+  size_t precompute_budget = 0;  // bytes one base vector may occupy with its copies (0: whatever hipMalloc grants)
   bool msm_profile = false;
   pcd::MsmTimings msm_tm;
   float fft_ms[8] = {0};

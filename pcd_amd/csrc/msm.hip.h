@@ -1005,6 +1005,7 @@ struct MsmWorkspace {
   void* buf[24] = {nullptr};
   size_t cap[24] = {0};
   const uint32_t* last_err_dev = nullptr;  // device word raised by the last MSM's digit pass when a scalar was not reduced (null: not checked)
+  int cus = 0;                             // compute units of the device this workspace lives on (queried on first use)
   hipError_t ensure(int slot, size_t bytes) {
     if (cap[slot] >= bytes) return hipSuccess;
     if (buf[slot]) { hipError_t e = hipFree(buf[slot]); if (e != hipSuccess) return e; buf[slot] = nullptr; cap[slot] = 0; }
@@ -1072,7 +1073,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   // 60 % of the SIMDs during the last one (G1-753 at 2^20: 48 entries = 12.0 rounds, 55.5 -> 53.7 ms)
   pl.chunk = chunk_override ? chunk_override : 40;
   if (!chunk_override) {
-    static int cus = 0;
+    int& cus = ws.cus;  // cached per workspace (= per context and stream: no sharing between host threads, right device)
     if (!cus) {
       int dev = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;

@@ -48,6 +48,10 @@ class DeviceExchange:
         limbs = 3 * capi.point_limbs(curve, group) // 2
         self.send = torch.zeros(limbs, dtype=torch.int64, device=device)
         self.recv = torch.zeros(self.world * limbs, dtype=torch.int64, device=device)
+        # the pipelined form (submit / collect): one send and one receive buffer per ticket of the library (four in flight)
+        self.limbs = limbs
+        self.sends = torch.zeros(4 * limbs, dtype=torch.int64, device=device)
+        self.recvs = [torch.zeros(self.world * limbs, dtype=torch.int64, device=device) for _ in range(4)]
 
     def msm(self, bases, scalars_buf):
         import torch
@@ -58,3 +62,18 @@ class DeviceExchange:
         dist.all_gather_into_tensor(self.recv, self.send)
         self.ctx.stream_wait(ts, 0)                       # the library's stream waits for the gathered points
         return self.ctx.points_sum_device(self.curve, self.group, self.recv.data_ptr(), self.world)
+
+    def submit(self, bases, scalars_buf):
+        """enqueue this rank's shard MSM on one of the library's side streams (at most four outstanding) -> ticket; the partial
+        lands in slot `ticket` of the send buffers"""
+        return self.ctx.msm_submit_partial(bases, scalars_buf, self.sends.data_ptr(), 8 * self.limbs)
+
+    def collect(self, ticket):
+        """all-gather of the partials of `ticket` (RCCL, on torch's stream, ordered behind the MSM by an event) + the EC sum"""
+        import torch
+        import torch.distributed as dist
+        ts = torch.cuda.current_stream().cuda_stream
+        self.ctx.msm_ticket_wait(ticket, ts)              # torch's stream waits for this slot's MSM (no host wait)
+        dist.all_gather_into_tensor(self.recvs[ticket], self.sends[ticket * self.limbs:(ticket + 1) * self.limbs])
+        self.ctx.stream_wait(ts, 0)                       # the library's stream (and every later submission) waits for the gather
+        return self.ctx.points_sum_device(self.curve, self.group, self.recvs[ticket].data_ptr(), self.world)

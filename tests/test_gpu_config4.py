@@ -1,0 +1,137 @@
+"""BASELINE configs[4] -- "arity-8 PCD DAG merge, MNT4-753 Groth16 2^22 constraints, 8 x MI355X: per-branch GPUs + intra-MSM split" --
+on whatever GPUs are visible.  The reference shape is the per-prior loop of a merge node
+(/root/reference src/ec_cycle_pcd/data_structures.rs:269-304) inside `ECCyclePCD::prove` (mod.rs:92-181): eight prior proofs made
+independently (one branch per GPU), then ONE proof at the merge node whose MSMs use all GPUs.  With fewer than eight GPUs the device
+list names devices several times: eight logical shards run exactly the code eight GPUs run (per-device sub-contexts, peer copies,
+gather, slot-wise sums), so the results -- bit for bit against the oracle -- are what an 8-GPU node computes.
+
+  * the G1 MSM of the merge node at its full size, 2^22 pairs over MNT4-753, cut into eight shards of 2^19
+  * eight DAG branches (threads x contexts), each a main MNT4-753 + help MNT6-753 proof, then the merge node's proof sharded 8 ways
+  * the fewer-copies fallback of the window-shifted precomputation, forced at 2^20 (one key of configs[4] with every copy is ~195 GB)
+
+The full 2^22-constraint merge proof (15 minutes, most of it the CPU oracle) is tools/config4_full.py; its log is under profiles/."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THREADS = min(os.cpu_count() or 1, 64)
+
+
+def _devices(k):
+    from pcd_amd import capi
+    n = capi.lib().pcdhip_device_count()
+    return [i % n for i in range(k)]
+
+
+def _same_point(co, cid, grp, got, want):
+    g, w = co.to_affine(cid, grp, got), co.to_affine(cid, grp, want)
+    return np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1])
+
+
+def test_config4_msm_g1_753_2p22_eight_shards(co, gpu_ctx):
+    from pcd_amd import capi
+    cid, grp, n = 2, 1, 1 << 22
+    fr = co.CURVE_FR[cid]
+    pts = co.gen_points_mt(cid, grp, n, seed=4400, threads=THREADS)
+    sc = co.gen_scalars(fr, n, seed=4401)
+    mctx = capi.Context(devices=_devices(8))
+    try:
+        assert capi.lib().pcdhip_ctx_devices(mctx._ctx) == 8
+        b = mctx.bases_upload(cid, grp, pts)
+        c_bits, W, copies = mctx.bases_info(b)
+        assert copies == W, (c_bits, W, copies)   # every shard holds one copy per scalar window of ITS plan (2^19 points each)
+        got = mctx.msm(b, sc)
+        b.free()
+    finally:
+        mctx.close()
+    want = co.msm(cid, grp, pts, sc, nthreads=THREADS)
+    assert _same_point(co, cid, grp, got, want)
+
+
+def _statement(co, curve, nc, seed, mt=False):
+    fr = co.CURVE_FR[curve]
+    r = co.synthetic_r1cs(fr, nc, 2, seed=seed)
+    keys = co.synthetic_keys(curve, r, seed=seed + 1, mt=mt)
+    rs = co.gen_field(fr, 2, seed=seed + 2)
+    return r, keys, rs
+
+
+def test_config4_arity8_branches_then_sharded_merge(co, gpu_ctx):
+    from pcd_amd import capi, dag
+    # eight prior messages: each branch proves a main (MNT4-753, domain 2^13) and a help (MNT6-753, domain 2^13) statement
+    jobs, wants = [], []
+    for i in range(8):
+        main = _statement(co, 2, (1 << 13) - 8 - i, seed=4500 + 10 * i)
+        helper = _statement(co, 3, (1 << 12) + 500 + i, seed=4505 + 10 * i)
+        wants.append([co.groth16_prove(k, r, rs[0], rs[1], nthreads=THREADS)[0] for r, k, rs in (main, helper)])
+
+        def branch(ctx, main=main, helper=helper):
+            out = []
+            for curve, (r, keys, rs) in ((2, main), (3, helper)):
+                pk = ctx.g16_pk_upload(keys.host_struct(), curve)
+                out.append(ctx.groth16_prove(pk, r, rs[0], rs[1])[0])
+                pk.free()
+            return out
+        jobs.append(branch)
+    results = dag.run_branches(jobs, _devices(8))
+    for got, want in zip(results, wants):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # the merge node: one MNT4-753 proof whose five MSMs run on all eight (logical) devices
+    r, keys, rs = _statement(co, 2, (1 << 17) - 8, seed=4600, mt=True)
+    want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)
+    mctx = capi.Context(devices=_devices(8))
+    try:
+        mpk = mctx.g16_pk_upload(keys.host_struct(), 2)
+        mctx.g16_pk_set_r1cs(mpk, r)
+        got, inf = mctx.groth16_prove(mpk, r, rs[0], rs[1], resident_r1cs=True)
+        mpk.free()
+    finally:
+        mctx.close()
+    assert np.array_equal(got, want) and np.array_equal(inf, winf)
+
+
+@pytest.mark.parametrize("cid,log_n,budget_mb,expect", [(0, 20, 400, 4), (2, 20, 2500, 9)])
+def test_precompute_fallback_forced(co, gpu_ctx, cid, log_n, budget_mb, expect):
+    """pcdhip_set_precompute_budget makes a vector take the fewer-copies path a device short of memory takes: 15 -> 8 -> 4 copies
+    (MNT4-298 G1, 92 MB each) / 36 -> 18 -> 9 (MNT4-753 G1, 226 MB each); windows that share a copy come back as bucket windows +
+    the Horner combine.  Same result, and pcdhip_bases_info reports what the handle holds.  Also through a two-shard context
+    (the budget is per vector PER DEVICE) and with an explicit copy count."""
+    from pcd_amd import capi
+    n = 1 << log_n
+    fr = co.CURVE_FR[cid]
+    pts = co.gen_points_mt(cid, 1, n, seed=4700 + cid, threads=THREADS)
+    sc = co.gen_scalars(fr, n, seed=4701 + cid, dist=1)
+    want = co.msm(cid, 1, pts, sc, nthreads=THREADS)
+    ctx = gpu_ctx
+    try:
+        ctx.set_precompute_budget(budget_mb << 20)
+        b = ctx.bases_upload(cid, 1, pts)
+        c_bits, W, copies = ctx.bases_info(b)
+        assert copies == expect and copies < W, (c_bits, W, copies)
+        got = ctx.msm(b, sc)
+        b.free()
+        assert _same_point(co, cid, 1, got, want)
+        ctx.set_precompute_budget(0)
+        ctx.set_precompute(3)
+        b = ctx.bases_upload(cid, 1, pts)
+        assert ctx.bases_info(b)[2] == 3
+        got = ctx.msm(b, sc)
+        b.free()
+        assert _same_point(co, cid, 1, got, want)
+    finally:
+        ctx.set_precompute_budget(0)
+        ctx.set_precompute(-1)
+    mctx = capi.Context(devices=_devices(2))
+    try:
+        mctx.set_precompute_budget(budget_mb << 19)   # half the vector per device, half the budget
+        b = mctx.bases_upload(cid, 1, pts)
+        c_bits, W, copies = mctx.bases_info(b)        # (the plan of a 2^(log_n - 1)-point shard: its own window bits)
+        assert 1 < copies < W, (c_bits, W, copies)
+        got = mctx.msm(b, sc)
+        b.free()
+        assert _same_point(co, cid, 1, got, want)
+    finally:
+        mctx.close()

@@ -252,3 +252,39 @@ def test_submit_collect_pipelined(co, gpu_ctx):
         ctx.msm(b1, bad, n=64)
     for h in (b1, b2, sb, bb):
         h.free()
+
+
+def test_submit_partial_tickets(co, gpu_ctx):
+    """pcdhip_msm_submit_partial / pcdhip_msm_ticket_wait (the pipelined exchange of `bench.py --gpus N`): four shard MSMs in flight,
+    each partial left in the slot of the caller's device buffer that its ticket names, a foreign stream ordered behind each by an
+    event; the four slots summed on the device == the MSM over the whole range == the oracle.  Twice, so slots are reused."""
+    import torch
+    ctx = gpu_ctx
+    cid, grp, n = 0, 1, 4 * 9000
+    fr = co.CURVE_FR[cid]
+    pts = co.gen_points(cid, grp, n, seed=1601)
+    sc = co.gen_scalars(fr, n, seed=1602, dist=1)
+    want = co.to_affine(cid, grp, co.msm(cid, grp, pts, sc, nthreads=8))
+    limbs = 3 * co.point_words(cid, grp) // 2
+    b = ctx.bases_upload(cid, grp, pts)
+    parts = [ctx.buf_upload(fr, sc[q * 9000:(q + 1) * 9000]) for q in range(4)]
+    slots = torch.zeros(4 * limbs, dtype=torch.int64, device="cuda:0")
+    ts = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        slots.zero_()
+        torch.cuda.synchronize()
+        tickets = [ctx.msm_submit_partial(b, parts[q], slots.data_ptr(), 8 * limbs, offset=q * 9000, n=9000) for q in range(4)]
+        assert sorted(tickets) == [0, 1, 2, 3]
+        with pytest.raises(Exception):
+            ctx.msm_submit_partial(b, parts[0], slots.data_ptr(), 8 * limbs, offset=0, n=9000)   # four tickets are outstanding
+        for t in tickets:
+            ctx.msm_ticket_wait(t, ts)
+        gathered = slots.clone()                      # on torch's stream: ordered behind the four MSMs by the events
+        ctx.stream_wait(ts, 0)
+        got = co.to_affine(cid, grp, ctx.points_sum_device(cid, grp, gathered.data_ptr(), 4))
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    with pytest.raises(Exception):
+        ctx.msm_ticket_wait(0, ts)                    # not outstanding any more
+    b.free()
+    for p in parts:
+        p.free()
