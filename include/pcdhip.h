@@ -268,9 +268,14 @@ int pcdhip_groth16_setup(pcdhip_ctx* ctx, int curve_id, const pcdhip_csr* A, con
 
 /* ---- K6: pairing ---------------------------------------------------------------------------------
  * Replaces ark-ec `PairingEngine::product_of_pairings`: gt_out = final_exponentiation(prod_i miller_loop(P_i, Q_i)),
- * an element of Fq4 (MNT4) / Fq6 (MNT6) in tower order c0, c1 over Fq2 / Fq3, Montgomery limbs.  One lane per pair. */
+ * an element of Fq4 (MNT4) / Fq6 (MNT6) in tower order c0, c1 over Fq2 / Fq3, Montgomery limbs.  Up to 4096 pairs per call run ONE
+ * WAVE PER PAIRING (the independent field products of every curve / tower step on sibling lanes, values in LDS: the latency of a
+ * verification is what a merge node waits for); larger batches one lane per pair (64 pairings per wave: throughput). */
 int pcdhip_multi_pairing(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy,
                          const uint8_t* g2_inf, size_t n_pairs, uint64_t* gt_out);
+/* 0 (default): as described above; 1: always the lane-per-pair kernels (A/B measurements, parity tests of both forms).  Applies to
+ * every entry point that computes pairings (multi_pairing, the Groth16 verifications, process_vk). */
+int pcdhip_pairing_set_mode(pcdhip_ctx* ctx, int mode);
 /* Replaces ark-groth16 `Groth16::verify` (reference call site mod.rs:239):
  * e(A,B) == e(alpha,beta) e(gamma_abc[0] + sum_i x_i gamma_abc[i], gamma) e(C,delta); public inputs canonical, without the leading 1. */
 int pcdhip_groth16_verify(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, const uint64_t* beta_g2, const uint64_t* gamma_g2,

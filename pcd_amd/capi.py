@@ -51,7 +51,7 @@ EXPORTS = [
     "pcdhip_serialized_size", "pcdhip_serialize_points", "pcdhip_deserialize_points", "pcdhip_proof_serialized_size", "pcdhip_proof_serialize",
     "pcdhip_proof_deserialize", "pcdhip_vk_serialized_size", "pcdhip_vk_serialize", "pcdhip_vk_deserialize",
     "pcdhip_process_vk", "pcdhip_pvk_free", "pcdhip_groth16_verify_prepared", "pcdhip_groth16_verify_batch_rlc",
-    "pcdhip_multi_pairing", "pcdhip_groth16_verify", "pcdhip_groth16_verify_batch", "pcdhip_timer_start", "pcdhip_timer_stop",
+    "pcdhip_multi_pairing", "pcdhip_pairing_set_mode", "pcdhip_groth16_verify", "pcdhip_groth16_verify_batch", "pcdhip_timer_start", "pcdhip_timer_stop",
 ]
 
 
@@ -373,6 +373,10 @@ class Context:
         i2 = np.ascontiguousarray(g2_inf, dtype=np.uint8) if g2_inf is not None else None
         self._check(lib().pcdhip_multi_pairing(self._ctx, curve, _p(g1), _p(i1), _p(g2), _p(i2), C.c_size_t(n), _p(out)))
         return out
+
+    def pairing_set_mode(self, mode):
+        """0: one wave per pairing for batches up to 4096 pairs (default); 1: always one lane per pairing."""
+        self._check(lib().pcdhip_pairing_set_mode(self._ctx, int(mode)))
 
     def groth16_verify(self, curve, alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1, public_inputs_canonical, proof,
                        gamma_abc_inf=None, proof_inf=None):

@@ -285,6 +285,7 @@ void pcdhip_destroy(pcdhip_ctx* ctx) {
     (void)hipFree(kv.second.coset); (void)hipFree(kv.second.coset_inv_scaled);
   }
   if (ctx->xstream_ev) (void)hipEventDestroy(ctx->xstream_ev);
+  for (int c = 0; c < 4; c++) if (ctx->vm_block[c]) (void)hipFree(ctx->vm_block[c]);
   for (int k = 0; k < pcdhip_ctx::PIPE_SLOTS; k++) if (ctx->pipe_done[k]) (void)hipEventDestroy(ctx->pipe_done[k]);
   if (ctx->pipe_host) (void)hipHostFree(ctx->pipe_host);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
@@ -1629,9 +1630,15 @@ static int pairing_groups(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, 
     TRY(zero_flagged(ctx->stream, g1d, (uint8_t*)d + flag_off, g1_inf, n_pairs, w1));
     TRY(zero_flagged(ctx->stream, g2d, (uint8_t*)d + flag_off + n_pairs, g2_inf, n_pairs, w2));
   }
-  TRY(pe.multi_pairing(ctx->stream, g1d, g2d, (uint32_t)groups, (uint32_t)per, scr, out));
+  if (!ctx->vm_block[curve_id] && ctx->pairing_vm) TRY(pe.vm_upload(ctx->stream, &ctx->vm_block[curve_id], &ctx->vm_tables[curve_id]));
+  TRY(pe.multi_pairing(ctx->stream, g1d, g2d, (uint32_t)groups, (uint32_t)per, scr, out, ctx->pairing_vm ? &ctx->vm_tables[curve_id] : nullptr));
   TRY(hipMemcpyAsync(gt_out, out, groups * gb, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
+  return PCDHIP_OK;
+}
+int pcdhip_pairing_set_mode(pcdhip_ctx* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 1) return PCDHIP_E_ARG;
+  ctx->pairing_vm = mode == 0;
   return PCDHIP_OK;
 }
 int pcdhip_multi_pairing(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy,
@@ -1643,7 +1650,7 @@ int pcdhip_multi_pairing(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, c
     const PairingEntry& pe = pairing_entry(curve_id);
     TRY(ctx->aux_ws.ensure(AUX_MISC, (size_t)pe.gt_words * 4 + 256));
     uint32_t* out = (uint32_t*)ctx->aux_ws.buf[AUX_MISC];
-    TRY(pe.multi_pairing(ctx->stream, out, out, 1, 0, out, out));
+    TRY(pe.multi_pairing(ctx->stream, out, out, 1, 0, out, out, nullptr));  // (the lane-per-pairing kernels: one lane, no pairs)
     TRY(hipMemcpyAsync(gt_out, out, (size_t)pe.gt_words * 4, hipMemcpyDeviceToHost, ctx->stream));
     TRY(hipStreamSynchronize(ctx->stream));
     return PCDHIP_OK;

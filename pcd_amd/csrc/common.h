@@ -11,6 +11,7 @@
 
 #include "../../include/pcdhip.h"
 #include "msm.hip.h"
+#include "pairing_vm.hip.h"
 
 namespace pcd {
 
@@ -95,6 +96,10 @@ struct pcdhip_ctx {
   static constexpr size_t PIPE_HOST_WORDS = 256;  // >= one Jacobian point in the C-ABI image (216 u64 for Fq3-753) + the error word
   size_t pipe_out_bytes[PIPE_SLOTS] = {0, 0, 0, 0};
   int pipe_next = 0;
+  // program tables of the wave-per-pairing VM (pairing_vm.hip.h), uploaded per curve on first use
+  void* vm_block[4] = {nullptr, nullptr, nullptr, nullptr};
+  pcd::VmTables vm_tables[4] = {};
+  bool pairing_vm = true;  // small batches of pairings run one wave per pairing (pcdhip_pairing_set_mode)
   hipEvent_t xstream_ev = nullptr;  // pcdhip_stream_wait: ordering against a caller-owned stream (e.g. the RCCL stream)
   std::string last_hip_error;
 };
@@ -185,9 +190,11 @@ const CurveEntry& curve_entry(int curve_id);
 struct PairingEntry {
   int gt_words;           // u32 words of one GT element (Fq4 / Fq6) at the C-ABI
   int gt_internal_words;  // ... in the device image (scratch sizing)
-  // gt_out[g] = final_exp(prod_{i < per} miller(P_{g per + i}, Q_{g per + i})) for g < groups; scratch: groups * per GT elements
+  // gt_out[g] = final_exp(prod_{i < per} miller(P_{g per + i}, Q_{g per + i})) for g < groups; scratch: groups * per GT elements;
+  // vm: this device's copy of the curve's VM program tables (pairing_vm.hip.h; null = the lane-per-pairing kernels only)
   hipError_t (*multi_pairing)(hipStream_t, const uint32_t* g1_dev, const uint32_t* g2_dev, uint32_t groups, uint32_t per,
-                              uint32_t* scratch, uint32_t* gt_out);
+                              uint32_t* scratch, uint32_t* gt_out, const VmTables* vm);
+  hipError_t (*vm_upload)(hipStream_t, void** block, VmTables* out);
 };
 const PairingEntry& pairing_entry(int curve_id);
 

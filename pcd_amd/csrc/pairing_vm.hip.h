@@ -1,0 +1,193 @@
+// The MNT4 / MNT6 ate pairing with ONE WAVE PER PAIRING (K6 of SURVEY.md section 8; the latency form).
+//
+// Replaces, for small batches, the one-lane-per-pairing kernels of pairing.hip.h behind the same entry points
+// (`PairingEngine::{miller_loop, final_exponentiation}` under `Groth16::verify`, /root/reference src/ec_cycle_pcd/mod.rs:239, and
+// `process_vk`, mod.rs:71).  A pairing is ~13 000 (298-bit) field products of which a lane can only run one at a time; a verification
+// has three or four pairings, so the lane-per-pairing kernels used 4 of the chip's 65 536 lanes and took 28 ms where one host core
+// takes 5.  Here a wave is a little vector machine over Fq:
+//
+//   * every value is a REGISTER IN LDS (N 28-bit limbs, 16-byte aligned records);
+//   * a program is a list of steps; in a step up to 64 lanes execute ONE instruction each --
+//       MUL  dst = (sum_{t < T} a_t b_t) / R' mod p     all products into one set of 64-bit column sums, one Montgomery reduction
+//       LIN  dst = sum_{t < 8} c_t a_t mod p            small signed integer coefficients, one weak reduction
+//     -- reading their operands from LDS and writing dst back; the independent products of a tower operation (an Fq4 product is
+//     16 of them) and of a curve step sit on sibling lanes, so the dependent chain of a Miller-loop iteration is ~6 products long
+//     instead of ~90;
+//   * state that a program overwrites (the running point, f, a power) is double-banked per register, the bank bits travel in a
+//     scalar, so no copy-back steps exist;
+//   * the programs (tools/gen_pairing_vm.py -> pairing_vm_gen.h) are traced from the same formulas as pairing.hip.h, levelled and
+//     register-allocated offline, and evaluated against the textbook pairing in tests/test_pairing_vm.py.
+// The interpreter is one copy of the unrolled product and of the reductions (it stays in the instruction cache); everything
+// that is data-dependent in a pairing -- the loop bits -- is compile-time constant, so control flow is uniform across the wave.
+// The arithmetic (vm_mul / vm_lin) is __host__ __device__: tests/hostcheck runs whole programs on the host against the oracle.
+#pragma once
+#include "fp.hip.h"
+#include "pairing_vm_gen.h"
+
+namespace pcd {
+
+struct VmTables {  // device (or, in the host harness, host) copies of one curve's generated tables
+  const uint32_t* progs;   // [nprogs][3]  first step, steps, mask of the state slots written
+  const uint32_t* steps;   // [nsteps][3]  kind, first instruction, instructions
+  const uint32_t* code;    // 12 words per instruction
+  const uint32_t* consts;  // [NCONST][N]
+};
+
+template <class F>
+struct VmArith {
+  typedef typename F::Params P;
+  static constexpr int N = F::N;
+  static constexpr int STRIDE = (N + 3) & ~3;  // words per register record
+  static constexpr uint32_t MASK = F::MASK;
+
+  PCD_HD static uint32_t reg_of(uint32_t op, uint32_t bank) {
+    const uint32_t sp = op >> 14, idx = op & 0x3FFFu;
+    return sp == 0 ? idx : 2 * idx + (((bank >> idx) & 1u) ^ (sp == 2 ? 1u : 0u));
+  }
+  template <class PTR>
+  PCD_HD static F ld(PTR regs, uint32_t r) {
+    F v;
+#pragma unroll
+    for (int i = 0; i < N; i++) v.v[i] = regs[r * STRIDE + i];
+    return v;
+  }
+  template <class PTR>
+  PCD_HD static void st(PTR regs, uint32_t r, const F& v) {
+#pragma unroll
+    for (int i = 0; i < N; i++) regs[r * STRIDE + i] = v.v[i];
+  }
+
+  // dst = (sum a_t b_t) / R', operands and result in [0, 2p): T (<= VM_TMAX) products summed column-wise in 64 bits
+  // ((T + 1) N 2^56 < 2^63), then one Montgomery reduction over the columns.  T = 2: 8 p^2 / R' + p < 2p (R' > 8p).
+  template <class PTR>
+  PCD_HD static F mul(const uint32_t* w, PTR regs, uint32_t bank) {
+    const int T = (int)((w[0] >> 8) & 0xFFu);
+    uint64_t col[2 * N];
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) col[i] = 0;
+    // (unrolled over the term slots with a predicate: the instruction words are indexed statically and stay in registers)
+#pragma unroll
+    for (int t = 0; t < vmgen::VM_TMAX; t++) {
+      if (t < T) {
+        const F a = ld(regs, reg_of(w[1 + t] & 0xFFFFu, bank)), b = ld(regs, reg_of(w[1 + t] >> 16, bank));
+#pragma unroll
+        for (int i = 0; i < N; i++)
+#pragma unroll
+          for (int j = 0; j < N; j++) col[i + j] += (uint64_t)a.v[i] * b.v[j];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      const uint32_t m = ((uint32_t)col[k] * P::INV) & MASK;
+#pragma unroll
+      for (int j = 0; j < N; j++) col[k + j] += (uint64_t)m * P::mod(j);
+      col[k + 1] += col[k] >> 28;
+    }
+    int32_t r[N];
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+      r[i] = (int32_t)((uint32_t)col[N + i] & MASK);
+      col[N + i + 1] += col[N + i] >> 28;
+    }
+    r[N - 1] = (int32_t)(uint32_t)col[2 * N - 1];
+    if (vmgen::VM_TMAX > 2) return F::template norm_reduce<false>(r);  // up to 4p with more products per instruction
+    F o;
+#pragma unroll
+    for (int i = 0; i < N; i++) o.v[i] = (uint32_t)r[i];
+    return o;
+  }
+
+  // dst = sum c_t a_t mod p, |c_t| small (sum of |c_t| <= 124), operands and result in [0, 2p).  Negative terms are covered by adding
+  // K p, K = 2 sum |negative c_t| (every operand is below 2p), so the limb-wise signed sum is a non-negative integer V < 2^8 p; a
+  // quotient estimate from its two top limbs (never above V / p, at most 2 short) and one conditional subtraction finish.
+  template <class PTR>
+  PCD_HD static F lin(const uint32_t* w, PTR regs, uint32_t bank) {
+    const int T = (int)((w[0] >> 8) & 0xFFu);
+    int64_t s[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) s[i] = 0;
+    int64_t K = 0;
+#pragma unroll
+    for (int t = 0; t < vmgen::VM_LIN_TERMS; t++) {
+      if (t < T) {
+        const uint32_t op = (w[1 + t / 2] >> (16 * (t & 1))) & 0xFFFFu;
+        const int64_t c = (int64_t)(int16_t)((w[5 + t / 2] >> (16 * (t & 1))) & 0xFFFFu);
+        const F a = ld(regs, reg_of(op, bank));
+        if (c < 0) K -= 2 * c;
+#pragma unroll
+        for (int i = 0; i < N; i++) s[i] += c * (int64_t)a.v[i];
+      }
+    }
+    uint32_t t28[N];
+    int64_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+      cy += s[i] + K * (int64_t)P::mod(i);
+      t28[i] = (uint32_t)cy & MASK;
+      cy >>= 28;
+    }
+    cy += s[N - 1] + K * (int64_t)P::mod(N - 1);  // top limb, kept whole (>= 0)
+    const uint64_t top2 = ((uint64_t)cy << 28) | t28[N - 2];
+    const uint32_t est = (uint32_t)(top2 >> P::EST_SHIFT);
+    const uint32_t q = (uint32_t)(((uint64_t)est * P::EST_RECIP) >> 32);
+    int32_t r[N];
+    int64_t cc = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+      cc += (int64_t)t28[i] - (int64_t)((uint64_t)q * P::mod(i));
+      r[i] = (int32_t)((uint32_t)cc & MASK);
+      cc >>= 28;
+    }
+    cc += cy - (int64_t)((uint64_t)q * P::mod(N - 1));
+    r[N - 1] = (int32_t)cc;
+    return F::template norm_reduce<false>(r);
+  }
+};
+
+#if defined(__HIPCC__)
+// ---- the interpreter: one wave, registers in LDS ---------------------------------------------------------------------------------
+template <class F, class G /* vmgen::<curve> */>
+struct VmWave {
+  typedef VmArith<F> A;
+  typedef __attribute__((address_space(3))) uint32_t* Lds;
+  Lds regs;
+  uint32_t bank;
+  VmTables tb;
+
+  PCD_DEV void init(Lds r, const VmTables& t) {
+    regs = r; bank = 0; tb = t;
+    for (uint32_t c = threadIdx.x; c < (uint32_t)G::NCONST; c += 64) {
+      F v;
+#pragma unroll
+      for (int i = 0; i < F::N; i++) v.v[i] = tb.consts[c * F::N + i];
+      A::st(regs, G::CONST_BASE + c, v);
+    }
+  }
+  PCD_DEV F get_state(int slot) const { return A::ld(regs, A::reg_of((1u << 14) | (uint32_t)slot, bank)); }
+  PCD_DEV void set_state(int slot, const F& v) { A::st(regs, A::reg_of((1u << 14) | (uint32_t)slot, bank), v); }
+  PCD_DEV F get_reg(int r) const { return A::ld(regs, (uint32_t)r); }
+  PCD_DEV void set_reg(int r, const F& v) { A::st(regs, (uint32_t)r, v); }
+
+  // one program: steps in order, a barrier (one wave: a fence) after each; lanes beyond a step's instruction count idle
+  __device__ __noinline__ void run(int pid) {
+    const uint32_t first = tb.progs[3 * pid], cnt = tb.progs[3 * pid + 1];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t s = first; s < first + cnt; s++) {
+      const uint32_t kind = tb.steps[3 * s], off = tb.steps[3 * s + 1], n = tb.steps[3 * s + 2];
+      if (lane < n) {
+        uint32_t w[12];
+        const uint4* src = (const uint4*)(tb.code + (size_t)(off + lane) * 12);
+        const uint4 w0 = src[0], w1 = src[1], w2 = src[2];
+        w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+        w[8] = w2.x; w[9] = w2.y; w[10] = w2.z; w[11] = w2.w;
+        const F o = kind ? A::mul(w, regs, bank) : A::lin(w, regs, bank);
+        A::st(regs, A::reg_of(w[0] >> 16, bank), o);   // (every lane has read its operands before any lane stores: lockstep)
+      }
+      __syncthreads();
+    }
+    bank ^= tb.progs[3 * pid + 2];
+  }
+};
+#endif
+
+}  // namespace pcd

@@ -52,6 +52,9 @@ class DeviceExchange:
         self.limbs = limbs
         self.sends = torch.zeros(4 * limbs, dtype=torch.int64, device=device)
         self.recvs = [torch.zeros(self.world * limbs, dtype=torch.int64, device=device) for _ in range(4)]
+        # the collective of the pipelined form goes on a HIGH-PRIORITY stream: its few workgroups must be dispatched ahead of the thousands
+        # of accumulate workgroups of the other MSMs in flight, which would otherwise keep it waiting for a free CU
+        self.comm_stream = torch.cuda.Stream(device=device, priority=-1)
 
     def msm(self, bases, scalars_buf):
         import torch
@@ -72,8 +75,9 @@ class DeviceExchange:
         """all-gather of the partials of `ticket` (RCCL, on torch's stream, ordered behind the MSM by an event) + the EC sum"""
         import torch
         import torch.distributed as dist
-        ts = torch.cuda.current_stream().cuda_stream
-        self.ctx.msm_ticket_wait(ticket, ts)              # torch's stream waits for this slot's MSM (no host wait)
-        dist.all_gather_into_tensor(self.recvs[ticket], self.sends[ticket * self.limbs:(ticket + 1) * self.limbs])
+        ts = self.comm_stream.cuda_stream
+        self.ctx.msm_ticket_wait(ticket, ts)              # the collective's stream waits for this slot's MSM (no host wait)
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_gather_into_tensor(self.recvs[ticket], self.sends[ticket * self.limbs:(ticket + 1) * self.limbs])
         self.ctx.stream_wait(ts, 0)                       # the library's stream (and every later submission) waits for the gather
         return self.ctx.points_sum_device(self.curve, self.group, self.recvs[ticket].data_ptr(), self.world)

@@ -7,14 +7,23 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[0, 1], ids=["wave-per-pairing", "lane-per-pairing"])
+def pmode(request, gpu_ctx):
+    """both forms of the pairing kernels behind the same entry points (pcdhip_pairing_set_mode): one wave per pairing (default for
+    batches up to 4096 pairs: pairing_vm.hip.h) and one lane per pairing (pairing.hip.h)"""
+    gpu_ctx.pairing_set_mode(request.param)
+    yield request.param
+    gpu_ctx.pairing_set_mode(0)
+
+
 @pytest.mark.parametrize("cid", [0, 1, 2, 3])
-def test_pairing_golden(golden, gpu_ctx, cid):
+def test_pairing_golden(golden, gpu_ctx, pmode, cid):
     g = golden("pairing")
     assert np.array_equal(gpu_ctx.multi_pairing(cid, g[f"c{cid}_p"], g[f"c{cid}_q"]), g[f"c{cid}_gt"])
 
 
 @pytest.mark.parametrize("cid", [0, 1, 2, 3])
-def test_pairing_vs_oracle_bilinear_and_product(co, gpu_ctx, cid):
+def test_pairing_vs_oracle_bilinear_and_product(co, gpu_ctx, pmode, cid):
     fr = co.CURVE_FR[cid]
     k = co.gen_scalars(fr, 2, seed=31)
     g1, g2 = co.generator(cid, 1), co.generator(cid, 2)
@@ -35,7 +44,7 @@ def test_pairing_vs_oracle_bilinear_and_product(co, gpu_ctx, cid):
 
 
 @pytest.mark.parametrize("cid,nc", [(0, 300), (1, 200)])
-def test_groth16_verify_on_gpu(co, gpu_ctx, cid, nc):
+def test_groth16_verify_on_gpu(co, gpu_ctx, pmode, cid, nc):
     """tests/mnt4_groth16.rs:87 / :119 with BOTH prove and verify on the HIP path."""
     fr = co.CURVE_FR[cid]
     r = co.synthetic_r1cs(fr, nc, 3, seed=41)
@@ -57,7 +66,7 @@ def test_groth16_verify_on_gpu(co, gpu_ctx, cid, nc):
 
 
 @pytest.mark.parametrize("cid,nc", [(0, 300), (1, 200), (2, 40)])
-def test_groth16_verify_batch(co, gpu_ctx, cid, nc):
+def test_groth16_verify_batch(co, gpu_ctx, pmode, cid, nc):
     """The inputs of a merge node verified in one call (one launch for all Miller loops): per-proof answers equal the
     single verification and the oracle's, including a wrong public input, a wrong proof point and an empty batch."""
     import time
@@ -92,7 +101,7 @@ def test_groth16_verify_batch(co, gpu_ctx, cid, nc):
 
 
 @pytest.mark.parametrize("cid,nc", [(0, 300), (1, 200), (3, 40)])
-def test_process_vk_prepared_and_rlc_batch(co, gpu_ctx, cid, nc):
+def test_process_vk_prepared_and_rlc_batch(co, gpu_ctx, pmode, cid, nc):
     """SNARK::process_vk + verify_with_processed_vk (three Miller loops, one final exponentiation per proof, e(alpha, beta) cached) and
     the random-linear-combination batch with ONE shared final exponentiation: accept a batch of valid proofs, reject a batch with a
     wrong public input / a tampered proof; the prepared answers equal the plain ones and the oracle's."""
@@ -127,6 +136,34 @@ def test_process_vk_prepared_and_rlc_batch(co, gpu_ctx, cid, nc):
             gpu_ctx.groth16_verify_batch_rlc(pvk, pubs, proofs, np.zeros((k, 2), dtype=np.uint64))   # zero is not a challenge
     finally:
         pvk.free()
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_pairing_batch_both_forms_agree(co, gpu_ctx, cid):
+    """70 pairs in groups (more than one wave's worth of lanes, infinities at both ends, a group per two pairs): the wave-per-pairing
+    and the lane-per-pairing kernels return the same GT elements, and single pairs equal the oracle"""
+    n = 70 if cid < 2 else 10
+    fr = co.CURVE_FR[cid]
+    k = co.gen_scalars(fr, 2 * n, seed=211 + cid)
+    g1, g2 = co.generator(cid, 1), co.generator(cid, 2)
+    ps = np.stack([co.to_affine(cid, 1, co.scalar_mul(cid, 1, g1, k[i]))[0][0] for i in range(n)])
+    qs = np.stack([co.to_affine(cid, 2, co.scalar_mul(cid, 2, g2, k[n + i]))[0][0] for i in range(n)])
+    inf1 = np.zeros(n, dtype=np.uint8); inf2 = np.zeros(n, dtype=np.uint8)
+    inf1[0] = 1; inf2[n - 1] = 1; inf1[5] = inf2[5] = 1
+    outs = []
+    for mode in (0, 1):
+        gpu_ctx.pairing_set_mode(mode)
+        try:
+            whole = gpu_ctx.multi_pairing(cid, ps, qs, g1_inf=inf1, g2_inf=inf2)
+            singles = [gpu_ctx.multi_pairing(cid, ps[i], qs[i]) for i in (1, 2)]
+        finally:
+            gpu_ctx.pairing_set_mode(0)
+        outs.append((whole, singles))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(outs[0][1][0], co.pairing(cid, ps[1], qs[1]))
+    assert np.array_equal(outs[0][1][1], co.pairing(cid, ps[2], qs[2]))
 
 
 def test_proof_wire_round_trip_verifies(co, gpu_ctx):

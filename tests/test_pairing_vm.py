@@ -1,0 +1,81 @@
+"""CPU: the programs of the wave-per-pairing VM (tools/gen_pairing_vm.py -> pcd_amd/csrc/pairing_vm_gen.h).
+
+  * the generated header is the one the generator writes today (nobody edited either side alone);
+  * the programs -- formulas, levelling, register allocation, per-slot banking -- evaluated with Python integers give the textbook
+    reduced ate pairing of the test oracle (oracle/pyoracle.py: affine slopes, naive final exponent) on all four curves, for single
+    pairings, for products, and with points at both ends of the group;
+  * structural bounds the device interpreter relies on (terms per instruction, coefficient weight, register counts).
+The device's limb arithmetic for the same programs is checked in tests/test_hostcheck.py::test_vm_pairing (host build) and under
+`-m gpu` (tests/test_gpu_pairing_kzg.py)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def gen():
+    import gen_pairing_vm as g
+    return g
+
+
+@pytest.fixture(scope="module")
+def envs(gen):
+    return [gen.compile_env(gen.build(c)) for c in range(4)]
+
+
+def test_header_is_current(gen, envs):
+    have = open(os.path.join(ROOT, "pcd_amd", "csrc", "pairing_vm_gen.h")).read()
+    assert have == gen.emit(envs), "pairing_vm_gen.h is stale: run python tools/gen_pairing_vm.py"
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_programs_compute_the_pairing(gen, envs, cid):
+    from oracle import pyoracle as po
+    env, cv = envs[cid], po.CURVES[cid]
+    F1, a1 = cv.group(1)
+    F2, a2 = cv.group(2)
+    r = cv.fr.p
+    pairs = []
+    for s1, s2 in ((12345 + cid, 6789), (1, 1), (r - 1, 2), (777, r - 5)):
+        P, Q = po.ec_mul(F1, a1, s1, cv.g1), po.ec_mul(F2, a2, s2, cv.g2)
+        pairs.append((P, Q))
+    want_prod = cv.Fk.one()
+    fs = []
+    for P, Q in pairs:
+        f, _ = gen.eval_miller(env, (P[0][0], P[1][0]), (list(Q[0]), list(Q[1])))
+        gt, _ = gen.eval_final_exp(env, [f])
+        want = po.pairing(cv, P, Q)
+        assert tuple(gt) == tuple(want)
+        want_prod = cv.Fk.mul(want_prod, want)
+        fs.append(f)
+    gt, _ = gen.eval_final_exp(env, fs)
+    assert tuple(gt) == tuple(want_prod)
+    # e(P, Q) e(-P, Q) = 1
+    P, Q = pairs[0]
+    f2, _ = gen.eval_miller(env, (P[0][0], (-P[1][0]) % cv.fq.p), (list(Q[0]), list(Q[1])))
+    gt, _ = gen.eval_final_exp(env, [fs[0], f2])
+    assert tuple(gt) == tuple(cv.Fk.one())
+
+
+def test_bounds_the_interpreter_relies_on(gen, envs):
+    for env in envs:
+        nregs = 2 * len(env.slots) + len(env.const_values) + len(env.regs) + env.ntemp
+        assert len(env.slots) <= 32 and nregs < (1 << 14)
+        stride = (env.N + 3) // 4 * 4
+        assert nregs * stride * 4 <= 64 * 1024          # LDS of one workgroup
+        for name, c in env.compiled.items():
+            for kind, instrs in c["steps"]:
+                assert 1 <= len(instrs) <= 64
+                for dst, terms, k in instrs:
+                    assert k == kind
+                    if kind == gen.K_MUL:
+                        assert 1 <= len(terms) <= gen.TMAX
+                    else:
+                        assert 1 <= len(terms) <= gen.LIN_TERMS and sum(abs(cf) for cf, _ in terms) <= gen.LIN_WEIGHT
+        # MUL closes on [0, 2p) without a final subtraction only while TMAX * 4 p^2 / R' + p < 2p
+        Rp = 1 << (28 * env.N)
+        assert gen.TMAX * 4 * env.p < Rp or gen.TMAX > 2

@@ -1,0 +1,749 @@
+#!/usr/bin/env python3
+"""Compile the MNT4 / MNT6 ate pairing into straight-line programs for the wave-wide field VM (pcd_amd/csrc/pairing_vm.hip.h).
+
+K6 of SURVEY.md section 8: `PairingEngine::{miller_loop, final_exponentiation}` behind `Groth16::verify`
+(/root/reference src/ec_cycle_pcd/mod.rs:239) and `process_vk` (mod.rs:71).  One pairing in one lane is a chain of ~13 000 dependent
+field products; here ONE WAVE runs one pairing: every value lives in an LDS register, a program is a list of steps, and in a step
+up to 64 lanes execute one instruction each --
+
+    MUL   dst = (sum_{t < T} A_t * B_t) / R'  mod p        (T <= TMAX products into one column accumulator, one Montgomery reduction)
+    LIN   dst = sum_{t < 8} c_t * A_t        mod p        (small signed integer coefficients)
+
+both closed on [0, 2p).  Fq4 / Fq6 are the binomial extensions Fq[v]/(v^k - nr) (u = v^2 spans the twist field Fq2 / Fq3), so every
+tower operation is a sparse polynomial product whose coefficient sums of equal weight become MUL instructions on sibling lanes and
+whose weights (1, 2, nr, 2 nr) are applied by the LIN that follows.  This script traces the formulas (the ones of pairing.hip.h, i.e.
+ark-ec's flipped Miller loop with extended Jacobian coordinates, written once over that polynomial ring), levels the dependency
+graph (LIN on even slots, MUL on odd ones), allocates registers (state registers are double-banked per slot so that a program may
+overwrite its inputs), evaluates the programs with Python integers -- tests/test_pairing_vm.py compares that evaluation with the
+textbook pairing of the test oracle -- and writes pcd_amd/csrc/pairing_vm_gen.h.
+
+    python tools/gen_pairing_vm.py            # regenerate the header
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B28 = 28
+TMAX = 2          # products per MUL instruction
+LIN_TERMS = 8     # terms per LIN instruction
+LIN_WEIGHT = 124  # sum of |coefficients| a LIN may carry (inputs below 2p: the device reduces values below 2^8 p)
+LANES = 64
+
+K_LIN, K_MUL = 0, 1
+SP_REG, SP_IN, SP_OUT = 0, 1, 2   # operand spaces: plain register, state slot (current bank), state slot (other bank)
+
+
+def params():
+    return json.load(open(os.path.join(ROOT, "oracle", "params.json")))
+
+
+# ------------------------------------------------------------------------------------------------ program builder
+class Prog:
+    """One straight-line program.  Values are node ids (None = zero).  Leaves: state slots and plain registers (constants, inputs)."""
+
+    def __init__(self, env, name):
+        self.env, self.name = env, name
+        self.nodes = []       # (kind, payload): ('leaf', (space, idx)) | ('mul', [(a, b)]) | ('lin', [(c, a)])
+        self.leaf_cache = {}
+        self.outputs = []     # (state slot, node)
+        self.reg_outputs = [] # (plain register index, node): values handed to later programs of the same kernel without banking
+
+    def leaf(self, space, idx):
+        key = (space, idx)
+        if key not in self.leaf_cache:
+            self.nodes.append(("leaf", key))
+            self.leaf_cache[key] = len(self.nodes) - 1
+        return self.leaf_cache[key]
+
+    def state(self, name):
+        return self.leaf(SP_IN, self.env.slot(name))
+
+    def reg(self, name):
+        return self.leaf(SP_REG, self.env.reg(name))
+
+    def const(self, value):
+        return self.leaf(SP_REG, self.env.const(value))
+
+    def mul(self, terms):
+        terms = [(a, b) for a, b in terms if a is not None and b is not None]
+        if not terms:
+            return None
+        assert len(terms) <= TMAX
+        self.nodes.append(("mul", terms))
+        return len(self.nodes) - 1
+
+    def lin(self, terms):
+        """sum c * a with integer c; LIN operands that are themselves LIN nodes are expanded (one LIN level between products)"""
+        p = self.env.p
+        flat = {}
+
+        def put(c, a):
+            if a is None or c % p == 0:
+                return
+            flat[a] = flat.get(a, 0) + c
+        for c, a in terms:
+            if a is None:
+                continue
+            kind, pay = self.nodes[a]
+            if kind == "lin":
+                for c2, a2 in pay:
+                    put(c * c2, a2)
+            else:
+                put(c, a)
+        out = [(c, a) for a, c in flat.items() if c != 0]
+        if not out:
+            return None
+        if len(out) == 1 and out[0][0] == 1:
+            return out[0][1]
+        if len(out) > LIN_TERMS or sum(abs(c) for c, _ in out) > LIN_WEIGHT:
+            # too wide to expand: keep the LIN operands as values of their own
+            out2 = {}
+            for c, a in terms:
+                if a is not None and c != 0:
+                    out2[a] = out2.get(a, 0) + c
+            out = [(c, a) for a, c in out2.items() if c != 0]
+            assert len(out) <= LIN_TERMS and sum(abs(c) for c, _ in out) <= LIN_WEIGHT, (self.name, out)
+        self.nodes.append(("lin", out))
+        return len(self.nodes) - 1
+
+    def out(self, name, node):
+        self.outputs.append((self.env.slot(name), node))
+
+    def out_reg(self, name, node):
+        self.reg_outputs.append((self.env.reg(name), node))
+
+
+class X:
+    """element of Fq[v]/(v^k - nr) with sparse coefficients (node ids of a Prog, None = 0)"""
+
+    def __init__(self, P, c):
+        self.P, self.c = P, list(c)
+
+    @property
+    def k(self):
+        return len(self.c)
+
+    def _lin2(self, o, ca, cb):
+        return X(self.P, [self.P.lin([(ca, a), (cb, b)]) for a, b in zip(self.c, o.c)])
+
+    def __add__(self, o):
+        return self._lin2(o, 1, 1)
+
+    def __sub__(self, o):
+        return self._lin2(o, 1, -1)
+
+    def neg(self):
+        return X(self.P, [self.P.lin([(-1, a)]) for a in self.c])
+
+    def times(self, m):
+        return X(self.P, [self.P.lin([(m, a)]) for a in self.c])
+
+    def dbl(self):
+        return self.times(2)
+
+    def shift(self, power, coeff=1):
+        """self * coeff * v^power"""
+        nr, k = self.P.env.nr, self.k
+        out = [None] * k
+        for j, a in enumerate(self.c):
+            m = (j + power) % k
+            wraps = (j + power) // k
+            out[m] = self.P.lin([(coeff * nr ** wraps, a)])
+        return X(self.P, out)
+
+    def __mul__(self, o):
+        P, k, nr = self.P, self.k, self.P.env.nr
+        same = self.c == o.c
+        groups = [dict() for _ in range(k)]   # output coefficient -> weight -> list of products
+        for i, a in enumerate(self.c):
+            for j, b in enumerate(o.c):
+                if a is None or b is None:
+                    continue
+                w = nr if i + j >= k else 1
+                if same:
+                    if j < i:
+                        continue
+                    if j > i:
+                        w *= 2
+                groups[(i + j) % k].setdefault(w, []).append((a, b))
+        out = []
+        for m in range(k):
+            terms = []
+            for w, prods in sorted(groups[m].items()):
+                for s in range(0, len(prods), TMAX):
+                    terms.append((w, P.mul(prods[s:s + TMAX])))
+            out.append(P.lin(terms))
+        return X(P, out)
+
+    def sqr(self):
+        return self * self
+
+    def frob(self, i):
+        """x^(q^i): coefficient j times w^(i j), w = nr^((q - 1) / k)"""
+        env = self.P.env
+        out = []
+        for j, a in enumerate(self.c):
+            e = (i * j) % self.k
+            out.append(a if (a is None or e == 0) else self.P.mul([(a, self.P.const(env.frob_w[e]))]))
+        return X(self.P, out)
+
+    def even(self):
+        return X(self.P, [a if j % 2 == 0 else None for j, a in enumerate(self.c)])
+
+    def odd_over_v(self):
+        """A1 with self = A0(v^2) + v A1(v^2), as an even polynomial"""
+        out = [None] * self.k
+        for j, a in enumerate(self.c):
+            if j % 2 == 1:
+                out[j - 1] = a
+        return X(self.P, out)
+
+    def conj(self):
+        return X(self.P, [a if j % 2 == 0 else self.P.lin([(-1, a)]) for j, a in enumerate(self.c)])
+
+
+# ------------------------------------------------------------------------------------------------ one curve
+class Env:
+    def __init__(self, cid):
+        PR = params()
+        c = PR["curves"][cid]
+        f = PR["fields"][int(c["fq"])]
+        self.cid, self.name = cid, c["name"]
+        self.p = int(f["p"])
+        self.field_name = f["name"]
+        self.N = 11 if f["bits"] < 320 else 27
+        self.k = int(c["k"])
+        self.nr = int(c["nr"])
+        self.a = int(c["a"])
+        self.ate_loop, self.ate_neg = int(c["ate_loop"]), c["ate_neg"] in (True, "True")
+        self.w0, self.w0_neg = int(c["w0"]), c["w0_neg"] in (True, "True")
+        assert (self.p - 1) % self.k == 0
+        w = pow(self.nr, (self.p - 1) // self.k, self.p)
+        self.frob_w = [pow(w, i, self.p) for i in range(self.k)]
+        self.slots, self.regs, self.consts = {}, {}, {}
+        self.const_values = []   # plain registers 0 .. : constants first, then named registers
+        self.progs = {}
+
+    def slot(self, name):
+        if name not in self.slots:
+            self.slots[name] = len(self.slots)
+        return self.slots[name]
+
+    def const(self, value):
+        value %= self.p
+        if value not in self.consts:
+            self.consts[value] = len(self.const_values)
+            self.const_values.append(value)
+        return ("c", self.consts[value])
+
+    def reg(self, name):
+        if name not in self.regs:
+            self.regs[name] = len(self.regs)
+        return ("r", self.regs[name])
+
+    def prog(self, name):
+        P = Prog(self, name)
+        self.progs[name] = P
+        return P
+
+    # ---- named groups of registers / slots
+    def st(self, P, name, idxs):
+        return X(P, [P.state(f"{name}{j}") if j in idxs else None for j in range(self.k)])
+
+    def rg(self, P, name, idxs):
+        return X(P, [P.reg(f"{name}{j}") if j in idxs else None for j in range(self.k)])
+
+    def put(self, P, name, x, idxs):
+        for j in idxs:
+            node = x.c[j]
+            if node is None:
+                node = P.lin([(0, None)]) or P.const(0)
+            P.out(f"{name}{j}", node)
+
+    def put_reg(self, P, name, x, idxs):
+        for j in idxs:
+            node = x.c[j] if x.c[j] is not None else P.const(0)
+            P.out_reg(f"{name}{j}", node)
+
+
+def build(cid):
+    env = Env(cid)
+    k, nr = env.k, env.nr
+    EV = list(range(0, k, 2))    # coefficient positions of a twist-field element (even powers of v)
+    ALL = list(range(k))
+    one = lambda P: X(P, [P.const(1)] + [None] * (k - 1))
+
+    def mul_by_a(x):             # times the twist's a' = a u^2 = a v^4
+        return x.shift(4, env.a)
+
+    # ---------------- Miller loop (one wave per pair) ----------------
+    # plain registers: px0, py0 (G1 point), qx*, qy* (G2 point, even positions), derived once by `setup`:
+    #   qyo* = qy / twist, l1c* = px - qx / twist, qy2* = qy^2      (twist = u = v^2;  1 / u = u^(d-1) / nr)
+    P = env.prog("setup")
+    px, py = P.reg("px0"), P.reg("py0")
+    qx, qy = env.rg(P, "qx", EV), env.rg(P, "qy", EV)
+    inv_nr = pow(nr, -1, env.p)
+    # x / u = x * v^(k-2) / nr
+    def over_twist(x):
+        sh = x.shift(k - 2)
+        return X(P, [None if a is None else P.mul([(a, P.const(inv_nr))]) for a in sh.c])
+    qxo, qyo = over_twist(qx), over_twist(qy)
+    l1c = X(P, [px] + [None] * (k - 1)) - qxo
+    env.put_reg(P, "qyo", qyo, EV)
+    env.put_reg(P, "l1c", l1c, EV)
+    env.put_reg(P, "qy2", qy.sqr(), EV)
+    # state: r = (x, y, z, t) <- (qx, qy, 1, 1), f <- 1
+    env.put(P, "rx", qx, EV); env.put(P, "ry", qy, EV)
+    env.put(P, "rz", one(P), EV); env.put(P, "rt", one(P), EV)
+    env.put(P, "f", one(P), ALL)
+
+    def line_regs(P):
+        pxt = X(P, [None, None, P.reg("px0")] + [None] * (k - 3))   # px * twist
+        pyt = X(P, [None, None, P.reg("py0")] + [None] * (k - 3))
+        return pxt, pyt
+
+    P = env.prog("dbl")
+    x, y, z, t = (env.st(P, n, EV) for n in ("rx", "ry", "rz", "rt"))
+    f = env.st(P, "f", ALL)
+    pxt, pyt = line_regs(P)
+    a, b, c = t.sqr(), x.sqr(), y.sqr()
+    d = c.sqr()
+    e = (x + c).sqr() - b - d
+    fq = b.times(3) + mul_by_a(a)
+    g = fq.sqr()
+    ox = g - e.times(4)
+    oy = fq * (e.dbl() - ox) - d.times(8)
+    oz = (y + z).sqr() - c - z.sqr()
+    ot = oz.sqr()
+    c_h = (oz + t).sqr() - ot - a
+    c_j = (fq + t).sqr() - g - a
+    c_l = (fq + x).sqr() - g - b
+    g_rr = (c_l - c.times(4) - c_j * pxt) + (c_h * pyt).shift(1)
+    fn = f.sqr() * g_rr
+    for n, v in (("rx", ox), ("ry", oy), ("rz", oz), ("rt", ot)):
+        env.put(P, n, v, EV)
+    env.put(P, "f", fn, ALL)
+
+    P = env.prog("add")
+    x, y, z, t = (env.st(P, n, EV) for n in ("rx", "ry", "rz", "rt"))
+    f = env.st(P, "f", ALL)
+    pxt, pyt = line_regs(P)
+    qx, qy, qy2 = env.rg(P, "qx", EV), env.rg(P, "qy", EV), env.rg(P, "qy2", EV)
+    qyo, l1c = env.rg(P, "qyo", EV), env.rg(P, "l1c", EV)
+    bb = t * qx
+    dd = ((z + qy).sqr() - qy2 - t) * t
+    h = bb - x
+    i = h.sqr()
+    e = i.times(4)
+    j = h * e
+    v = x * e
+    l1 = dd - y.dbl()
+    ox = l1.sqr() - j - v.dbl()
+    oy = l1 * (v - ox) - j * y.dbl()
+    oz = (z + h).sqr() - t - i
+    ot = oz.sqr()
+    line = (oz * pyt) + (qyo * oz + l1c * l1).neg().shift(1)
+    fn = f * line
+    for n, vv in (("rx", ox), ("ry", oy), ("rz", oz), ("rt", ot)):
+        env.put(P, n, vv, EV)
+    env.put(P, "f", fn, ALL)
+
+    # loop count < 0: upstream multiplies by the line through R and -R and inverts.  That line is (0, 4 l1c r.y) exactly (the mixed
+    # addition of R and its own affine negation has h = 0, so o.z = 0 and l1 = -4 r.y: no inversion of r.z is needed to know it),
+    # and the inversion of f is deferred: the final exponentiation of an inverse is the conjugate of the final exponentiation.
+    P = env.prog("negfix")
+    y = env.st(P, "ry", EV)
+    f = env.st(P, "f", ALL)
+    l1c = env.rg(P, "l1c", EV)
+    line = (l1c * y).times(4).shift(1)
+    env.put(P, "f", f * line, ALL)
+
+    # ---------------- final exponentiation (one wave per product of Miller values) ----------------
+    # state: acc (the product, then powers), plain registers: g (the next factor), v, vi, fst, fsti, nrm (Fq), ninv (Fq)
+    P = env.prog("fe_mul")      # acc *= g
+    env.put(P, "acc", env.st(P, "acc", ALL) * env.rg(P, "g", ALL), ALL)
+
+    P = env.prog("fe_norm")     # the norm of acc down to Fq: acc^-1 = conj-like / norm
+    v = env.st(P, "acc", ALL)
+    A0, A1 = v.even(), v.odd_over_v()
+    n_e = A0.sqr() - A1.sqr().shift(2)                 # in the twist field (even positions): A0^2 - u A1^2
+    d = k // 2
+    ne = [n_e.c[2 * j] for j in range(d)]              # coefficients over u
+    if d == 2:
+        t0, t1 = ne[0], P.lin([(-1, ne[1])])
+        nrm = P.lin([(1, P.mul([(ne[0], ne[0])])), (-nr, P.mul([(ne[1], ne[1])]))])
+        cof = [t0, t1]
+    else:
+        m = lambda a_, b_: P.mul([(a_, b_)])
+        t0 = P.lin([(1, m(ne[0], ne[0])), (-nr, m(ne[1], ne[2]))])
+        t1 = P.lin([(nr, m(ne[2], ne[2])), (-1, m(ne[0], ne[1]))])
+        t2 = P.lin([(1, m(ne[1], ne[1])), (-1, m(ne[0], ne[2]))])
+        nrm = P.lin([(1, m(ne[0], t0)), (nr, m(ne[2], t1)), (nr, m(ne[1], t2))])
+        cof = [t0, t1, t2]
+    P.out_reg("nrm0", nrm)
+    for j in range(d):
+        P.out_reg(f"cof{2 * j}", cof[j])                # inverse of n_e = cof / nrm
+    env.put_reg(P, "v", v, ALL)
+
+    P = env.prog("fq_sqr")      # Fermat inversion of nrm: pw <- pw^2, pw <- pw * nrm
+    P.out("pw0", P.mul([(P.state("pw0"), P.state("pw0"))]))
+    P = env.prog("fq_mul")
+    P.out("pw0", P.mul([(P.state("pw0"), P.reg("nrm0"))]))
+    P = env.prog("fq_init")
+    P.out("pw0", P.reg("nrm0"))
+
+    P = env.prog("fe_easy")     # vi = conj_v(v) * (cof * ninv); first = v^(q^(k/2)) * vi ...
+    v = env.rg(P, "v", ALL)
+    ninv = P.state("pw0")
+    ne_inv = X(P, [None] * k)
+    for j in range(d):
+        ne_inv.c[2 * j] = P.mul([(P.reg(f"cof{2 * j}"), ninv)])
+    A0, A1 = v.even(), v.odd_over_v()
+    vi = (A0 * ne_inv) + (A1 * ne_inv).neg().shift(1)
+    if k == 4:
+        first, first_inv = v.frob(2) * vi, vi.frob(2) * v
+    else:
+        aa, ai = v.frob(3) * vi, vi.frob(3) * v
+        first, first_inv = aa.frob(1) * aa, ai.frob(1) * ai
+    base = first_inv if env.w0_neg else first
+    env.put_reg(P, "pb", base, ALL)                     # the base of the w0 power
+    env.put_reg(P, "ff", first.frob(1), ALL)            # first^q
+    env.put(P, "acc", base, ALL)                        # the power accumulator starts at the base (top bit of w0)
+
+    P = env.prog("pow_sqr")
+    env.put(P, "acc", env.st(P, "acc", ALL).sqr(), ALL)
+    P = env.prog("pow_mul")
+    env.put(P, "acc", env.st(P, "acc", ALL) * env.rg(P, "pb", ALL), ALL)
+    P = env.prog("fe_last")     # result = first^q * pow;  conjugated when the Miller values were left un-inverted (loop count < 0)
+    res = env.rg(P, "ff", ALL) * env.st(P, "acc", ALL)
+    if env.ate_neg:
+        res = res.conj()
+    env.put(P, "acc", res, ALL)
+    return env
+
+
+# ------------------------------------------------------------------------------------------------ scheduling / allocation
+def compile_prog(env, P, nconst_regs):
+    """-> dict(steps=[(kind, [instr])], written=[slots], ntemp) with instr = (dst, [(x, y)]) operands encoded as (space, index)"""
+    nodes = P.nodes
+    wanted = {}
+    for slot, node in P.outputs:
+        wanted.setdefault(node, []).append((SP_OUT, slot))
+    for reg, node in P.reg_outputs:
+        wanted.setdefault(node, []).append((SP_REG, reg))
+    # liveness from the outputs
+    live = set()
+    stack = list(wanted)
+    while stack:
+        n = stack.pop()
+        if n in live:
+            continue
+        live.add(n)
+        kind, pay = nodes[n]
+        if kind == "mul":
+            for a, b in pay:
+                stack += [a, b]
+        elif kind == "lin":
+            stack += [a for _, a in pay]
+    # an output that is a leaf (or shared by two destinations) needs a copy: a LIN with one unit term
+    extra = []
+    for node, dests in list(wanted.items()):
+        kind, _ = nodes[node]
+        first = 0 if kind != "leaf" else None
+        for di, dest in enumerate(dests):
+            if first is not None and di == first:
+                continue
+            extra.append((dest, node))
+        wanted[node] = [dests[first]] if first is not None else []
+    slot_of = {}
+    order = [n for n in range(len(nodes)) if n in live]
+    for n in order:
+        kind, pay = nodes[n]
+        if kind == "leaf":
+            slot_of[n] = -1
+            continue
+        preds = [x for t in pay for x in (t if kind == "mul" else (t[1],))]
+        lo = max(slot_of[x] for x in preds) + 1
+        par = 1 if kind == "mul" else 0
+        if lo % 2 != par:
+            lo += 1
+        slot_of[n] = lo
+    copies = []   # (slot time, dest, src node)
+    for dest, node in extra:
+        lo = slot_of[node] + 1
+        if lo % 2 != 0:
+            lo += 1
+        copies.append((lo, dest, node))
+    last = max([slot_of[n] for n in order] + [c[0] for c in copies] + [0])
+    # last use of every node (in slot time)
+    last_use = {}
+    for n in order:
+        kind, pay = nodes[n]
+        if kind == "leaf":
+            continue
+        preds = [x for t in pay for x in (t if kind == "mul" else (t[1],))]
+        for x in preds:
+            last_use[x] = max(last_use.get(x, -1), slot_of[n])
+    for lo, dest, node in copies:
+        last_use[node] = max(last_use.get(node, -1), lo)
+    # registers: outputs go straight to their destination; everything else gets a temporary, freed after its last use
+    loc = {}
+    free, ntemp = [], 0
+    by_slot = {}
+    for n in order:
+        if nodes[n][0] != "leaf":
+            by_slot.setdefault(slot_of[n], []).append(n)
+    for lo, dest, node in copies:
+        by_slot.setdefault(lo, []).append(("copy", dest, node))
+    for n in order:
+        if nodes[n][0] == "leaf":
+            loc[n] = nodes[n][1]
+    expiring = {}
+    steps = []
+    tbase = None
+    for s in range(last + 1):
+        items = by_slot.get(s, [])
+        # temporaries whose last reader ran in an EARLIER slot are free again (readers of slot s read before anyone writes in s)
+        for n in expiring.pop(s - 1, []):
+            free.append(loc[n][1][1])
+        instrs = []
+        for it in items:
+            if isinstance(it, tuple):
+                _, dest, node = it
+                instrs.append((dest, [(1, loc[node])], K_LIN))
+                continue
+            n = it
+            kind, pay = nodes[n]
+            if wanted.get(n):
+                loc[n] = wanted[n][0]
+            else:
+                if free:
+                    r = free.pop()
+                else:
+                    r = ntemp
+                    ntemp += 1
+                loc[n] = (SP_REG, ("t", r))
+                expiring.setdefault(last_use.get(n, s), []).append(n)
+            if kind == "mul":
+                instrs.append((loc[n], [(loc[a], loc[b]) for a, b in pay], K_MUL))
+            else:
+                instrs.append((loc[n], [(c, loc[a]) for c, a in pay], K_LIN))
+        if not instrs:
+            continue
+        kind = instrs[0][2]
+        assert all(i[2] == kind for i in instrs)
+        for q in range(0, len(instrs), LANES):
+            steps.append((kind, instrs[q:q + LANES]))
+    written = sorted({d[1] for d, _, _ in sum((i for _, i in steps), []) if d[0] == SP_OUT})
+    return dict(steps=steps, written=written, ntemp=ntemp)
+
+
+def compile_env(env):
+    out = {}
+    for name, P in env.progs.items():
+        out[name] = compile_prog(env, P, len(env.const_values))
+    env.compiled = out
+    env.ntemp = max(c["ntemp"] for c in out.values())
+    return env
+
+
+# register file layout: [2 * nslots state registers][constants][named registers][temporaries]
+def reg_index(env, op):
+    space, idx = op
+    if space in (SP_IN, SP_OUT):
+        return space, idx
+    tag, i = idx
+    base = 2 * len(env.slots)
+    if tag == "c":
+        return SP_REG, base + i
+    if tag == "r":
+        return SP_REG, base + len(env.const_values) + i
+    return SP_REG, base + len(env.const_values) + len(env.regs) + i
+
+
+# ------------------------------------------------------------------------------------------------ evaluation with Python integers
+class Machine:
+    """what the device interpreter does, on integers mod p (no Montgomery form, no limbs): program logic, schedule, banking"""
+
+    def __init__(self, env):
+        self.env = env
+        self.nregs = 2 * len(env.slots) + len(env.const_values) + len(env.regs) + env.ntemp
+        self.r = [0] * self.nregs
+        self.bank = 0
+        base = 2 * len(env.slots)
+        for i, v in enumerate(env.const_values):
+            self.r[base + i] = v
+        self.steps_run = 0
+
+    def addr(self, op, writing=False):
+        space, idx = reg_index(self.env, op)
+        if space == SP_REG:
+            return idx
+        cur = (self.bank >> idx) & 1
+        return 2 * idx + (cur ^ (1 if space == SP_OUT else 0))
+
+    def set_reg(self, name, value):
+        self.r[self.addr((SP_REG, ("r", self.env.regs[name])))] = value % self.env.p
+
+    def get_reg(self, name):
+        return self.r[self.addr((SP_REG, ("r", self.env.regs[name])))]
+
+    def set_state(self, name, value):
+        self.r[self.addr((SP_IN, self.env.slots[name]))] = value % self.env.p
+
+    def get_state(self, name):
+        return self.r[self.addr((SP_IN, self.env.slots[name]))]
+
+    def run(self, name):
+        p = self.env.p
+        c = self.env.compiled[name]
+        for kind, instrs in c["steps"]:
+            vals = []
+            for dst, terms, _ in instrs:       # every lane reads ...
+                if kind == K_MUL:
+                    vals.append(sum(self.r[self.addr(a)] * self.r[self.addr(b)] for a, b in terms) % p)
+                else:
+                    vals.append(sum(cf * self.r[self.addr(a)] for cf, a in terms) % p)
+            for (dst, _, _), v in zip(instrs, vals):   # ... before any lane writes
+                self.r[self.addr(dst)] = v
+            self.steps_run += 1
+        for s in c["written"]:
+            self.bank ^= 1 << s
+
+
+def eval_miller(env, P1, Q2):
+    """P1 = (x, y) in Fq, Q2 = (x coefficients, y coefficients) over u -> the k flat coefficients of the (un-inverted) Miller value"""
+    M = Machine(env)
+    M.set_reg("px0", P1[0]); M.set_reg("py0", P1[1])
+    for j in range(env.k // 2):
+        M.set_reg(f"qx{2 * j}", Q2[0][j]); M.set_reg(f"qy{2 * j}", Q2[1][j])
+    M.run("setup")
+    bits = bin(env.ate_loop)[3:]
+    for b in bits:
+        M.run("dbl")
+        if b == "1":
+            M.run("add")
+    if env.ate_neg:
+        M.run("negfix")
+    return [M.get_state(f"f{j}") for j in range(env.k)], M.steps_run
+
+
+def eval_final_exp(env, fs):
+    """fs: list of flat Miller values -> flat GT element"""
+    M = Machine(env)
+    for j in range(env.k):
+        M.set_state(f"acc{j}", fs[0][j])
+    for g in fs[1:]:
+        for j in range(env.k):
+            M.set_reg(f"g{j}", g[j])
+        M.run("fe_mul")
+    M.run("fe_norm")
+    M.run("fq_init")
+    e = env.p - 2
+    for b in bin(e)[3:]:
+        M.run("fq_sqr")
+        if b == "1":
+            M.run("fq_mul")
+    M.run("fe_easy")
+    for b in bin(env.w0)[3:]:
+        M.run("pow_sqr")
+        if b == "1":
+            M.run("pow_mul")
+    M.run("fe_last")
+    return [M.get_state(f"acc{j}") for j in range(env.k)], M.steps_run
+
+
+# ------------------------------------------------------------------------------------------------ header
+def limbs28(x, n):
+    return [(x >> (B28 * i)) & ((1 << B28) - 1) for i in range(n)]
+
+
+def enc_operand(env, op):
+    space, idx = reg_index(env, op)
+    assert idx < (1 << 14)
+    return (space << 14) | idx
+
+
+def emit(envs):
+    L = ["// GENERATED by tools/gen_pairing_vm.py -- do not edit.  Programs of the wave-wide field VM (pairing_vm.hip.h).",
+         "#pragma once", "#include <stdint.h>", "", "namespace pcd { namespace vmgen {", "",
+         f"constexpr int VM_TMAX = {TMAX}, VM_LIN_TERMS = {LIN_TERMS};",
+         "// instruction = 12 words: w0 = kind | terms << 8 | dst << 16;  MUL: w[1 + t] = a_t | b_t << 16;  LIN: w[1 + t / 2] holds operand t in its",
+         "// low / high half, w[5 + t / 2] the signed 16-bit coefficient.  Operand = space << 14 | index (space 0: register, 1: state slot in its",
+         "// current bank, 2: state slot in the other bank).", ""]
+    for env in envs:
+        N = env.N
+        Rp = 1 << (B28 * N)
+        nm = env.name
+        words, steps, progs = [], [], []
+        for pname, c in env.compiled.items():
+            first = len(steps)
+            for kind, instrs in c["steps"]:
+                steps.append((kind, len(words) // 12, len(instrs)))
+                for dst, terms, _ in instrs:
+                    w = [0] * 12
+                    w[0] = kind | (len(terms) << 8) | (enc_operand(env, dst) << 16)
+                    if kind == K_MUL:
+                        for t, (a, b) in enumerate(terms):
+                            w[1 + t] = enc_operand(env, a) | (enc_operand(env, b) << 16)
+                    else:
+                        for t, (cf, a) in enumerate(terms):
+                            assert -32768 <= cf < 32768
+                            w[1 + t // 2] |= enc_operand(env, a) << (16 * (t % 2))
+                            w[5 + t // 2] |= (cf & 0xFFFF) << (16 * (t % 2))
+                    words += w
+            mask = 0
+            for s in c["written"]:
+                mask |= 1 << s
+            progs.append((pname, first, len(steps) - first, mask))
+        assert len(env.slots) <= 32
+        nregs = 2 * len(env.slots) + len(env.const_values) + len(env.regs) + env.ntemp
+        L.append(f"// ---- {nm}: {len(env.slots)} state slots, {len(env.const_values)} constants, {len(env.regs)} named registers, {env.ntemp} temporaries")
+        L.append(f"struct {nm} {{")
+        L.append(f"  static constexpr int NSLOTS = {len(env.slots)}, NCONST = {len(env.const_values)}, NNAMED = {len(env.regs)}, NTEMP = {env.ntemp}, NREGS = {nregs};")
+        L.append(f"  static constexpr int CONST_BASE = {2 * len(env.slots)}, NAMED_BASE = {2 * len(env.slots) + len(env.const_values)};")
+        for pi, (pname, first, cnt, mask) in enumerate(progs):
+            L.append(f"  static constexpr int P_{pname.upper()} = {pi};")
+        for sname, si in env.slots.items():
+            L.append(f"  static constexpr int S_{sname.upper()} = {si};")
+        for rname, ri in env.regs.items():
+            L.append(f"  static constexpr int R_{rname.upper()} = {2 * len(env.slots) + len(env.const_values) + ri};")
+        L.append("};")
+        L.append(f"static const uint32_t {nm}_progs[{len(progs)}][3] = {{  // first step, steps, mask of the state slots written")
+        L.append("  " + ", ".join(f"{{{first}, {cnt}, 0x{mask:08x}u}}" for _, first, cnt, mask in progs) + "};")
+        L.append(f"static const uint32_t {nm}_steps[{len(steps)}][3] = {{  // kind, first instruction, instructions")
+        for q in range(0, len(steps), 8):
+            L.append("  " + ", ".join(f"{{{k_}, {o}, {n_}}}" for k_, o, n_ in steps[q:q + 8]) + ",")
+        L.append("};")
+        L.append(f"static const uint32_t {nm}_code[{len(words)}] = {{")
+        for q in range(0, len(words), 12):
+            L.append("  " + ", ".join(f"0x{w:08x}u" for w in words[q:q + 12]) + ",")
+        L.append("};")
+        L.append(f"static const uint32_t {nm}_consts[{len(env.const_values)}][{N}] = {{  // Montgomery form (R' = 2^{B28 * N}), 28-bit limbs")
+        for v in env.const_values:
+            L.append("  {" + ", ".join(f"0x{x:07x}u" for x in limbs28(v * Rp % env.p, N)) + "},")
+        L.append("};")
+        L.append("")
+    L.append("} }  // namespace pcd::vmgen")
+    return "\n".join(L) + "\n"
+
+
+def main():
+    envs = [compile_env(build(c)) for c in range(4)]
+    for env in envs:
+        # the kernels address these families as base + j
+        for fam, step in (("qx", 2), ("qy", 2), ("g", 1), ("v", 1)):
+            assert all(env.regs[f"{fam}{step * j}"] == env.regs[f"{fam}0"] + j for j in range(env.k // step)), fam
+        for fam in ("f", "acc"):
+            assert all(env.slots[f"{fam}{j}"] == env.slots[f"{fam}0"] + j for j in range(env.k)), fam
+        tot = {n: (len(c["steps"]), sum(len(i) for _, i in c["steps"])) for n, c in env.compiled.items()}
+        print(env.name, "slots", len(env.slots), "consts", len(env.const_values), "named", len(env.regs), "temps", env.ntemp, tot)
+    path = os.path.join(ROOT, "pcd_amd", "csrc", "pairing_vm_gen.h")
+    with open(path, "w") as fh:
+        fh.write(emit(envs))
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
