@@ -1,3 +1,4 @@
+#include <cmath>
 // TEST INFRASTRUCTURE ONLY -- flat C entry points (ctypes) over the CPU oracle in oracle/*.hpp.
 // Used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product.
 // PARITY UNPINNED (see field.hpp / DESIGN.md).
@@ -325,6 +326,78 @@ int orc_synthetic_r1cs(int field, size_t nc, size_t num_inputs, u64 seed, u64* r
   return 0;
 }
 size_t orc_synthetic_r1cs_num_vars(size_t nc, size_t num_inputs) { return num_inputs + 4 + nc; }
+
+// A constraint system shaped like what `cs.finalize()` leaves of a verifier circuit (the MainCircuit / HelpCircuit of
+// /root/reference src/ec_cycle_pcd/data_structures.rs:109-311 after linear-combination inlining): row lengths follow a power law
+// (most rows have 1-3 entries, a few have thousands: packing constraints, inlined sums), >= 80 % of the coefficients are +-1, ~12 %
+// small integers (2, 3, 4, 8, 16, 32 and their negatives), the rest random field elements; A rows long, B rows mostly a single
+// entry, C rows the new variable plus now and then a few +-1 terms.  Satisfied by construction (z[new] = <A,z><B,z> - rest of C).
+// Two rows with > 4096 entries and one B row with 300 are forced in when there is room.  Output arrays are caller-allocated with
+// capacity `cap` entries per matrix; returns the three entry counts in nnz_out (or -2 when the capacity does not suffice).
+int orc_skewed_r1cs(int field, size_t nc, size_t num_inputs, u64 seed, size_t cap, u64* rp_a, uint32_t* col_a, u64* coeff_a, u64* rp_b,
+                    uint32_t* col_b, u64* coeff_b, u64* rp_c, uint32_t* col_c, u64* coeff_c, u64* z_out, u64* nnz_out) {
+  DISPATCH_FIELD(field, {
+    SplitMix g(seed);
+    F* z = reinterpret_cast<F*>(z_out);
+    F* cf[3] = {reinterpret_cast<F*>(coeff_a), reinterpret_cast<F*>(coeff_b), reinterpret_cast<F*>(coeff_c)};
+    uint32_t* cl[3] = {col_a, col_b, col_c};
+    u64* rp[3] = {rp_a, rp_b, rp_c};
+    size_t cnt[3] = {0, 0, 0};
+    size_t m = 0;
+    z[m++] = F::one();
+    u64 tmp[F::N];
+    for (size_t i = 1; i < num_inputs + 4; i++) { rand_canonical<F>(g, tmp); z[m++] = F::from_raw(tmp); }
+    auto small = [&](int c) { F v = F::zero(); F one = F::one(); for (int i = 0; i < (c < 0 ? -c : c); i++) v = v + one; return c < 0 ? F::zero() - v : v; };
+    F smalls[65];
+    for (int c = -32; c <= 32; c++) smalls[c + 32] = small(c);
+    auto coeff = [&]() -> F {
+      const u64 t = g.next() % 100;
+      if (t < 80) return smalls[(g.next() & 1) ? 33 : 31];
+      if (t < 92) { static const int sm[6] = {2, 3, 4, 8, 16, 32}; const int c = sm[g.next() % 6]; return smalls[32 + ((g.next() & 1) ? c : -c)]; }
+      rand_canonical<F>(g, tmp);
+      return F::from_raw(tmp);
+    };
+    auto power_law = [&](size_t lmax) -> size_t {   // P(L >= x) = x^-1.5
+      const double u = ((double)(g.next() >> 11) + 1.0) / 9007199254740993.0;
+      const double l = std::pow(u, -1.0 / 1.5);
+      return l >= (double)lmax ? lmax : (size_t)l;
+    };
+    for (size_t j = 0; j < nc; j++) {
+      size_t la = power_law(std::min<size_t>(m, 4096)), lb = (g.next() % 10 < 7) ? 1 : power_law(std::min<size_t>(m, 64));
+      if (nc >= 8192 && (j == nc / 3 || j == 2 * (nc / 3))) la = std::min<size_t>(m, 4096 + 17 + (j & 63));
+      if (nc >= 8192 && j == nc / 2) lb = 300;
+      const size_t lens[2] = {la, lb};
+      F val[2];
+      for (int w = 0; w < 2; w++) {
+        rp[w][j] = cnt[w];
+        if (cnt[w] + lens[w] > cap) return -2;
+        F acc = F::zero();
+        for (size_t t = 0; t < lens[w]; t++) {
+          const F c = coeff();
+          const uint32_t col = (uint32_t)(g.next() % m);
+          cf[w][cnt[w]] = c; cl[w][cnt[w]] = col; cnt[w]++;
+          acc = acc + c * z[col];
+        }
+        val[w] = acc;
+      }
+      rp[2][j] = cnt[2];
+      const size_t extra = (g.next() % 10 < 2) ? 1 + g.next() % 3 : 0;
+      if (cnt[2] + 1 + extra > cap) return -2;
+      F rest = F::zero();
+      for (size_t t = 0; t < extra; t++) {
+        const F c = smalls[(g.next() & 1) ? 33 : 31];
+        const uint32_t col = (uint32_t)(g.next() % m);
+        cf[2][cnt[2]] = c; cl[2][cnt[2]] = col; cnt[2]++;
+        rest = rest + c * z[col];
+      }
+      z[m] = val[0] * val[1] - rest;
+      cf[2][cnt[2]] = F::one(); cl[2][cnt[2]] = (uint32_t)m; cnt[2]++;
+      m++;
+    }
+    for (int w = 0; w < 3; w++) { rp[w][nc] = cnt[w]; nnz_out[w] = cnt[w]; }
+  });
+  return 0;
+}
 
 int orc_witness_map(int field, size_t nc, size_t num_inputs, const u64* rp_a, const uint32_t* col_a, const u64* coeff_a,
                     const u64* rp_b, const uint32_t* col_b, const u64* coeff_b, const u64* rp_c,

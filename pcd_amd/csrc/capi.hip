@@ -834,13 +834,17 @@ int pcdhip_fft_last_timings(pcdhip_ctx* ctx, float out_ms[8]) {
 // ------------------------------------------------------------------------------------------------ witness map
 namespace {
 
-// device layout of one CSR matrix inside `d`: row_ptr | coeff (device image) | col;  `stage` holds the ABI coefficients
-size_t csr_bytes(const pcdhip_csr* m, const FieldEntry& fe, size_t off[3]) {
+// device layout of one CSR matrix inside `d`: row_ptr | coeff (device image) | col | nl | long_rows | lc  (DevCsr, common.h)
+size_t csr_bytes(const pcdhip_csr* m, const FieldEntry& fe, size_t off[6]) {
   const uint64_t nnz = m->row_ptr[m->num_rows];
+  auto up8 = [](size_t x) { return (x + 7) / 8 * 8; };
   off[0] = 0;
   off[1] = (m->num_rows + 1) * 8;
-  off[2] = off[1] + nnz * fe.words * 4;
-  return off[2] + (nnz * 4 + 7) / 8 * 8;
+  off[2] = off[1] + up8(nnz * fe.words * 4);
+  off[3] = off[2] + up8(nnz * 4);
+  off[4] = off[3] + up8((m->num_rows + 1) * 4);
+  off[5] = off[4] + up8((m->num_rows + 1) * 4);   // (at most every row is long)
+  return off[5] + up8(nnz + 8);
 }
 // host-side shape check of a caller's CSR matrix: row_ptr starts at 0 and never decreases, every column index is below
 // `num_cols` (the kernels index the assignment with it) -- PCDHIP_E_ARG instead of an out-of-bounds device read
@@ -854,29 +858,74 @@ int validate_csr(const pcdhip_csr* m, size_t num_cols) {
   for (uint64_t k = 0; k < nnz; k++) worst = std::max(worst, m->col[k]);
   return (nnz && worst >= num_cols) ? PCDHIP_E_ARG : PCDHIP_OK;
 }
-int upload_csr_to(pcdhip_ctx* ctx, const pcdhip_csr* m, const FieldEntry& fe, size_t num_cols, char* d, DevCsr* out) {
+// The small integers among the coefficients, recognised on the host by their C-ABI image (65 candidates, -32 .. 32, keyed by their
+// first limb).  Real constraint systems are mostly such coefficients; the mat-vec kernels add instead of multiplying for them.
+struct SmallCoeffTable {
+  size_t limbs;
+  std::vector<uint64_t> img;              // 65 x limbs
+  std::vector<std::pair<uint64_t, int>> key;  // (first limb, c) sorted
+  SmallCoeffTable(const FieldEntry& fe) : limbs((size_t)fe.abi_words / 2), img(65 * limbs) {
+    for (int c = -32; c <= 32; c++) {
+      fe.small_abi(c, (uint32_t*)&img[(size_t)(c + 32) * limbs]);
+      key.push_back({img[(size_t)(c + 32) * limbs], c});
+    }
+    std::sort(key.begin(), key.end());
+  }
+  // the small integer equal to the coefficient at `w`, or 127
+  int classify(const uint64_t* w) const {
+    auto it = std::lower_bound(key.begin(), key.end(), std::make_pair(w[0], -64));
+    for (; it != key.end() && it->first == w[0]; ++it)
+      if (memcmp(w, &img[(size_t)(it->second + 32) * limbs], limbs * 8) == 0) return it->second;
+    return 127;
+  }
+};
+int upload_csr_to(pcdhip_ctx* ctx, const pcdhip_csr* m, const FieldEntry& fe, size_t num_cols, char* d, DevCsr* out) try {
   int vrc = validate_csr(m, num_cols);
   if (vrc) return vrc;
-  const uint64_t nnz = m->row_ptr[m->num_rows];
-  size_t off[3];
+  const uint64_t nnz = m->row_ptr[m->num_rows], rows = m->num_rows;
+  size_t off[6];
   csr_bytes(m, fe, off);
-  TRY(hipMemcpyAsync(d + off[0], m->row_ptr, (m->num_rows + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  // classify, and reorder every row: light entries (small integer coefficients) first
+  const size_t limbs = (size_t)fe.abi_words / 2;
+  const SmallCoeffTable table(fe);
+  std::vector<uint32_t> col(nnz), nl(rows + 1, 0), long_rows;
+  std::vector<int8_t> lc(nnz + 8, 0);
+  std::vector<uint64_t> heavy(nnz * limbs, 0);   // ABI coefficients in the new order (light slots stay zero)
+  for (uint64_t r = 0; r < rows; r++) {
+    const uint64_t lo = m->row_ptr[r], hi = m->row_ptr[r + 1];
+    uint64_t front = lo, back = hi;
+    for (uint64_t k = lo; k < hi; k++) {
+      const int c = table.classify(m->coeff + k * limbs);
+      if (c != 127) { col[front] = m->col[k]; lc[front] = (int8_t)c; front++; }
+      else { back--; col[back] = m->col[k]; lc[back] = 127; memcpy(&heavy[back * limbs], m->coeff + k * limbs, limbs * 8); }
+    }
+    nl[r] = (uint32_t)(front - lo);
+    if (hi - lo > SPMV_LONG_ROW) long_rows.push_back((uint32_t)r);
+  }
+  TRY(hipMemcpyAsync(d + off[0], m->row_ptr, (rows + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  TRY(hipMemcpyAsync(d + off[3], nl.data(), (rows + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (!long_rows.empty()) TRY(hipMemcpyAsync(d + off[4], long_rows.data(), long_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   if (nnz) {
     TRY(ctx->aux_ws.ensure(AUX_SCAL, nnz * fe.abi_words * 4));
-    TRY(hipMemcpyAsync(ctx->aux_ws.buf[AUX_SCAL], m->coeff, nnz * fe.abi_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    TRY(hipMemcpyAsync(ctx->aux_ws.buf[AUX_SCAL], heavy.data(), nnz * fe.abi_words * 4, hipMemcpyHostToDevice, ctx->stream));
     TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_SCAL], (uint32_t*)(d + off[1]), (uint32_t)nnz, 0));
-    TRY(hipMemcpyAsync(d + off[2], m->col, nnz * 4, hipMemcpyHostToDevice, ctx->stream));
-    TRY(hipStreamSynchronize(ctx->stream));  // the staging slot is reused by the next matrix
+    TRY(hipMemcpyAsync(d + off[2], col.data(), nnz * 4, hipMemcpyHostToDevice, ctx->stream));
+    TRY(hipMemcpyAsync(d + off[5], lc.data(), nnz, hipMemcpyHostToDevice, ctx->stream));
   }
+  TRY(hipStreamSynchronize(ctx->stream));  // the host vectors above and the staging slot (reused by the next matrix) are done with
   out->rp = (const uint64_t*)(d + off[0]);
   out->coeff = (const uint32_t*)(d + off[1]);
   out->col = (const uint32_t*)(d + off[2]);
+  out->nl = (const uint32_t*)(d + off[3]);
+  out->long_rows = (const uint32_t*)(d + off[4]);
+  out->lc = (const int8_t*)(d + off[5]);
+  out->n_long = (uint32_t)long_rows.size();
   out->rows = (uint32_t)m->num_rows;
   return PCDHIP_OK;
-}
+} catch (const std::bad_alloc&) { return PCDHIP_E_OOM; }
 int upload_csr(pcdhip_ctx* ctx, int slot, const pcdhip_csr* m, const FieldEntry& fe, size_t num_cols, DevCsr* out) {
   if (!m || !m->row_ptr) return PCDHIP_E_ARG;
-  size_t off[3];
+  size_t off[6];
   TRY(ctx->aux_ws.ensure(slot, csr_bytes(m, fe, off) + 64));
   return upload_csr_to(ctx, m, fe, num_cols, (char*)ctx->aux_ws.buf[slot], out);
 }
@@ -900,7 +949,7 @@ int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const u
   hipStream_t st = ctx->stream;
   uint32_t* vecs[3] = {a, b, c};
   for (int k = 0; k < 3; k++)
-    TRY(fe.spmv(st, mats[k].rp, mats[k].col, mats[k].coeff, mats[k].rows, z_dev, (uint32_t)num_inputs, k == 0 ? 1 : 0, n, vecs[k]));
+    TRY(fe.spmv(st, mats[k], z_dev, (uint32_t)num_inputs, k == 0 ? 1 : 0, n, vecs[k]));
   if (after_spmv) TRY(hipEventRecord(after_spmv, st));
   // 3 x (ifft, coset_fft), pointwise, coset_ifft
   for (uint32_t* v : vecs) {
@@ -970,7 +1019,7 @@ int pcdhip_g16_witness_map_resident(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, co
   TRY(hipMemcpyAsync(ctx->aux_ws.buf[AUX_Z_CANON], z, m * fe.abi_words * 4, hipMemcpyHostToDevice, ctx->stream));
   TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_Z_CANON], (uint32_t*)ctx->aux_ws.buf[AUX_Z], (uint32_t)m, 0));
   DevCsr mats[3];
-  for (int k = 0; k < 3; k++) mats[k] = {pk->rp[k], pk->col[k], pk->coeff[k], pk->rows};
+  for (int k = 0; k < 3; k++) mats[k] = pk->mats[k];
   EventSet<3> ev;
   TRY(ev.create());
   TRY(hipEventRecord(ev[0], ctx->stream));
@@ -1084,7 +1133,7 @@ int pcdhip_g16_pk_set_r1cs(pcdhip_ctx* ctx, pcdhip_g16_pk* pk, const pcdhip_csr*
   const FieldEntry& fe = field_entry(kCurveFr[pk->curve_id]);
   const pcdhip_csr* ms[3] = {A, B, C};
   for (int k = 0; k < 3; k++) { int rc = validate_csr(ms[k], pk->num_vars); if (rc) return rc; }
-  size_t total = 0, base[3], off[3];
+  size_t total = 0, base[3], off[6];
   for (int k = 0; k < 3; k++) { base[k] = total; total += csr_bytes(ms[k], fe, off) + 64; }
   if (pk->r1cs_dev) { (void)hipFree(pk->r1cs_dev); pk->r1cs_dev = nullptr; }
   TRY(hipMalloc(&pk->r1cs_dev, total + 64));
@@ -1092,7 +1141,7 @@ int pcdhip_g16_pk_set_r1cs(pcdhip_ctx* ctx, pcdhip_g16_pk* pk, const pcdhip_csr*
     DevCsr dc;
     int rc = upload_csr_to(ctx, ms[k], fe, pk->num_vars, (char*)pk->r1cs_dev + base[k], &dc);
     if (rc) return rc;
-    pk->rp[k] = dc.rp; pk->coeff[k] = dc.coeff; pk->col[k] = dc.col;
+    pk->mats[k] = dc;
   }
   pk->rows = (uint32_t)A->num_rows;
   TRY(hipStreamSynchronize(ctx->stream));
@@ -1290,7 +1339,7 @@ int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_cs
   BIND();
   DevCsr mats[3];
   if (A && B && C) { TRY(hipStreamSynchronize(ctx->stream)); rc = upload_three(ctx, A, B, C, fe, m, mats); if (rc) return rc; }
-  else for (int k = 0; k < 3; k++) mats[k] = {pk0->rp[k], pk0->col[k], pk0->coeff[k], pk0->rows};
+  else for (int k = 0; k < 3; k++) mats[k] = pk0->mats[k];
   Dom dom_used;
   rc = witness_map_dev(ctx, fr, mats, runs[0].z_dev, ni, &dom_used);
   if (rc) return rc;
@@ -1391,7 +1440,7 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   // ---- K1: h, on the context's stream, while the MSMs above run
   DevCsr mats[3];
   if (A && B && C) { TRY(hipStreamSynchronize(st)); rc = upload_three(ctx, A, B, C, fe, m, mats); if (rc) return rc; }  // (staging slot AUX_SCAL is reused)
-  else for (int k = 0; k < 3; k++) mats[k] = {pk->rp[k], pk->col[k], pk->coeff[k], pk->rows};
+  else for (int k = 0; k < 3; k++) mats[k] = pk->mats[k];
   Dom dom_used;
   rc = witness_map_dev(ctx, fr, mats, run.z_dev, ni, &dom_used);
   if (rc) return rc;
@@ -1557,7 +1606,7 @@ int pcdhip_groth16_setup(pcdhip_ctx* ctx, int curve_id, const pcdhip_csr* A, con
     DevCsr dm;
     rc = upload_csr(ctx, AUX_CSR_RP, &tr.view, fe, nc, &dm);
     if (rc) return rc;
-    TRY(fe.spmv(st, dm.rp, dm.col, dm.coeff, dm.rows, u, 0, 0, (uint32_t)m, vecs[k]));
+    TRY(fe.spmv(st, dm, u, 0, 0, (uint32_t)m, vecs[k]));
     TRY(hipStreamSynchronize(st));  // `tr` and the staging slot are reused by the next matrix
   }
   uint32_t err = 0;
@@ -1667,8 +1716,13 @@ struct pcdhip_pvk {
   size_t num_inputs = 0;
   std::vector<uint64_t> alpha, beta, neg_gamma, neg_delta, gamma_abc, alpha_beta /* e(alpha, beta) */, gt_one;
   std::vector<uint8_t> gamma_abc_inf;
-  pcdhip_bases* abc = nullptr;  // gamma_abc_g1 resident (no precomputed copies: the MSMs over it are tiny)
+  pcdhip_bases* abc = nullptr;  // gamma_abc_g1 resident (no precomputed copies; used when there are too many inputs for window tables)
+  // prepared inputs (fixed_base.hip.h): gamma_abc_g1 in the C-ABI image with flagged points zeroed, then one window table per
+  // gamma_abc_g1[j], j >= 1 -- one device block; null when the key has more than PVK_TABLE_INPUTS inputs
+  uint32_t* abc_dev = nullptr;
+  size_t abc_tables_off = 0;  // u32 words from abc_dev to the tables
 };
+constexpr size_t PVK_TABLE_INPUTS = 256;
 
 namespace {
 // y -> -y of n affine points in the C-ABI image, on the host (the library's own host-callable field templates)
@@ -1717,6 +1771,22 @@ int prepare_inputs(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_t k, const uint6
   std::vector<uint64_t> acc_j(k * (l1 / 2 * 3)), scal(ni * sl);
   acc_a->assign(k * l1, 0);
   acc_inf->assign(k, 0);
+  if (pvk->abc_dev) {  // window tables: every proof's accumulation in one launch, no doubling chains
+    const GroupEntry& ge = group_entry(cid, 1);
+    const size_t jw = (size_t)ge.point_words / 2 * 3, sb = (ni - 1) * sl * 8;
+    TRY(ctx->aux_ws.ensure(AUX_FB_JAC, k * (64 * jw * 4 + sb + l1 * 8 + 1) + 64));
+    char* d = (char*)ctx->aux_ws.buf[AUX_FB_JAC];
+    uint32_t* scratch = (uint32_t*)d;
+    uint32_t* scal_d = (uint32_t*)(d + k * 64 * jw * 4);
+    uint32_t* out_d = (uint32_t*)((char*)scal_d + k * sb);
+    uint8_t* inf_d = (uint8_t*)out_d + k * l1 * 8;
+    if (sb) TRY(hipMemcpyAsync(scal_d, public_inputs, k * sb, hipMemcpyHostToDevice, ctx->stream));
+    TRY(ge.fb_inputs(ctx->stream, pvk->abc_dev + pvk->abc_tables_off, pvk->abc_dev, (uint32_t)ni, scal_d, (uint32_t)k, scratch, out_d, inf_d));
+    TRY(hipMemcpyAsync(acc_a->data(), out_d, k * l1 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(hipMemcpyAsync(acc_inf->data(), inf_d, k, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(hipStreamSynchronize(ctx->stream));
+    return PCDHIP_OK;
+  }
   for (size_t i = 0; i < k; i++) {
     std::fill(scal.begin(), scal.end(), 0);
     scal[0] = 1;
@@ -1755,6 +1825,20 @@ int pcdhip_process_vk(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, c
   ctx->precompute = 0;
   int rc = bases_upload_single(ctx, curve_id, 1, gamma_abc_g1, gamma_abc_inf, num_inputs, &pvk->abc);  // (device 0 of a multi-device context)
   ctx->precompute = saved;
+  if (!rc && num_inputs <= PVK_TABLE_INPUTS) {
+    const GroupEntry& ge = group_entry(curve_id, 1);
+    const size_t abi_w = (size_t)ge.point_abi_words;
+    const size_t tab_w = ge.fb_table_words;   // one table + the Jacobians of its doubling chain
+    const size_t head = (num_inputs * abi_w + num_inputs / 4 + 64 + 3) / 4 * 4;   // points, then the flag bytes, 16-byte aligned
+    hipError_t e = hipMalloc((void**)&pvk->abc_dev, (head + std::max<size_t>(num_inputs - 1, 1) * tab_w) * 4);
+    if (e != hipSuccess) { pcdhip_pvk_free(ctx, pvk); return fail(ctx, e); }
+    pvk->abc_tables_off = head;
+    e = hipMemcpyAsync(pvk->abc_dev, gamma_abc_g1, num_inputs * abi_w * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = zero_flagged(ctx->stream, pvk->abc_dev, (uint8_t*)(pvk->abc_dev + num_inputs * abi_w), gamma_abc_inf, num_inputs, abi_w * 4);
+    if (e == hipSuccess) e = ge.fb_tables(ctx->stream, pvk->abc_dev, (uint32_t)num_inputs, pvk->abc_dev + head);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { pcdhip_pvk_free(ctx, pvk); return fail(ctx, e); }
+  }
   rc = rc ? rc : pcdhip_multi_pairing(ctx, curve_id, alpha_g1, nullptr, beta_g2, nullptr, 1, pvk->alpha_beta.data());  // e(alpha, beta), once
   rc = rc ? rc : pcdhip_multi_pairing(ctx, curve_id, nullptr, nullptr, nullptr, nullptr, 0, pvk->gt_one.data());
   if (rc) { pcdhip_pvk_free(ctx, pvk); return rc; }
@@ -1765,6 +1849,7 @@ int pcdhip_process_vk(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, c
 void pcdhip_pvk_free(pcdhip_ctx* ctx, pcdhip_pvk* pvk) {
   if (!pvk) return;
   pcdhip_bases_free(ctx, pvk->abc);
+  if (pvk->abc_dev) { if (ctx) (void)hipSetDevice(ctx->device); (void)hipFree(pvk->abc_dev); }
   delete pvk;
 }
 

@@ -40,14 +40,21 @@ struct pcdhip_bases {
   std::vector<size_t> shard_lo;
 };
 namespace pcd {
-struct DevCsr { const uint64_t* rp; const uint32_t* col; const uint32_t* coeff; uint32_t rows; };
+// One constraint matrix on the device (built by upload_csr_to, capi.hip).  Inside every row the entries whose coefficient is a SMALL
+// integer (|c| <= 32: the +-1 of linear combinations and booleanity constraints, the 2, 3, 4 of range checks -- most of what
+// `cs.finalize()` leaves in a verifier circuit) come first: `nl[r]` of them, coefficient in `lc` (int8); the others follow with
+// their coefficients as field elements (device image) in `coeff` (indexed like col; the slots of light entries are unused).  Rows with
+// more than SPMV_LONG_ROW entries are listed in `long_rows`: they get a wave each instead of a lane.
+constexpr uint32_t SPMV_LONG_ROW = 16;
+struct DevCsr {
+  const uint64_t* rp; const uint32_t* col; const uint32_t* coeff; uint32_t rows;
+  const uint32_t* nl = nullptr; const int8_t* lc = nullptr; const uint32_t* long_rows = nullptr; uint32_t n_long = 0;
+};
 }
 struct pcdhip_g16_pk {
   // constraint matrices kept resident by pcdhip_g16_pk_set_r1cs (fixed per circuit, like the key)
   void* r1cs_dev = nullptr;
-  const uint64_t* rp[3] = {nullptr, nullptr, nullptr};
-  const uint32_t* col[3] = {nullptr, nullptr, nullptr};
-  const uint32_t* coeff[3] = {nullptr, nullptr, nullptr};
+  pcd::DevCsr mats[3];
   uint32_t rows = 0;
   int curve_id = 0;
   uint64_t num_vars = 0, num_inputs = 0, domain_size = 0;
@@ -133,6 +140,11 @@ struct GroupEntry {
   size_t fb_table_words;
   hipError_t (*fixed_base)(hipStream_t, const uint32_t* base_abi, const uint32_t* scalars, uint32_t n, uint32_t* table_scratch,
                            uint32_t* jac_scratch, uint32_t* out_abi, uint8_t* out_inf);
+  // prepared public inputs (fixed_base.hip.h): window tables of the bases 1 .. ni - 1 (fb_table_words each, consecutive), then
+  // acc_i = base_0 + sum_j x_ij base_j for k proofs in one launch (scratch: k x 64 Jacobians), C-ABI affine out
+  hipError_t (*fb_tables)(hipStream_t, const uint32_t* bases_abi, uint32_t ni, uint32_t* tables);
+  hipError_t (*fb_inputs)(hipStream_t, const uint32_t* tables, const uint32_t* base0_abi, uint32_t ni, const uint32_t* scalars, uint32_t k,
+                          uint32_t* scratch, uint32_t* out_abi, uint8_t* out_inf);
 };
 const GroupEntry& group_entry(int curve_id, int group_id);  // group_id 1 / 2
 
@@ -150,8 +162,9 @@ struct FieldEntry {
   // 3: ABI Montgomery -> canonical words
   hipError_t (*convert)(hipStream_t, const uint32_t* in, uint32_t* out, uint32_t n, int mode);
   // a[i] = <A_i, z> for the rows, a[nc + j] = z[j] for inputs when `append_inputs`, zero padding to n
-  hipError_t (*spmv)(hipStream_t, const uint64_t* row_ptr, const uint32_t* col, const uint32_t* coeff, uint32_t rows,
-                     const uint32_t* z, uint32_t num_inputs, int append_inputs, uint32_t n, uint32_t* out);
+  hipError_t (*spmv)(hipStream_t, const DevCsr& m, const uint32_t* z, uint32_t num_inputs, int append_inputs, uint32_t n, uint32_t* out);
+  // the C-ABI image of the small integer c (|c| <= 32) as a field element: what upload_csr_to looks for among the coefficients (host)
+  void (*small_abi)(int c, uint32_t* out_abi_words);
   // a = (a * b - c) / Z(g) on the coset of size 2^log_n
   hipError_t (*mul_sub_divz)(hipStream_t, const FftTables& t, uint32_t* a, const uint32_t* b, const uint32_t* c, int log_n);
   // mixed-radix domain n = m * 2^a (ark-poly MixedRadixEvaluationDomain): tables, transform, pointwise step

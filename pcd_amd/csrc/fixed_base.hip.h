@@ -99,6 +99,69 @@ __global__ void __launch_bounds__(64) fb_normalize_kernel(const uint32_t* __rest
   }
 }
 
+// ---- prepared public inputs of a verification: acc_i = abc_0 + sum_{j >= 1} x_ij abc_j with the abc_j FIXED (a verifying key:
+// `prepare_verifying_key` / the input accumulation of ark-groth16 `prepare_inputs`, under /root/reference src/ec_cycle_pcd/mod.rs:239).
+// As a variable-base MSM of a handful of points this was a chain of ~300 (750) dependent doublings in one lane -- 5.8 ms (37 ms) per
+// proof, more than the pairings of the verification once those run one wave each.  With a window table per abc_j (built once, at
+// process_vk) it is (ni - 1) nwin mixed additions spread over the 64 lanes of one workgroup per proof, a tree over the lanes and
+// one inversion: tables[j] = the fb_table_kernel table of abc_j, j = 1 .. ni - 1.
+template <class G>
+__global__ void __launch_bounds__(64) fb_inputs_kernel(const uint32_t* __restrict__ tables, size_t tab_words, const uint32_t* __restrict__ abc0_abi, uint32_t ni,
+                                                       const uint32_t* __restrict__ scalars /* k x (ni - 1) canonical */, int nwin, int w,
+                                                       uint32_t* __restrict__ scratch /* k x 64 Jacobians */, uint32_t* __restrict__ out_abi,
+                                                       uint8_t* __restrict__ out_inf) {
+  typedef typename G::F F;
+  constexpr int SW = G::FR::N32, JW = Jac<F>::WORDS;
+  const uint32_t proof = blockIdx.x, lane = threadIdx.x;
+  Jac<F> acc = Jac<F>::infinity();
+  if (lane == 0) { const Aff<F> a0 = Aff<F>::from_abi(abc0_abi); if (!a0.is_inf()) acc = {a0.x, a0.y, F::one()}; }
+  const uint32_t items = (ni - 1) * (uint32_t)nwin;
+  for (uint32_t it = lane; it < items; it += 64) {
+    const uint32_t j = it / (uint32_t)nwin, win = it % (uint32_t)nwin;
+    const uint32_t* k = scalars + ((size_t)proof * (ni - 1) + j) * SW;
+    const int bit = (int)win * w, word = bit >> 5, sh = bit & 31;
+    uint32_t d = k[word] >> sh;
+    if (sh + w > 32 && word + 1 < SW) d |= k[word + 1] << (32 - sh);
+    d &= (1u << w) - 1;
+    if (d) acc = EC<G>::madd(acc, Aff<F>::load(tables + (size_t)j * tab_words + (((size_t)win << w) + d) * Aff<F>::WORDS));
+  }
+  uint32_t* my = scratch + (size_t)proof * 64 * JW;
+  acc.store(my + (size_t)lane * JW);
+  __syncthreads();
+  for (uint32_t s = 32; s > 0; s >>= 1) {
+    if (lane < s) {
+      acc = EC<G>::add(acc, Jac<F>::load(my + (size_t)(lane + s) * JW));
+      acc.store(my + (size_t)lane * JW);
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    const Aff<F> a = EC<G>::to_affine(acc);
+    a.to_abi(out_abi + (size_t)proof * Aff<F>::ABI_WORDS);
+    out_inf[proof] = acc.is_inf() ? 1 : 0;
+  }
+}
+// tables of the bases 1 .. ni - 1 (C-ABI affine image, consecutive), `tab_words` apart: each slot = the table, then the nwin Jacobians
+// of its doubling chain
+template <class G>
+hipError_t fb_tables_build(hipStream_t st, const uint32_t* bases_abi, uint32_t ni, size_t tab_words, uint32_t* tables) {
+  constexpr int w = FB_WINDOW, nwin = (G::FR::BITS + w - 1) / w;
+  const size_t pure = ((size_t)nwin << w) * Aff<typename G::F>::WORDS;
+  for (uint32_t j = 1; j < ni; j++) {
+    uint32_t* slot = tables + (size_t)(j - 1) * tab_words;
+    hipLaunchKernelGGL((fb_powers_kernel<G>), dim3(1), dim3(64), 0, st, bases_abi + (size_t)j * Aff<typename G::F>::ABI_WORDS, slot + pure, nwin, w);
+    hipLaunchKernelGGL((fb_table_kernel<G>), dim3(((nwin << w) + 63) / 64), dim3(64), 0, st, slot + pure, slot, nwin, w);
+  }
+  return hipGetLastError();
+}
+template <class G>
+hipError_t fb_inputs_run(hipStream_t st, const uint32_t* tables, size_t tab_words, const uint32_t* abc0_abi, uint32_t ni, const uint32_t* scalars,
+                         uint32_t k, uint32_t* scratch, uint32_t* out_abi, uint8_t* out_inf) {
+  constexpr int w = FB_WINDOW, nwin = (G::FR::BITS + w - 1) / w;
+  if (k) hipLaunchKernelGGL((fb_inputs_kernel<G>), dim3(k), dim3(64), 0, st, tables, tab_words, abc0_abi, ni, scalars, nwin, w, scratch, out_abi, out_inf);
+  return hipGetLastError();
+}
+
 // table: nwin << w affine points; bj: nwin Jacobians; jac_tmp: n Jacobians (all device image)
 template <class G>
 hipError_t fixed_base_run(hipStream_t st, const uint32_t* base_abi, const uint32_t* scalars, uint32_t n, uint32_t* bj, uint32_t* table,

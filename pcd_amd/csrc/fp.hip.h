@@ -527,6 +527,35 @@ struct Fp {
     r[N - 1] = (int32_t)cc;  // < 4p / 2^(28(N-1)): small
     return norm_reduce<false>(r);
   }
+  // The value of a signed limb-wise sum of small multiples of field elements: s[i] = sum_t c_t a_t[i] with every a_t in [0, 2p) and
+  // sum |c_t| <= 124; K = 2 sum |negative c_t| (K p is added so that the integer is non-negative and below 2^8 p).  One carry chain,
+  // a quotient estimate from the two top limbs (never above the true quotient, at most 2 short) and one conditional subtraction
+  // bring it to [0, 2p).  The LIN instruction of the pairing VM and the unit / small-coefficient terms of the mat-vec use it.
+  PCD_HD static Fp from_signed_sum(const int64_t* s, int64_t K) {
+    uint32_t t28[N];
+    int64_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+      cy += s[i] + K * (int64_t)P::mod(i);
+      t28[i] = (uint32_t)cy & MASK;
+      cy >>= 28;
+    }
+    cy += s[N - 1] + K * (int64_t)P::mod(N - 1);  // top limb, kept whole (>= 0)
+    const uint64_t top2 = ((uint64_t)cy << 28) | t28[N - 2];
+    const uint32_t est = (uint32_t)(top2 >> P::EST_SHIFT);
+    const uint32_t q = (uint32_t)(((uint64_t)est * P::EST_RECIP) >> 32);
+    int32_t r[N];
+    int64_t cc = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+      cc += (int64_t)t28[i] - (int64_t)((uint64_t)q * P::mod(i));
+      r[i] = (int32_t)((uint32_t)cc & MASK);
+      cc >>= 28;
+    }
+    cc += cy - (int64_t)((uint64_t)q * P::mod(N - 1));
+    r[N - 1] = (int32_t)cc;
+    return norm_reduce<false>(r);
+  }
   // a^(p-2) (inverse; zero maps to zero)
   PCD_HD Fp inv() const {
     Fp r = one();

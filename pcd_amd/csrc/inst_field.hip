@@ -226,25 +226,81 @@ hipError_t convert(hipStream_t st, const uint32_t* in, uint32_t* out, uint32_t n
   return hipGetLastError();
 }
 
-// out[i] = <M_i, z> (i < rows);  out[rows + j] = z[j] (j < num_inputs) if append_inputs;  0 up to n
-__global__ void __launch_bounds__(256) spmv_kernel(const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
-                                                   const uint32_t* __restrict__ coeff, uint32_t rows, const uint32_t* __restrict__ z,
-                                                   uint32_t num_inputs, int append_inputs, uint32_t n, uint32_t* __restrict__ out) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- the three mat-vecs of the witness map: out[i] = <M_i, z> (i < rows);  out[rows + j] = z[j] (j < num_inputs) if append_inputs;
+// 0 up to n.  Entries with small integer coefficients (DevCsr, common.h) cost additions, not products: a lane sums c * z[col] limb-wise
+// in 64 bits for up to SPMV_FLUSH entries (sum |c| <= 124) and reduces once (Fp::from_signed_sum); only the heavy entries take a
+// Montgomery product.  The two kinds are separate loops, so a wave whose rows hold no heavy entry never executes a product.
+constexpr int SPMV_FLUSH = 3;  // light entries per reduction: 3 x 32 <= 124
+struct SpmvLight {
+  int64_t s[FT::N];
+  int64_t K = 0;
+  int cnt = 0;
+  PCD_DEV SpmvLight() {
+#pragma unroll
+    for (int i = 0; i < FT::N; i++) s[i] = 0;
+  }
+  PCD_DEV void add(int c, const FT& v, FT& acc) {
+    if (c < 0) K -= 2 * c;
+#pragma unroll
+    for (int i = 0; i < FT::N; i++) s[i] += (int64_t)c * (int64_t)v.v[i];
+    if (++cnt == SPMV_FLUSH) flush(acc);
+  }
+  PCD_DEV void flush(FT& acc) {
+    if (!cnt) return;
+    acc = acc + FT::from_signed_sum(s, K);
+#pragma unroll
+    for (int i = 0; i < FT::N; i++) s[i] = 0;
+    K = 0; cnt = 0;
+  }
+};
+// one lane per row (rows of up to SPMV_LONG_ROW entries; longer ones are left to spmv_long_kernel), the tail of the vector too
+__global__ void __launch_bounds__(256) spmv_kernel(const DevCsr m, const uint32_t* __restrict__ z, uint32_t num_inputs, int append_inputs,
+                                                   uint32_t n, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   FT acc = FT::zero();
-  if (i < rows) {
-    for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; k++)
-      acc = acc + FT::load(coeff + k * EW) * FT::load(z + (size_t)col[k] * EW);
-  } else if (append_inputs && i < rows + num_inputs) {
-    acc = FT::load(z + (size_t)(i - rows) * EW);
+  if (i < m.rows) {
+    const uint64_t lo = m.rp[i], hi = m.rp[i + 1];
+    if (hi - lo > SPMV_LONG_ROW) return;
+    const uint64_t mid = lo + m.nl[i];
+    SpmvLight L;
+    for (uint64_t k = lo; k < mid; k++) L.add((int)m.lc[k], FT::load(z + (size_t)m.col[k] * EW), acc);
+    L.flush(acc);
+    for (uint64_t k = mid; k < hi; k++) acc = acc + FT::load(m.coeff + k * EW) * FT::load(z + (size_t)m.col[k] * EW);
+  } else if (append_inputs && i < m.rows + num_inputs) {
+    acc = FT::load(z + (size_t)(i - m.rows) * EW);
   }
   acc.store(out + (size_t)i * EW);
 }
-hipError_t spmv(hipStream_t st, const uint64_t* row_ptr, const uint32_t* col, const uint32_t* coeff, uint32_t rows,
-                const uint32_t* z, uint32_t num_inputs, int append_inputs, uint32_t n, uint32_t* out) {
-  hipLaunchKernelGGL(spmv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, row_ptr, col, coeff, rows, z, num_inputs, append_inputs, n, out);
+// one wave per long row: lanes stride over the entries, then a butterfly of field additions over the wave
+__global__ void __launch_bounds__(64) spmv_long_kernel(const DevCsr m, const uint32_t* __restrict__ z, uint32_t* __restrict__ out) {
+  const uint32_t w = blockIdx.x, lane = threadIdx.x;
+  if (w >= m.n_long) return;
+  const uint32_t i = m.long_rows[w];
+  const uint64_t lo = m.rp[i], hi = m.rp[i + 1], mid = lo + m.nl[i];
+  FT acc = FT::zero();
+  SpmvLight L;
+  for (uint64_t k = lo + lane; k < mid; k += 64) L.add((int)m.lc[k], FT::load(z + (size_t)m.col[k] * EW), acc);
+  L.flush(acc);
+  for (uint64_t k = mid + lane; k < hi; k += 64) acc = acc + FT::load(m.coeff + k * EW) * FT::load(z + (size_t)m.col[k] * EW);
+  for (int d = 32; d > 0; d >>= 1) {
+    FT o;
+#pragma unroll
+    for (int q = 0; q < FT::N; q++) o.v[q] = (uint32_t)__shfl_xor((int)acc.v[q], d, 64);
+    acc = acc + o;
+  }
+  if (lane == 0) acc.store(out + (size_t)i * EW);
+}
+hipError_t spmv(hipStream_t st, const DevCsr& m, const uint32_t* z, uint32_t num_inputs, int append_inputs, uint32_t n, uint32_t* out) {
+  hipLaunchKernelGGL(spmv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, m, z, num_inputs, append_inputs, n, out);
+  if (m.n_long) hipLaunchKernelGGL(spmv_long_kernel, dim3(m.n_long), dim3(64), 0, st, m, z, out);
   return hipGetLastError();
+}
+// host: the C-ABI image of a small integer (the field templates are __host__ __device__)
+void small_abi(int c, uint32_t* out) {
+  FT v = FT::from_u64((uint64_t)(c < 0 ? -c : c));
+  if (c < 0) v = v.neg();
+  v.to_abi(out);
 }
 
 hipError_t mul_sub_divz(hipStream_t st, const FftTables& t, uint32_t* a, const uint32_t* b, const uint32_t* c, int log_n) {
@@ -357,7 +413,7 @@ hipError_t setup_scalars(hipStream_t st, const void* domain_consts, const uint32
 #define PCD_CAT_(a, b) a##b
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const FieldEntry* PCD_CAT(pcd_field_entry_, PCD_FIELD_IDX)() {
-  static const FieldEntry e = {EW, FT::ABI_WORDS, FT::Params::TWO_ADICITY, make_tables, run, convert, spmv, mul_sub_divz,
+  static const FieldEntry e = {EW, FT::ABI_WORDS, FT::Params::TWO_ADICITY, make_tables, run, convert, spmv, small_abi, mul_sub_divz,
                                mixed_make_tables, mixed_run, mixed_mul_sub_divz, scale_canon, SETUP_CONSTS, setup_scalars};
   return &e;
 }

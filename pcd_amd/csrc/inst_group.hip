@@ -116,13 +116,22 @@ hipError_t fixed_base_entry(hipStream_t st, const uint32_t* base_abi, const uint
   return fixed_base_run<GT>(st, base_abi, scalars, n, bj, table_scratch, jac_scratch, out_abi, out_inf);
 }
 
+hipError_t fb_tables_entry(hipStream_t st, const uint32_t* bases_abi, uint32_t ni, uint32_t* tables) {
+  return fb_tables_build<GT>(st, bases_abi, ni, FB_TABLE_WORDS, tables);
+}
+hipError_t fb_inputs_entry(hipStream_t st, const uint32_t* tables, const uint32_t* abc0_abi, uint32_t ni, const uint32_t* scalars, uint32_t k,
+                           uint32_t* scratch, uint32_t* out_abi, uint8_t* out_inf) {
+  return fb_inputs_run<GT>(st, tables, FB_TABLE_WORDS, abc0_abi, ni, scalars, k, scratch, out_abi, out_inf);
+}
+
 }  // namespace
 
 #define PCD_CAT_(a, b) a##b
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const GroupEntry* PCD_CAT(pcd_group_entry_, PCD_GROUP_IDX)() {
   static const GroupEntry e = {Aff<F>::WORDS, MsmBaseStride<GT>::value, Aff<F>::ABI_WORDS, GT::FR::N32, GT::FR::BITS, msm_entry, precompute_entry,
-                               points_in_entry, jac_out_entry, points_sum_entry, jac_sum_parts_entry, to_affine_entry, FB_TABLE_WORDS, fixed_base_entry};
+                               points_in_entry, jac_out_entry, points_sum_entry, jac_sum_parts_entry, to_affine_entry, FB_TABLE_WORDS, fixed_base_entry,
+                               fb_tables_entry, fb_inputs_entry};
   return &e;
 }
 

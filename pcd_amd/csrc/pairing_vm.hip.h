@@ -98,8 +98,7 @@ struct VmArith {
   }
 
   // dst = sum c_t a_t mod p, |c_t| small (sum of |c_t| <= 124), operands and result in [0, 2p).  Negative terms are covered by adding
-  // K p, K = 2 sum |negative c_t| (every operand is below 2p), so the limb-wise signed sum is a non-negative integer V < 2^8 p; a
-  // quotient estimate from its two top limbs (never above V / p, at most 2 short) and one conditional subtraction finish.
+  // K p, K = 2 sum |negative c_t| (every operand is below 2p): Fp::from_signed_sum.
   template <class PTR>
   PCD_HD static F lin(const uint32_t* w, PTR regs, uint32_t bank) {
     const int T = (int)((w[0] >> 8) & 0xFFu);
@@ -118,29 +117,7 @@ struct VmArith {
         for (int i = 0; i < N; i++) s[i] += c * (int64_t)a.v[i];
       }
     }
-    uint32_t t28[N];
-    int64_t cy = 0;
-#pragma unroll
-    for (int i = 0; i < N - 1; i++) {
-      cy += s[i] + K * (int64_t)P::mod(i);
-      t28[i] = (uint32_t)cy & MASK;
-      cy >>= 28;
-    }
-    cy += s[N - 1] + K * (int64_t)P::mod(N - 1);  // top limb, kept whole (>= 0)
-    const uint64_t top2 = ((uint64_t)cy << 28) | t28[N - 2];
-    const uint32_t est = (uint32_t)(top2 >> P::EST_SHIFT);
-    const uint32_t q = (uint32_t)(((uint64_t)est * P::EST_RECIP) >> 32);
-    int32_t r[N];
-    int64_t cc = 0;
-#pragma unroll
-    for (int i = 0; i < N - 1; i++) {
-      cc += (int64_t)t28[i] - (int64_t)((uint64_t)q * P::mod(i));
-      r[i] = (int32_t)((uint32_t)cc & MASK);
-      cc >>= 28;
-    }
-    cc += cy - (int64_t)((uint64_t)q * P::mod(N - 1));
-    r[N - 1] = (int32_t)cc;
-    return F::template norm_reduce<false>(r);
+    return F::from_signed_sum(s, K);
   }
 };
 

@@ -110,3 +110,22 @@ def test_config3_kzg_commit_2p20(co, gpu_ctx):
             assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (off, length)
     finally:
         P.free(); G.free(); S.free(); B.free()
+
+
+def test_witness_map_skewed_2p20(co, gpu_ctx):
+    """2^20 rows of the skewed verifier-circuit shape (2.7 M entries in A, rows up to 4155 entries, 80 % unit coefficients) over the
+    MNT4-298 scalar field: the witness map against the oracle, matrices handed over with the call and resident with a key (the
+    latter with its stage times printed)"""
+    fr = co.CURVE_FR[0]
+    r = co.skewed_r1cs(fr, (1 << 20) - 8, 2, seed=2020)
+    want = co.witness_map(r, nthreads=THREADS)
+    assert np.array_equal(gpu_ctx.witness_map(fr, r), want)
+    pk = gpu_ctx.g16_pk_upload(co.synthetic_keys(0, r, seed=2022, mt=True).host_struct(), 0)
+    gpu_ctx.g16_pk_set_r1cs(pk, r)
+    try:
+        h, ms = gpu_ctx.witness_map_resident(pk, r)
+        h2, ms = gpu_ctx.witness_map_resident(pk, r)
+        print(f"skewed witness map 2^20 (MNT4-298 Fr): {ms}")
+        assert np.array_equal(h, want) and np.array_equal(h2, want)
+    finally:
+        pk.free()

@@ -103,6 +103,30 @@ def test_witness_map_vs_oracle(co, gpu_ctx, cid, nc):
     assert np.array_equal(gpu_ctx.witness_map(fr, r), co.witness_map(r, nthreads=16))
 
 
+@pytest.mark.parametrize("cid,nc", [(0, 20000), (1, 9000), (2, 9000), (3, 9000), (0, 50)])
+def test_witness_map_skewed_matrix(co, gpu_ctx, cid, nc):
+    """the shape `cs.finalize()` leaves of a verifier circuit (coracle.skewed_r1cs: power-law row lengths with rows above 4096
+    entries, >= 80 % unit coefficients, small integers, a few random ones): the mat-vec kernels take the small-integer entries through
+    additions, the others through products, rows above 16 entries with a wave each -- h equal to the oracle's, through the call that
+    hands the matrices over and through the resident-matrix path"""
+    fr = co.CURVE_FR[cid]
+    r = co.skewed_r1cs(fr, nc, 2, seed=300 + nc + cid)
+    want = co.witness_map(r, nthreads=16)
+    assert np.array_equal(gpu_ctx.witness_map(fr, r), want)
+    keys = co.synthetic_keys(cid, r, seed=301)
+    pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
+    gpu_ctx.g16_pk_set_r1cs(pk, r)
+    try:
+        h, ms = gpu_ctx.witness_map_resident(pk, r)
+        assert np.array_equal(h, want) and ms["total"] > 0
+        rs = co.gen_field(fr, 2, seed=302)
+        got, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
+        w, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=16)
+        assert np.array_equal(got, w) and np.array_equal(inf, winf)
+    finally:
+        pk.free()
+
+
 @pytest.mark.parametrize("cid", [0, 1])
 def test_groth16_golden_proof(co, golden, gpu_ctx, cid):
     """Keys and expected proof come from the pure-Python oracle (tests/golden/groth16.npz)."""

@@ -90,3 +90,23 @@ def test_fixed_base_msm_matches_double_and_add(co, cid, group):
             want, winf = co.to_affine(cid, group, co.scalar_mul(cid, group, base, sc[i])[None])
             assert inf[i] == winf[0] and np.array_equal(got[i], want[0])
         assert inf[0] == 1 and np.array_equal(got[1], base)
+
+
+def test_skewed_r1cs_generator(co):
+    """coracle.skewed_r1cs (what the mat-vec kernels are measured on): satisfied, power-law row lengths with the forced long rows,
+    >= 75 % unit coefficients, every column index in range"""
+    from oracle import pyoracle as po
+    r = co.skewed_r1cs(1, 9000, 2, seed=9)
+    f = po.FIELDS[1]
+    z = [f.from_mont(f.unlimbs(x)) for x in r.z]
+
+    def row(rp, col, cf, j):
+        return sum(f.from_mont(f.unlimbs(cf[k])) * z[col[k]] for k in range(int(rp[j]), int(rp[j + 1]))) % f.p
+    for j in list(range(40)) + [3000, 6000, 4500, 8999]:
+        assert row(r.rp_a, r.col_a, r.coeff_a, j) * row(r.rp_b, r.col_b, r.coeff_b, j) % f.p == row(r.rp_c, r.col_c, r.coeff_c, j)
+    la, lb = np.diff(r.rp_a.astype(np.int64)), np.diff(r.rp_b.astype(np.int64))
+    assert la.max() > 4096 and lb.max() == 300 and la.min() >= 1 and np.median(la) <= 2
+    one, mone = f.to_mont(1), f.to_mont(f.p - 1)
+    vals = [f.unlimbs(x) for x in r.coeff_a[:20000]]
+    assert sum(v in (one, mone) for v in vals) / len(vals) > 0.75
+    assert max(r.col_a.max(), r.col_b.max(), r.col_c.max()) < r.num_vars and r.num_vars == r.z.shape[0]
