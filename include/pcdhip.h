@@ -323,11 +323,16 @@ int pcdhip_groth16_verify_batch(pcdhip_ctx* ctx, int curve_id, const uint64_t* a
  * (no GPU, no context).  Field elements: canonical little-endian integers in ceil(bits / 8) bytes (38 / 95), Fq2 / Fq3 as c0, c1
  * (, c2); flags in the top bits of the last byte: 0x80 = y is the larger of (y, -y), 0x40 = infinity; compressed = x with flags,
  * uncompressed = x, y with flags.  Points at this ABI are x || y Montgomery limbs + a flag byte, as everywhere in this header.
- * Reading checks that coordinates are reduced and that the point lies on the curve (compressed: rebuilds y by a square root);
- * PCDHIP_E_ARG otherwise.  Sizes are 0 for invalid ids. */
+ * Reading checks that coordinates are reduced, that the point lies on the curve (compressed: rebuilds y by a square root) and --
+ * like upstream's checked `deserialize` -- that a G2 point lies in the prime-order subgroup ([r]Q = O; G1 has cofactor 1):
+ * PCDHIP_E_ARG otherwise.  The subgroup test is one scalar multiplication on the host per G2 point (~10 ms at 298 bits, ~0.1 s at
+ * 753 bits); pcdhip_deserialize_points_unchecked (= `deserialize_unchecked`: curve check only) is for bulk data a trusted party
+ * wrote, e.g. a proving key.  Proofs and verifying keys are always checked.  Sizes are 0 for invalid ids. */
 size_t pcdhip_serialized_size(int curve_id, int group_id, int compressed);  /* bytes of one point */
 int pcdhip_serialize_points(int curve_id, int group_id, const uint64_t* xy_mont, const uint8_t* inf, size_t n, int compressed, uint8_t* out);
 int pcdhip_deserialize_points(int curve_id, int group_id, const uint8_t* in, size_t n, int compressed, uint64_t* xy_mont, uint8_t* inf);
+int pcdhip_deserialize_points_unchecked(int curve_id, int group_id, const uint8_t* in, size_t n, int compressed, uint64_t* xy_mont,
+                                        uint8_t* inf);
 size_t pcdhip_proof_serialized_size(int curve_id, int compressed);
 int pcdhip_proof_serialize(int curve_id, const uint64_t* proof, const uint8_t* proof_inf, int compressed, uint8_t* out);
 int pcdhip_proof_deserialize(int curve_id, const uint8_t* in, int compressed, uint64_t* proof, uint8_t* proof_inf);

@@ -48,7 +48,7 @@ EXPORTS = [
     "pcdhip_set_precompute", "pcdhip_set_precompute_budget", "pcdhip_msm_set_sort", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
     "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_g16_witness_map_resident", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
-    "pcdhip_serialized_size", "pcdhip_serialize_points", "pcdhip_deserialize_points", "pcdhip_proof_serialized_size", "pcdhip_proof_serialize",
+    "pcdhip_serialized_size", "pcdhip_serialize_points", "pcdhip_deserialize_points", "pcdhip_deserialize_points_unchecked", "pcdhip_proof_serialized_size", "pcdhip_proof_serialize",
     "pcdhip_proof_deserialize", "pcdhip_vk_serialized_size", "pcdhip_vk_serialize", "pcdhip_vk_deserialize",
     "pcdhip_process_vk", "pcdhip_pvk_free", "pcdhip_groth16_verify_prepared", "pcdhip_groth16_verify_batch_rlc",
     "pcdhip_multi_pairing", "pcdhip_pairing_set_mode", "pcdhip_groth16_verify", "pcdhip_groth16_verify_batch", "pcdhip_timer_start", "pcdhip_timer_stop",
@@ -464,11 +464,13 @@ def serialize_points(curve, group, xy, inf=None, compressed=True):
     return out.tobytes()
 
 
-def deserialize_points(curve, group, data, n, compressed=True):
+def deserialize_points(curve, group, data, n, compressed=True, unchecked=False):
+    """CanonicalDeserialize of n affine points; unchecked=True skips the G2 subgroup test (`deserialize_unchecked`)."""
     buf = np.frombuffer(data, dtype=np.uint8).copy()
     xy = np.zeros((n, point_limbs(curve, group)), dtype=np.uint64)
     inf = np.zeros(n, dtype=np.uint8)
-    _wire_check(lib().pcdhip_deserialize_points(curve, group, _p(buf), C.c_size_t(n), int(compressed), _p(xy), _p(inf)))
+    fn = lib().pcdhip_deserialize_points_unchecked if unchecked else lib().pcdhip_deserialize_points
+    _wire_check(fn(curve, group, _p(buf), C.c_size_t(n), int(compressed), _p(xy), _p(inf)))
     return xy, inf
 
 

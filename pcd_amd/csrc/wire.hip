@@ -15,8 +15,12 @@
 //   Proof         A (G1) || B (G2) || C (G1)
 //   VerifyingKey  alpha_g1, beta_g2, gamma_g2, delta_g2, then gamma_abc_g1 as u64 LE length + points
 // Reading accepts what writing produces; a point read back is checked to lie on the curve (uncompressed) or rebuilt from x
-// (compressed: y = sqrt(x^3 + a x + b), the root selected by the sign flag).  The subgroup check of `deserialize` (as opposed to
-// `deserialize_unchecked`) is not made here: G1 has cofactor 1; for G2 the verifier's pairing check fails for a point outside it.
+// (compressed: y = sqrt(x^3 + a x + b), the root selected by the sign flag) and, as upstream's checked `deserialize` does
+// (`is_in_correct_subgroup_assuming_on_curve`), to lie in the prime-order subgroup: G1 has cofactor 1 on all four curves, so
+// there is nothing to test; a G2 point Q is accepted only if [r]Q = O (the twists have cofactors of ~300 / ~1500 bits, and
+// neither the Miller loop nor e(rho A, B) = e(A, B)^rho of the batched verification means anything for a point outside the
+// r-torsion).  One scalar multiplication on the host per G2 point (10 ms at 298 bits, ~0.1 s at 753 bits with these templates): a
+// proof has one, a key three.  pcdhip_deserialize_points_unchecked skips it (bulk reads of keys a trusted party wrote).
 #include <string.h>
 
 #include <vector>
@@ -272,15 +276,32 @@ template <class FQ, unsigned NR, int DEG> struct G2Field;
 template <class FQ, unsigned NR> struct G2Field<FQ, NR, 2> { typedef Fp2<Fp<FQ, false>, NR> type; };
 template <class FQ, unsigned NR> struct G2Field<FQ, NR, 3> { typedef Fp3<Fp<FQ, false>, NR> type; };
 
+// [r]Q == O for a point of the twist (affine, C-ABI image), r = the modulus of the scalar field FRP
+template <class G2C>
+bool g2_in_subgroup(const uint32_t* xy_abi) {
+  typedef typename G2C::F E;
+  typedef typename G2C::FR FRP;
+  uint32_t r[FRP::N32];
+  uint64_t carry = 2;  // r = (r - 2) + 2
+  for (int i = 0; i < FRP::N32; i++) { const uint64_t x = (uint64_t)FRP::modm2(i) + carry; r[i] = (uint32_t)x; carry = x >> 32; }
+  const Jac<E> q = {E::from_abi(xy_abi), E::from_abi(xy_abi + E::ABI_WORDS), E::one()};
+  return EC<G2C>::mul(q, r, FRP::N32).is_inf();
+}
+
 #define PCD_WIRE_CURVE(NAME, FQ, NRV, DEGV)                                                                          \
   struct Wire_##NAME {                                                                                               \
     typedef Fp<FQ, false> B;                                                                                         \
     typedef G2Field<FQ, NRV, DEGV>::type E2;                                                                         \
+    typedef G2_##NAME##_CHK G2C;                                                                                     \
     static B a1() { static const uint32_t w[] = PCD_##NAME##_A_MONT; return B::from_abi(w); }                        \
     static B b1() { static const uint32_t w[] = PCD_##NAME##_B_MONT; return B::from_abi(w); }                        \
     static E2 a2() { static const uint32_t w[] = PCD_##NAME##_TWIST_A_MONT; return E2::from_abi(w); }                \
     static E2 b2() { static const uint32_t w[] = PCD_##NAME##_TWIST_B_MONT; return E2::from_abi(w); }                \
   };
+typedef G2_MNT4_298_C G2_MNT4_298_CHK;   // (the compact, non-inlined field variants: the same memory image as Wire_*::E2)
+typedef G2_MNT6_298_C G2_MNT6_298_CHK;
+typedef G2_MNT4_753 G2_MNT4_753_CHK;
+typedef G2_MNT6_753 G2_MNT6_753_CHK;
 PCD_WIRE_CURVE(MNT4_298, F298A, PCD_MNT4_298_NR_SMALL, 2)
 PCD_WIRE_CURVE(MNT6_298, F298B, PCD_MNT6_298_NR_SMALL, 3)
 PCD_WIRE_CURVE(MNT4_753, F753A, PCD_MNT4_753_NR_SMALL, 2)
@@ -304,7 +325,7 @@ int w_serialize(int group, const uint64_t* xy, const uint8_t* inf, size_t n, int
   return PCDHIP_OK;
 }
 template <class W>
-int w_deserialize(int group, const uint8_t* in, size_t n, int compressed, uint64_t* xy, uint8_t* inf) {
+int w_deserialize(int group, const uint8_t* in, size_t n, int compressed, uint64_t* xy, uint8_t* inf, bool check_subgroup = true) {
   if (group == 1) {
     typedef CurveIO<typename W::B> IO;
     const typename W::B a = W::a1(), b = W::b1();
@@ -318,6 +339,8 @@ int w_deserialize(int group, const uint8_t* in, size_t n, int compressed, uint64
     for (size_t i = 0; i < n; i++) {
       int rc = IO::deserialize(in + i * IO::size(compressed), compressed, a, b, (uint32_t*)xy + i * 2 * W::E2::ABI_WORDS, inf + i);
       if (rc) return rc;
+      static_assert(std::is_same<typename W::G2C::F, typename W::E2>::value, "subgroup check runs on the field type the point was read in");
+      if (check_subgroup && !inf[i] && !g2_in_subgroup<typename W::G2C>((const uint32_t*)xy + i * 2 * W::E2::ABI_WORDS)) return PCDHIP_E_ARG;
     }
   }
   return PCDHIP_OK;
@@ -347,6 +370,15 @@ int pcdhip_serialize_points(int curve_id, int group_id, const uint64_t* xy_mont,
   if ((group_id != 1 && group_id != 2) || (n && (!xy_mont || !out))) return PCDHIP_E_ARG;
   try {
 #define CALL(W) w_serialize<W>(group_id, xy_mont, inf, n, compressed, out)
+    PCD_WIRE_DISPATCH(curve_id, CALL)
+#undef CALL
+  } catch (...) { return PCDHIP_E_OOM; }
+  return PCDHIP_E_ARG;
+}
+int pcdhip_deserialize_points_unchecked(int curve_id, int group_id, const uint8_t* in, size_t n, int compressed, uint64_t* xy_mont, uint8_t* inf) {
+  if ((group_id != 1 && group_id != 2) || (n && (!in || !xy_mont || !inf))) return PCDHIP_E_ARG;
+  try {
+#define CALL(W) w_deserialize<W>(group_id, in, n, compressed, xy_mont, inf, false)
     PCD_WIRE_DISPATCH(curve_id, CALL)
 #undef CALL
   } catch (...) { return PCDHIP_E_OOM; }

@@ -120,7 +120,8 @@ def test_witness_map_skewed_2p20(co, gpu_ctx):
     r = co.skewed_r1cs(fr, (1 << 20) - 8, 2, seed=2020)
     want = co.witness_map(r, nthreads=THREADS)
     assert np.array_equal(gpu_ctx.witness_map(fr, r), want)
-    pk = gpu_ctx.g16_pk_upload(co.synthetic_keys(0, r, seed=2022, mt=True).host_struct(), 0)
+    keys = co.synthetic_keys(0, r, seed=2022, mt=True)          # (kept alive: host_struct() points into its arrays)
+    pk = gpu_ctx.g16_pk_upload(keys.host_struct(), 0)
     gpu_ctx.g16_pk_set_r1cs(pk, r)
     try:
         h, ms = gpu_ctx.witness_map_resident(pk, r)

@@ -65,3 +65,32 @@ def test_rejects_malformed(golden):
             rejected += 1
     assert 0 < rejected < 8
     assert capi.lib().pcdhip_serialized_size(7, 1, 1) == 0
+
+
+@pytest.mark.parametrize("cid", CURVES)
+def test_g2_subgroup_check(golden, cid):
+    """a point of the twist that is on the curve but outside the prime-order subgroup (the twists have huge cofactors: a point
+    rebuilt from a small abscissa is such a point, all but surely) is refused by the checked reads and accepted by the unchecked one;
+    a proof whose B is such a point is refused too"""
+    size = capi.lib().pcdhip_serialized_size(cid, 2, 1)
+    found = None
+    for k in range(2, 40):
+        x = bytearray(size); x[0] = k
+        try:
+            xy, inf = capi.deserialize_points(cid, 2, bytes(x), 1, compressed=True, unchecked=True)
+        except capi.PcdHipError:
+            continue                                            # not an abscissa
+        found = (bytes(x), xy)
+        break
+    assert found is not None
+    with pytest.raises(capi.PcdHipError):
+        capi.deserialize_points(cid, 2, found[0], 1, compressed=True)
+    g = golden("wire")
+    p1 = g[f"c{cid}_g1_xy"]
+    good = g[f"c{cid}_proof_ser1"].tobytes()
+    s1 = capi.lib().pcdhip_serialized_size(cid, 1, 1)
+    bad = good[:s1] + found[0] + good[s1 + size:]
+    assert len(bad) == len(good)
+    capi.proof_deserialize(cid, good, compressed=True)
+    with pytest.raises(capi.PcdHipError):
+        capi.proof_deserialize(cid, bad, compressed=True)
