@@ -1,10 +1,15 @@
 //! ark-ec fork, `src/msm_dispatch.rs`: route `VariableBaseMSM::multi_scalar_mul` for the eight groups libpcdhip.so supports to
 //! `pcdhip_msm`, keyed by the concrete affine type; `None` = run the upstream CPU code.  Bases are uploaded once per distinct
-//! slice (address + length + a digest of the first and last point) and kept resident: a KZG committer key is one vector that
-//! every commitment indexes by prefix (`powers_of_g[..deg + 1]`), which is exactly `pcdhip_msm(bases, offset, .., n)`.
+//! vector and kept resident: a KZG committer key is one vector that every commitment indexes by prefix
+//! (`powers_of_g[..deg + 1]`), which is exactly `pcdhip_msm(bases, offset, .., n)`.
+//!
+//! Marshalling goes through the CONCRETE curve types (`Any` downcast of the slice element to e.g. `ark_mnt4_298::G1Affine`,
+//! then its public `x`, `y`, `infinity` fields and the `BigInteger` limbs of each coefficient): `GroupAffine` / `GroupProjective`
+//! are not `repr(C)`, so nothing here looks at their memory.  A resident vector is identified by a digest of EVERY point it holds
+//! (plus curve, group and length) -- an address can be reused by another vector, and two keys can share their first and last point.
 use crate::AffineCurve;
-use ark_ff::PrimeField;
-use core::any::TypeId;
+use ark_ff::{BigInteger, PrimeField, Zero};
+use core::any::Any;
 use std::os::raw::c_int;
 
 extern "C" {
@@ -16,24 +21,82 @@ extern "C" {
 /// below this many pairs the PCIe round trip costs more than the CPU
 const MIN_PAIRS: usize = 1 << 12;
 
-/// (curve_id, group_id, u64 limbs of one base-field element, base-field coefficients per coordinate) of a supported group
-fn group_of<G: AffineCurve>() -> Option<(c_int, c_int, usize, usize)> {
-    let t = TypeId::of::<G>();
-    macro_rules! row { ($ty:ty, $c:expr, $g:expr, $l:expr, $d:expr) => { if t == TypeId::of::<$ty>() { return Some(($c, $g, $l, $d)); } }; }
-    row!(ark_mnt4_298::G1Affine, 0, 1, 5, 1); row!(ark_mnt4_298::G2Affine, 0, 2, 5, 2);
-    row!(ark_mnt6_298::G1Affine, 1, 1, 5, 1); row!(ark_mnt6_298::G2Affine, 1, 2, 5, 3);
-    row!(ark_mnt4_753::G1Affine, 2, 1, 12, 1); row!(ark_mnt4_753::G2Affine, 2, 2, 12, 2);
-    row!(ark_mnt6_753::G1Affine, 3, 1, 12, 1); row!(ark_mnt6_753::G2Affine, 3, 2, 12, 3);
-    None
+/// One supported group: how its affine points become C-ABI limbs (x || y, extension coefficients c0, c1 (, c2) in order, each the
+/// Montgomery `BigInteger` limbs) and how the library's Jacobian X || Y || Z comes back as the group's projective type.
+trait HipGroup: AffineCurve {
+    const CURVE: c_int;
+    const GROUP: c_int;
+    const LIMBS: usize;   // u64 limbs of one base-field element
+    const DEG: usize;     // base-field coefficients per coordinate
+    fn push(&self, xy: &mut Vec<u64>, inf: &mut Vec<u8>);
+    fn projective(xyz: &[u64]) -> Self::Projective;
 }
+fn push_fp<F: PrimeField>(f: &F, out: &mut Vec<u64>) { out.extend_from_slice(f.0.as_ref()); }   // Fp256/320/768(pub BigInteger): Montgomery limbs
+fn fp_from<F: PrimeField>(l: &[u64]) -> F {
+    let mut r = F::BigInt::default();
+    r.as_mut().copy_from_slice(l);
+    F::new(r)   // `new` takes the Montgomery representation as it is (ark-ff 0.3 `Fp*::new`)
+}
+macro_rules! impl_g1 {
+    ($krate:ident, $curve:expr, $limbs:expr) => {
+        impl HipGroup for $krate::G1Affine {
+            const CURVE: c_int = $curve; const GROUP: c_int = 1; const LIMBS: usize = $limbs; const DEG: usize = 1;
+            fn push(&self, xy: &mut Vec<u64>, inf: &mut Vec<u8>) { inf.push(self.infinity as u8); push_fp(&self.x, xy); push_fp(&self.y, xy); }
+            fn projective(w: &[u64]) -> Self::Projective {
+                let l = $limbs;
+                $krate::G1Projective::new(fp_from(&w[..l]), fp_from(&w[l..2 * l]), fp_from(&w[2 * l..3 * l]))   // Z = 0: the identity
+            }
+        }
+    };
+}
+macro_rules! impl_g2 {
+    ($krate:ident, $curve:expr, $limbs:expr, $deg:expr, [$($c:ident),+]) => {
+        impl HipGroup for $krate::G2Affine {
+            const CURVE: c_int = $curve; const GROUP: c_int = 2; const LIMBS: usize = $limbs; const DEG: usize = $deg;
+            fn push(&self, xy: &mut Vec<u64>, inf: &mut Vec<u8>) {
+                inf.push(self.infinity as u8);
+                $( push_fp(&self.x.$c, xy); )+
+                $( push_fp(&self.y.$c, xy); )+
+            }
+            fn projective(w: &[u64]) -> Self::Projective {
+                let l = $limbs;
+                let mut k = 0usize;
+                let mut next = || { let v = fp_from(&w[k * l..(k + 1) * l]); k += 1; v };
+                let mut x = <Self as AffineCurve>::BaseField::zero();
+                let (mut y, mut z) = (x, x);
+                $( x.$c = next(); )+
+                $( y.$c = next(); )+
+                $( z.$c = next(); )+
+                $krate::G2Projective::new(x, y, z)
+            }
+        }
+    };
+}
+impl_g1!(ark_mnt4_298, 0, 5);  impl_g2!(ark_mnt4_298, 0, 5, 2, [c0, c1]);
+impl_g1!(ark_mnt6_298, 1, 5);  impl_g2!(ark_mnt6_298, 1, 5, 3, [c0, c1, c2]);
+impl_g1!(ark_mnt4_753, 2, 12); impl_g2!(ark_mnt4_753, 2, 12, 2, [c0, c1]);
+impl_g1!(ark_mnt6_753, 3, 12); impl_g2!(ark_mnt6_753, 3, 12, 3, [c0, c1, c2]);
 
-struct Resident { key: (usize, usize, u64), handle: *mut u8, n: usize }
+/// `running[i]` = digest of the points 0 ..= i: a call on a PREFIX of a resident vector (KZG: `powers_of_g[..deg + 1]`) is recognised
+/// by content, `running[n - 1]`, and served as `pcdhip_msm(handle, 0, .., n)` (16 bytes of host memory per resident point)
+struct Resident { curve: c_int, group: c_int, n: usize, running: Vec<[u64; 2]>, handle: *mut u8 }
 struct State { ctx: *mut u8, bases: Vec<Resident> }
 unsafe impl Send for State {}
 static STATE: std::sync::Mutex<Option<State>> = std::sync::Mutex::new(None);
 
-pub fn try_msm<G: AffineCurve>(bases: &[G], scalars: &[<G::ScalarField as PrimeField>::BigInt]) -> Option<G::Projective> {
-    let (curve, group, limbs, deg) = group_of::<G>()?;
+/// two FNV-1a lanes over every limb and flag, point after point (a cache key: what is compared is content, never an address)
+fn running_digest(xy: &[u64], inf: &[u8], words: usize) -> Vec<[u64; 2]> {
+    let mut h = [0xcbf29ce484222325u64, 0x84222325cbf29ce4u64];
+    let mut out = Vec::with_capacity(inf.len());
+    for (i, flag) in inf.iter().enumerate() {
+        for (j, w) in xy[i * words..(i + 1) * words].iter().enumerate() { let k = j & 1; h[k] ^= *w; h[k] = h[k].wrapping_mul(0x100000001b3); }
+        h[0] ^= *flag as u64; h[0] = h[0].wrapping_mul(0x100000001b3);
+        out.push(h);
+    }
+    out
+}
+
+fn run<H: HipGroup>(bases: &[H], scalars: &[<H::ScalarField as PrimeField>::BigInt]) -> Option<H::Projective> {
     let n = bases.len().min(scalars.len());
     if n < MIN_PAIRS { return None; }
     let mut guard = STATE.lock().ok()?;
@@ -43,46 +106,45 @@ pub fn try_msm<G: AffineCurve>(bases: &[G], scalars: &[<G::ScalarField as PrimeF
         *guard = Some(State { ctx, bases: Vec::new() });
     }
     let st = guard.as_mut()?;
-    // A prefix of an already resident vector (same start address) reuses it; anything else is uploaded.
-    let words = 2 * deg * limbs;
-    let start = bases.as_ptr() as usize;
-    let digest = crate::msm_dispatch::slice_digest(bases, 0);
-    let hit = st.bases.iter().position(|r| r.key.0 == start && r.n >= n && r.key.2 == digest);
+    // pack (needed for the digest anyway: ~1 ns per limb next to an MSM of milliseconds), then look the vector up BY CONTENT; a
+    // prefix of a resident vector hits when the digest of its n points equals the resident vector's running digest at n
+    let words = 2 * H::DEG * H::LIMBS;
+    let mut xy = Vec::with_capacity(n * words);
+    let mut inf = Vec::with_capacity(n);
+    for p in &bases[..n] { p.push(&mut xy, &mut inf); }
+    let running = running_digest(&xy, &inf, words);
+    let d = running[n - 1];
+    let hit = st.bases.iter().position(|r| r.curve == H::CURVE && r.group == H::GROUP && r.n >= n && r.running[n - 1] == d);
     let idx = match hit {
         Some(i) => i,
         None => {
-            // repack: `GroupAffine { x, y, infinity }` -> x || y limbs + flag bytes (coordinates are Montgomery `BigInteger` limbs)
-            let mut xy = Vec::with_capacity(n * words);
-            let mut inf = Vec::with_capacity(n);
-            for p in &bases[..n] { crate::msm_dispatch::push_point(p, &mut xy, &mut inf, words); }
             let mut h = core::ptr::null_mut();
-            if unsafe { pcdhip_bases_upload(st.ctx, curve, group, xy.as_ptr(), inf.as_ptr(), n, &mut h) } != 0 { return None; }
-            st.bases.push(Resident { key: (start, n, digest), handle: h, n });
+            if unsafe { pcdhip_bases_upload(st.ctx, H::CURVE, H::GROUP, xy.as_ptr(), inf.as_ptr(), n, &mut h) } != 0 { return None; }
+            st.bases.push(Resident { curve: H::CURVE, group: H::GROUP, n, running, handle: h });
             st.bases.len() - 1
         }
     };
-    let mut sc = Vec::with_capacity(n * limbs);
+    let mut sc = Vec::with_capacity(n * H::LIMBS);
     for s in &scalars[..n] { sc.extend_from_slice(s.as_ref()); }
-    let mut out = vec![0u64; 3 * deg * limbs];
+    let mut out = vec![0u64; 3 * H::DEG * H::LIMBS];
     if unsafe { pcdhip_msm(st.ctx, st.bases[idx].handle, 0, sc.as_ptr(), n, out.as_mut_ptr()) } != 0 { return None; }
-    Some(crate::msm_dispatch::projective_from_limbs::<G>(&out))
+    Some(H::projective(&out))
 }
 
-/// x || y Montgomery limbs of one point, as they sit in memory (the affine structs of the supported curves are
-/// `{ x, y, infinity: bool, PhantomData }`: two field elements followed by the flag)
-pub(crate) fn push_point<G: AffineCurve>(p: &G, xy: &mut Vec<u64>, inf: &mut Vec<u8>, words: usize) {
-    inf.push(p.is_zero() as u8);
-    xy.extend_from_slice(unsafe { core::slice::from_raw_parts(p as *const G as *const u64, words) });
-}
-/// X || Y || Z Montgomery limbs -> `G::Projective` (same layout argument; Z = 0 is the identity)
-pub(crate) fn projective_from_limbs<G: AffineCurve>(xyz: &[u64]) -> G::Projective {
-    let mut r = <G::Projective as ark_ff::Zero>::zero();
-    unsafe { core::ptr::copy_nonoverlapping(xyz.as_ptr(), &mut r as *mut G::Projective as *mut u64, xyz.len()) };
-    r
-}
-pub(crate) fn slice_digest<G: AffineCurve>(bases: &[G], _seed: u64) -> u64 {
-    let bytes = |p: &G| unsafe { core::slice::from_raw_parts(p as *const G as *const u8, core::mem::size_of::<G>()) };
-    let mut h: u64 = 0xcbf29ce484222325;
-    for b in bytes(&bases[0]).iter().chain(bytes(&bases[bases.len() - 1]).iter()) { h ^= *b as u64; h = h.wrapping_mul(0x100000001b3); }
-    h
+/// the generic entry point of the fork: `G` is one of the eight supported affine types, or the upstream code runs
+pub fn try_msm<G: AffineCurve>(bases: &[G], scalars: &[<G::ScalarField as PrimeField>::BigInt]) -> Option<G::Projective> {
+    macro_rules! route {
+        ($ty:ty) => {
+            if let Some(b) = (&bases as &dyn Any).downcast_ref::<&[$ty]>() {
+                let s = (&scalars as &dyn Any).downcast_ref::<&[<<$ty as AffineCurve>::ScalarField as PrimeField>::BigInt]>()?;
+                let r = run::<$ty>(b, s)?;
+                return (&r as &dyn Any).downcast_ref::<G::Projective>().copied();
+            }
+        };
+    }
+    route!(ark_mnt4_298::G1Affine); route!(ark_mnt4_298::G2Affine);
+    route!(ark_mnt6_298::G1Affine); route!(ark_mnt6_298::G2Affine);
+    route!(ark_mnt4_753::G1Affine); route!(ark_mnt4_753::G2Affine);
+    route!(ark_mnt6_753::G1Affine); route!(ark_mnt6_753::G2Affine);
+    None
 }

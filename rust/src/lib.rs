@@ -75,6 +75,15 @@ impl_hip_curve!(ark_mnt6_753::MNT6_753, ark_mnt6_753, 3, 12, 3, [c0, c1, c2]);
 
 pub struct HipGroth16<E: HipCurve>(PhantomData<E>);
 
+/// Proofs over fewer constraints than this stay on the CPU (upstream arithmetic on the same synthesis).  Every synthesis of the
+/// reference's Main / Help circuit makes a `circuit_specific_setup` + `prove` of a `DefaultCircuit` with `HelpSNARK`
+/// (/root/reference src/ec_cycle_pcd/data_structures.rs:134-143, :339-350): a few hundred rows, for which a key digest, an
+/// upload and the window-shifted copies of five queries cost far more than the proof.  `PCDHIP_MIN_CONSTRAINTS` overrides.
+pub const DEFAULT_MIN_CONSTRAINTS: usize = 1 << 12;
+fn min_constraints() -> usize {
+    std::env::var("PCDHIP_MIN_CONSTRAINTS").ok().and_then(|v| v.parse().ok()).unwrap_or(DEFAULT_MIN_CONSTRAINTS)
+}
+
 impl<E: HipCurve> SNARK<E::Fr> for HipGroth16<E> {
     // identical key / proof types: `ECCyclePCDPK` / `ECCyclePCDVK` (data_structures.rs:14-24, :40-47) are unchanged and keys
     // made by either SNARK work with the other
@@ -103,6 +112,10 @@ impl<E: HipCurve> SNARK<E::Fr> for HipGroth16<E> {
         circuit.generate_constraints(cs.clone())?;
         debug_assert!(cs.is_satisfied().unwrap());
         cs.finalize();
+        if cs.num_constraints() < min_constraints() {
+            // the tiny inner proofs of a synthesis (and anything else below the threshold): no device round trip
+            return prover::cpu_prove_with_rs::<E>(pk, cs, r, s);
+        }
         let matrices = cs.to_matrices().ok_or(SynthesisError::AssignmentMissing)?;
         let z: Vec<E::Fr> = {
             let prover = cs.borrow().ok_or(SynthesisError::MissingCS)?;

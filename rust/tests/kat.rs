@@ -1,0 +1,183 @@
+//! Known-answer test against the REAL arkworks: computes, with upstream ark-ec / ark-poly / ark-groth16 / ark-serialize, the values
+//! this repository's oracle, golden vectors and HIP kernels are pinned to, for the golden INPUTS, and writes them as text.
+//!
+//!     python tools/kat_export.py                                   # tests/golden/*.npz -> rust/tests/kat_inputs.txt
+//!     (cd rust && cargo test --release --test kat -- --nocapture)  # this file -> rust/tests/kat_outputs.txt
+//!     python tools/check_kat.py                                    # kat_outputs.txt == tests/golden/*.npz ?
+//!
+//! Covered: variable-base MSM on the eight groups (`VariableBaseMSM::multi_scalar_mul`), radix-2 transforms on the four scalar
+//! fields (`Radix2EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}`), the reduced pairing on the four curves, the witness map
+//! and the Groth16 proof for given (r, s) on MNT4-298 / MNT6-298 (`create_proof_with_reduction` over a circuit that replays the
+//! golden constraint system), and the `CanonicalSerialize` bytes of points.  Never compiled in the build container (no toolchain).
+use ark_ec::msm::VariableBaseMSM;
+use ark_ec::{AffineCurve, PairingEngine, ProjectiveCurve};
+use ark_ff::{BigInteger, Field, PrimeField, Zero};
+use ark_groth16::{create_proof_with_reduction, r1cs_to_qap::LibsnarkReduction, ProvingKey, VerifyingKey};
+use ark_pcd_hip::{marshal, HipCurve};
+use ark_poly::{EvaluationDomain, Radix2EvaluationDomain};
+use ark_relations::lc;
+use ark_relations::r1cs::{ConstraintSynthesizer, ConstraintSystemRef, LinearCombination, SynthesisError, Variable};
+use ark_serialize::CanonicalSerialize;
+use std::collections::HashMap;
+use std::fmt::Write as _;
+
+type Arrays = HashMap<String, (Vec<usize>, Vec<u64>)>;
+
+fn load() -> Arrays {
+    let text = std::fs::read_to_string(concat!(env!("CARGO_MANIFEST_DIR"), "/tests/kat_inputs.txt"))
+        .expect("run `python tools/kat_export.py` first");
+    let mut m = Arrays::new();
+    for ln in text.lines() {
+        let mut it = ln.split(' ');
+        let (name, _dtype, shape, data) = (it.next().unwrap(), it.next().unwrap(), it.next().unwrap(), it.next().unwrap());
+        let shape = shape.split('x').map(|d| d.parse().unwrap()).collect();
+        let data = data.split(',').map(|h| u64::from_str_radix(h, 16).unwrap()).collect();
+        m.insert(name.to_string(), (shape, data));
+    }
+    m
+}
+fn emit(out: &mut String, name: &str, dtype: &str, shape: &[usize], data: &[u64]) {
+    let shape: Vec<String> = shape.iter().map(|d| d.to_string()).collect();
+    let data: Vec<String> = data.iter().map(|v| format!("{:x}", v)).collect();
+    writeln!(out, "{} {} {} {}", name, dtype, shape.join("x"), data.join(",")).unwrap();
+}
+fn fr_vec<F: PrimeField>(a: &(Vec<usize>, Vec<u64>)) -> Vec<F> {   // rows of Montgomery limbs -> field elements
+    let l = a.0[a.0.len() - 1];
+    a.1.chunks(l).map(marshal::fp_from_limbs::<F>).collect()
+}
+fn fr_limbs<F: PrimeField>(v: &[F]) -> Vec<u64> { let mut o = Vec::new(); for x in v { marshal::push_fp(x, &mut o); } o }
+
+fn g1s<E: HipCurve>(a: &Arrays, xy: &str, inf: &str) -> Vec<E::G1Affine> {
+    let w = 2 * E::FQ_LIMBS;
+    let flags = a.get(inf).map(|f| f.1.clone()).unwrap_or_default();
+    a[xy].1.chunks(w).enumerate().map(|(i, c)| E::g1_from(c, flags.get(i).copied().unwrap_or(0) != 0)).collect()
+}
+fn g2s<E: HipCurve>(a: &Arrays, xy: &str, inf: &str) -> Vec<E::G2Affine> {
+    let w = 2 * E::G2_DEG * E::FQ_LIMBS;
+    let flags = a.get(inf).map(|f| f.1.clone()).unwrap_or_default();
+    a[xy].1.chunks(w).enumerate().map(|(i, c)| E::g2_from(c, flags.get(i).copied().unwrap_or(0) != 0)).collect()
+}
+
+fn msm<E: HipCurve>(a: &Arrays, out: &mut String) {
+    let c = E::CURVE_ID;
+    let scal = |name: &str| -> Vec<<E::Fr as PrimeField>::BigInt> {
+        a[name].1.chunks(a[name].0[1]).map(|l| { let mut b = <E::Fr as PrimeField>::BigInt::default(); b.as_mut().copy_from_slice(l); b }).collect()
+    };
+    let p1 = g1s::<E>(a, &format!("msm.c{}_g1_bases", c), &format!("msm.c{}_g1_inf", c));
+    let r1 = VariableBaseMSM::multi_scalar_mul(&p1, &scal(&format!("msm.c{}_g1_scalars", c))).into_affine();
+    let (mut xy, mut inf) = (Vec::new(), Vec::new());
+    E::push_g1(&r1, &mut xy, &mut inf);
+    if r1.is_zero() { xy.iter_mut().for_each(|w| *w = 0); }
+    emit(out, &format!("msm.c{}_g1_result_xy", c), "uint64", &[xy.len()], &xy);
+    emit(out, &format!("msm.c{}_g1_result_inf", c), "uint8", &[1], &[inf[0] as u64]);
+    let p2 = g2s::<E>(a, &format!("msm.c{}_g2_bases", c), &format!("msm.c{}_g2_inf", c));
+    let r2 = VariableBaseMSM::multi_scalar_mul(&p2, &scal(&format!("msm.c{}_g2_scalars", c))).into_affine();
+    let (mut xy, mut inf) = (Vec::new(), Vec::new());
+    E::push_g2(&r2, &mut xy, &mut inf);
+    if r2.is_zero() { xy.iter_mut().for_each(|w| *w = 0); }
+    emit(out, &format!("msm.c{}_g2_result_xy", c), "uint64", &[xy.len()], &xy);
+    emit(out, &format!("msm.c{}_g2_result_inf", c), "uint8", &[1], &[inf[0] as u64]);
+}
+
+fn fft<F: PrimeField + ark_ff::FftField>(a: &Arrays, fid: usize, out: &mut String) {
+    for (name, arr) in a.iter().filter(|(k, _)| k.starts_with(&format!("fft.f{}_n", fid)) && k.ends_with("_in")) {
+        let x: Vec<F> = fr_vec(arr);
+        let dom = Radix2EvaluationDomain::<F>::new(x.len()).unwrap();
+        let stem = &name[..name.len() - 3];
+        for (inv, coset) in [(0, 0), (0, 1), (1, 0), (1, 1)].iter() {
+            let mut v = x.clone();
+            match (inv, coset) {
+                (0, 0) => dom.fft_in_place(&mut v), (0, 1) => dom.coset_fft_in_place(&mut v),
+                (1, 0) => dom.ifft_in_place(&mut v), _ => dom.coset_ifft_in_place(&mut v),
+            }
+            emit(out, &format!("{}_i{}c{}", stem, inv, coset), "uint64", &arr.0, &fr_limbs(&v));
+        }
+    }
+}
+
+fn fqk_limbs<E: HipCurve>(g: &E::Fqk) -> Vec<u64> {
+    // GT in tower order c0, c1 over Fq2 / Fq3, base-field coefficients in order: exactly the element's `to_base_prime_field_elements`
+    let mut o = Vec::new();
+    for c in g.to_base_prime_field_elements() { marshal::push_fp(&c, &mut o); }
+    o
+}
+fn pairing<E: HipCurve>(a: &Arrays, out: &mut String) {
+    let c = E::CURVE_ID;
+    let p = E::g1_from(&a[&format!("pairing.c{}_p", c)].1, false);
+    let q = E::g2_from(&a[&format!("pairing.c{}_q", c)].1, false);
+    let gt = E::pairing(p, q);
+    let l = fqk_limbs::<E>(&gt);
+    emit(out, &format!("pairing.c{}_gt", c), "uint64", &[l.len()], &l);
+}
+
+/// the golden constraint system, replayed: variables carry the golden assignment, every row is enforced as it stands
+struct Replay<F: PrimeField> { rows: [Vec<Vec<(F, usize)>>; 3], z: Vec<F>, num_inputs: usize }
+impl<F: PrimeField> ConstraintSynthesizer<F> for Replay<F> {
+    fn generate_constraints(self, cs: ConstraintSystemRef<F>) -> Result<(), SynthesisError> {
+        let mut vars = vec![Variable::One];
+        for (i, v) in self.z.iter().enumerate().skip(1) {
+            let v = *v;
+            vars.push(if i < self.num_inputs { cs.new_input_variable(|| Ok(v))? } else { cs.new_witness_variable(|| Ok(v))? });
+        }
+        let lc_of = |row: &Vec<(F, usize)>| -> LinearCombination<F> { let mut l = lc!(); for (c, j) in row { l = l + (*c, vars[*j]); } l };
+        for j in 0..self.rows[0].len() { cs.enforce_constraint(lc_of(&self.rows[0][j]), lc_of(&self.rows[1][j]), lc_of(&self.rows[2][j]))?; }
+        Ok(())
+    }
+}
+fn csr<F: PrimeField>(a: &Arrays, pre: &str, m: &str) -> Vec<Vec<(F, usize)>> {
+    let rp = &a[&format!("{}rp_{}", pre, m)].1;
+    let col = &a[&format!("{}col_{}", pre, m)].1;
+    let cf: Vec<F> = fr_vec(&a[&format!("{}coeff_{}", pre, m)]);
+    (0..rp.len() - 1).map(|j| (rp[j] as usize..rp[j + 1] as usize).map(|k| (cf[k], col[k] as usize)).collect()).collect()
+}
+fn groth16<E: HipCurve>(a: &Arrays, out: &mut String) {
+    let pre = format!("groth16.c{}_", E::CURVE_ID);
+    let z: Vec<E::Fr> = fr_vec(&a[&format!("{}z", pre)]);
+    let ni = a[&format!("{}num_inputs", pre)].1[0] as usize;
+    let one1 = |k: &str| E::g1_from(&a[&format!("{}{}", pre, k)].1, false);
+    let one2 = |k: &str| E::g2_from(&a[&format!("{}{}", pre, k)].1, false);
+    let q1 = |k: &str| g1s::<E>(a, &format!("{}{}", pre, k), &format!("{}{}_inf", pre, k));
+    let vk = VerifyingKey::<E> { alpha_g1: one1("alpha_g1"), beta_g2: one2("beta_g2"), gamma_g2: one2("gamma_g2"), delta_g2: one2("delta_g2"),
+                                 gamma_abc_g1: q1("gamma_abc_g1") };
+    let pk = ProvingKey::<E> { vk, beta_g1: one1("beta_g1"), delta_g1: one1("delta_g1"), a_query: q1("a_query"), b_g1_query: q1("b_g1_query"),
+                               b_g2_query: g2s::<E>(a, &format!("{}b_g2_query", pre), &format!("{}b_g2_query_inf", pre)),
+                               h_query: q1("h_query"), l_query: q1("l_query") };
+    let circuit = Replay::<E::Fr> { rows: [csr(a, &pre, "a"), csr(a, &pre, "b"), csr(a, &pre, "c")], z, num_inputs: ni };
+    let r: E::Fr = marshal::fp_from_limbs(&a[&format!("{}r", pre)].1);
+    let s: E::Fr = marshal::fp_from_limbs(&a[&format!("{}s", pre)].1);
+    let proof = create_proof_with_reduction::<E, _, LibsnarkReduction>(circuit, &pk, r, s).unwrap();
+    let (mut xy, mut inf) = (Vec::new(), Vec::new());
+    E::push_g1(&proof.a, &mut xy, &mut inf); E::push_g2(&proof.b, &mut xy, &mut inf); E::push_g1(&proof.c, &mut xy, &mut inf);
+    emit(out, &format!("{}proof", pre), "uint64", &[xy.len()], &xy);
+}
+
+fn wire<E: HipCurve>(a: &Arrays, out: &mut String) {
+    let c = E::CURVE_ID;
+    let p1 = g1s::<E>(a, &format!("wire.c{}_g1_xy", c), &format!("wire.c{}_g1_inf", c));
+    let p2 = g2s::<E>(a, &format!("wire.c{}_g2_xy", c), &format!("wire.c{}_g2_inf", c));
+    let bytes = |v: &Vec<u8>| -> Vec<u64> { v.iter().map(|b| *b as u64).collect() };
+    for comp in 0..2 {
+        let (mut b1, mut b2) = (Vec::new(), Vec::new());
+        for p in &p1 { if comp == 1 { p.serialize(&mut b1).unwrap() } else { p.serialize_uncompressed(&mut b1).unwrap() } }
+        for p in &p2 { if comp == 1 { p.serialize(&mut b2).unwrap() } else { p.serialize_uncompressed(&mut b2).unwrap() } }
+        emit(out, &format!("wire.c{}_g1_ser{}", c, comp), "uint8", &[b1.len()], &bytes(&b1));
+        emit(out, &format!("wire.c{}_g2_ser{}", c, comp), "uint8", &[b2.len()], &bytes(&b2));
+    }
+}
+
+#[test]
+fn kat() {
+    let a = load();
+    let mut out = String::new();
+    msm::<ark_mnt4_298::MNT4_298>(&a, &mut out); msm::<ark_mnt6_298::MNT6_298>(&a, &mut out);
+    msm::<ark_mnt4_753::MNT4_753>(&a, &mut out); msm::<ark_mnt6_753::MNT6_753>(&a, &mut out);
+    fft::<ark_mnt4_298::Fq>(&a, 0, &mut out); fft::<ark_mnt4_298::Fr>(&a, 1, &mut out);
+    fft::<ark_mnt4_753::Fq>(&a, 2, &mut out); fft::<ark_mnt4_753::Fr>(&a, 3, &mut out);
+    pairing::<ark_mnt4_298::MNT4_298>(&a, &mut out); pairing::<ark_mnt6_298::MNT6_298>(&a, &mut out);
+    pairing::<ark_mnt4_753::MNT4_753>(&a, &mut out); pairing::<ark_mnt6_753::MNT6_753>(&a, &mut out);
+    groth16::<ark_mnt4_298::MNT4_298>(&a, &mut out); groth16::<ark_mnt6_298::MNT6_298>(&a, &mut out);
+    wire::<ark_mnt4_298::MNT4_298>(&a, &mut out); wire::<ark_mnt6_298::MNT6_298>(&a, &mut out);
+    wire::<ark_mnt4_753::MNT4_753>(&a, &mut out); wire::<ark_mnt6_753::MNT6_753>(&a, &mut out);
+    std::fs::write(concat!(env!("CARGO_MANIFEST_DIR"), "/tests/kat_outputs.txt"), &out).unwrap();
+    println!("wrote {} lines to rust/tests/kat_outputs.txt: now run `python tools/check_kat.py`", out.lines().count());
+}

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Known-answer-test bridge to the real arkworks (for whoever has `cargo`; there is none in the build container).
+
+    python tools/kat_export.py          # tests/golden/*.npz  ->  rust/tests/kat_inputs.txt   (inputs only, as text)
+    (cd rust && cargo test --release --test kat -- --nocapture)   # arkworks computes: rust/tests/kat_outputs.txt
+    python tools/check_kat.py           # compares kat_outputs.txt with the expected values in tests/golden/*.npz
+
+Text format, one array per line:  <file>.<key> <dtype> <dim0>x<dim1>.. <hex,hex,...>   (row-major, u64 / u32 / u8 as hex)."""
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+# what the Rust side needs as INPUT (expected outputs stay in the npz files and are compared by check_kat.py)
+INPUT_KEYS = {
+    "msm": lambda k: k.endswith(("_bases", "_inf", "_scalars")),
+    "fft": lambda k: k.endswith("_in"),
+    "pairing": lambda k: k.endswith(("_p", "_q")),
+    "groth16": lambda k: not k.endswith(("_h", "_proof", "_proof_inf")),
+    "wire": lambda k: k.endswith(("_xy", "_inf")),
+}
+
+
+def line(name, a):
+    a = np.ascontiguousarray(a)
+    shape = "x".join(str(d) for d in a.shape) or "1"
+    return f"{name} {a.dtype} {shape} " + ",".join(format(int(v), "x") for v in a.reshape(-1))
+
+
+def main():
+    out = []
+    for f, want in INPUT_KEYS.items():
+        g = np.load(os.path.join(GOLDEN, f + ".npz"))
+        for k in g.files:
+            if want(k):
+                out.append(line(f"{f}.{k}", g[k]))
+    path = os.path.join(ROOT, "rust", "tests", "kat_inputs.txt")
+    with open(path, "w") as fh:
+        fh.write("\n".join(out) + "\n")
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) // 1024} KiB")
+
+
+if __name__ == "__main__":
+    main()
