@@ -11,7 +11,7 @@
 
 #include "../../include/pcdhip.h"
 #include "msm.hip.h"
-#include "pairing_vm.hip.h"
+#include "vm_tables.h"
 
 namespace pcd {
 

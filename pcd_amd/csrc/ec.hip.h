@@ -163,8 +163,14 @@ template <class G> struct SplitOfTail {
   typedef typename std::conditional<(PCD_MAILBOX_TAIL != 0 && AccOf<G>::LANES == SplitOf<G>::LANES), typename AccOf<G>::type, typename SplitOf<G>::type>::type type;
   static constexpr int LANES = SplitOf<G>::LANES;
 };
+// (PCD_MAILBOX_TAIL_FQ3: the Fq3-753 reduction kernels in the mailbox form too.  Round 2 kept them on the plain form because ONE kernel
+//  returned a wrong limb there: msm_merge_ones_kernel -- one item, three active lanes, both operands finite; localised with
+//  tools/probe_fq3_tail.py, not cured by keeping every item slot of the wave active, gone when the result is canonicalised before the
+//  store: code generation, not arithmetic.  That kernel and msm_horner_kernel (the other single-item kernel) now always compute in the
+//  plain lane-split form -- one addition per MSM, the memory image is the same -- and with that every probe case, the edge-case tests
+//  on all eight groups and the at-size tests are exact in the mailbox form: Fq3-753 MSM at 2^15 20.8 -> 17.5 ms.)
 #ifndef PCD_MAILBOX_TAIL_FQ3
-#define PCD_MAILBOX_TAIL_FQ3 0
+#define PCD_MAILBOX_TAIL_FQ3 1
 #endif
 #if !PCD_MAILBOX_TAIL_FQ3
 template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE, bool INL>

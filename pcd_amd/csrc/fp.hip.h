@@ -879,7 +879,9 @@ struct Fp3S {
   // Mailbox forms: coefficients are posted in the lanes' LDS slots and the non-inlined bodies read the partners' directly (no
   // ds_bpermute exchange, no data selects -- the role picks addresses)
   __device__ __noinline__ static void mb_mul_call(typename F::MbPtr mb) {
-    const unsigned l = threadIdx.x & 63u, k = l % 3u, l0 = l - k;       // l0: the lane holding coefficient 0 of this triple
+    // l0: the lane holding coefficient 0 of this triple (lane 63 has no triple: it idles in every kernel; should it ever come here it
+    // reads lane 61's triple instead of indexing past the 64 slots)
+    const unsigned l = threadIdx.x & 63u, k = l % 3u, l0 = l == 63u ? 60u : l - k;
     const unsigned k1 = k == 2 ? 0 : k + 1, k2 = k == 0 ? 2 : k - 1;    // (k + 1) mod 3, (k + 2) mod 3
     const F a = F::mb_get_lane(mb, 0, l), an = F::mb_get_lane(mb, 0, l0 + k1), an2 = F::mb_get_lane(mb, 0, l0 + k2);
     // own a_k meets b_0, a_(k+1) meets b_2, a_(k+2) meets b_1 on every lane (the lane formulas above)
@@ -890,7 +892,7 @@ struct Fp3S {
     F::mb_put(mb, 0, o);
   }
   __device__ __noinline__ static void mb_sqr_call(typename F::MbPtr mb) {
-    const unsigned l = threadIdx.x & 63u, k = l % 3u, l0 = l - k;
+    const unsigned l = threadIdx.x & 63u, k = l % 3u, l0 = l == 63u ? 60u : l - k;
     const unsigned k1 = k == 2 ? 0 : k + 1, k2 = k == 0 ? 2 : k - 1;
     const F a = F::mb_get_lane(mb, 0, l), an = F::mb_get_lane(mb, 0, l0 + k1), an2 = F::mb_get_lane(mb, 0, l0 + k2);
     //   lane 0:  a0 a0 + (2 nr a1) a2      lane 1:  (2 a0) a1 + (nr a2) a2      lane 2:  a1 a1 + (2 a0) a2

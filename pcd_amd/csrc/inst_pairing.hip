@@ -56,7 +56,6 @@ __global__ void __launch_bounds__(64) final_exp_kernel(const uint32_t* __restric
 // ---- one wave per pairing (pairing_vm.hip.h): the latency form, used for small batches -------------------------------------------
 typedef VmWave<Fq, VG> VM;
 constexpr int KK = PE::K, DD = PE::K / 2;
-constexpr size_t VM_LDS_BYTES = (size_t)VG::NREGS * VmArith<Fq>::STRIDE * 4;
 // flat coefficient j (of v^j) <-> tower position: c_(j mod 2), coefficient j / 2 of the twist field
 PCD_DEV int tower_word(int j, int words) { return ((j & 1) * DD + (j >> 1)) * words; }
 
@@ -139,8 +138,9 @@ hipError_t multi_pairing(hipStream_t st, const uint32_t* g1_dev, const uint32_t*
                          uint32_t* gt_out, const VmTables* vm) {
   const uint32_t n = groups * per;
   if (vm && n <= VM_MAX_PAIRS) {
-    if (n) hipLaunchKernelGGL(vm_miller_kernel, dim3(n), dim3(64), VM_LDS_BYTES, st, g1_dev, g2_dev, n, scratch, *vm);
-    if (groups) hipLaunchKernelGGL(vm_final_exp_kernel, dim3(groups), dim3(64), VM_LDS_BYTES, st, scratch, groups, per, gt_out, *vm);
+    const size_t lds = (size_t)VM::lds_words(*vm) * 4;  // register file + the program tables
+    if (n) hipLaunchKernelGGL(vm_miller_kernel, dim3(n), dim3(64), lds, st, g1_dev, g2_dev, n, scratch, *vm);
+    if (groups) hipLaunchKernelGGL(vm_final_exp_kernel, dim3(groups), dim3(64), lds, st, scratch, groups, per, gt_out, *vm);
     return hipGetLastError();
   }
   if (n) hipLaunchKernelGGL(miller_kernel, dim3((n + 63) / 64), dim3(64), 0, st, g1_dev, g2_dev, n, scratch);
@@ -187,6 +187,7 @@ static hipError_t vm_upload(hipStream_t st, void** block, VmTables* out) {
   if ((e = hipMemcpyAsync(d + o2, VM_TABLE(code), b2, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(d + o3, VM_TABLE(consts), b3, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
   out->progs = (const uint32_t*)d; out->steps = (const uint32_t*)(d + o1); out->code = (const uint32_t*)(d + o2); out->consts = (const uint32_t*)(d + o3);
+  out->nprogs = (uint32_t)(b0 / 12); out->nsteps = (uint32_t)(b1 / 12); out->ncode = (uint32_t)(b2 / 4);
   return hipStreamSynchronize(st);
 }
 const PairingEntry* PCD_CAT(pcd_pairing_entry_, PCD_CURVE_IDX)() {

@@ -23,15 +23,9 @@
 #pragma once
 #include "fp.hip.h"
 #include "pairing_vm_gen.h"
+#include "vm_tables.h"
 
 namespace pcd {
-
-struct VmTables {  // device (or, in the host harness, host) copies of one curve's generated tables
-  const uint32_t* progs;   // [nprogs][3]  first step, steps, mask of the state slots written
-  const uint32_t* steps;   // [nsteps][3]  kind, first instruction, instructions
-  const uint32_t* code;    // 12 words per instruction
-  const uint32_t* consts;  // [NCONST][N]
-};
 
 template <class F>
 struct VmArith {
@@ -128,15 +122,24 @@ struct VmWave {
   typedef VmArith<F> A;
   typedef __attribute__((address_space(3))) uint32_t* Lds;
   Lds regs;
+  Lds code, steps, progs;  // the program tables, copied into LDS once: an instruction fetch is a ~100-cycle LDS read, not a dependent
+                           // trip to L2 in front of every one of the thousands of steps of a pairing
   uint32_t bank;
-  VmTables tb;
+
+  // LDS words: the register file, then the tables
+  static constexpr uint32_t REG_WORDS = (uint32_t)G::NREGS * A::STRIDE;
+  __host__ __device__ static uint32_t lds_words(const VmTables& t) { return REG_WORDS + t.ncode + 3 * t.nsteps + 3 * t.nprogs; }
 
   PCD_DEV void init(Lds r, const VmTables& t) {
-    regs = r; bank = 0; tb = t;
+    regs = r; bank = 0;
+    code = r + REG_WORDS; steps = code + t.ncode; progs = steps + 3 * t.nsteps;
+    for (uint32_t i = threadIdx.x; i < t.ncode; i += 64) code[i] = t.code[i];
+    for (uint32_t i = threadIdx.x; i < 3 * t.nsteps; i += 64) steps[i] = t.steps[i];
+    for (uint32_t i = threadIdx.x; i < 3 * t.nprogs; i += 64) progs[i] = t.progs[i];
     for (uint32_t c = threadIdx.x; c < (uint32_t)G::NCONST; c += 64) {
       F v;
 #pragma unroll
-      for (int i = 0; i < F::N; i++) v.v[i] = tb.consts[c * F::N + i];
+      for (int i = 0; i < F::N; i++) v.v[i] = t.consts[c * F::N + i];
       A::st(regs, G::CONST_BASE + c, v);
     }
   }
@@ -147,22 +150,20 @@ struct VmWave {
 
   // one program: steps in order, a barrier (one wave: a fence) after each; lanes beyond a step's instruction count idle
   __device__ __noinline__ void run(int pid) {
-    const uint32_t first = tb.progs[3 * pid], cnt = tb.progs[3 * pid + 1];
+    const uint32_t first = progs[3 * pid], cnt = progs[3 * pid + 1];
     const uint32_t lane = threadIdx.x;
     for (uint32_t s = first; s < first + cnt; s++) {
-      const uint32_t kind = tb.steps[3 * s], off = tb.steps[3 * s + 1], n = tb.steps[3 * s + 2];
+      const uint32_t kind = steps[3 * s], off = steps[3 * s + 1], n = steps[3 * s + 2];
       if (lane < n) {
         uint32_t w[12];
-        const uint4* src = (const uint4*)(tb.code + (size_t)(off + lane) * 12);
-        const uint4 w0 = src[0], w1 = src[1], w2 = src[2];
-        w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
-        w[8] = w2.x; w[9] = w2.y; w[10] = w2.z; w[11] = w2.w;
+#pragma unroll
+        for (int i = 0; i < 12; i++) w[i] = code[(off + lane) * 12 + i];
         const F o = kind ? A::mul(w, regs, bank) : A::lin(w, regs, bank);
         A::st(regs, A::reg_of(w[0] >> 16, bank), o);   // (every lane has read its operands before any lane stores: lockstep)
       }
       __syncthreads();
     }
-    bank ^= tb.progs[3 * pid + 2];
+    bank ^= progs[3 * pid + 2];
   }
 };
 #endif

@@ -220,7 +220,7 @@ static void vm_pairing_host(const VmTables& tb, const uint32_t* g1, const uint32
   vm.run(VG::P_FE_LAST);
   for (int j = 0; j < K; j++) vm.get_state(VG::S_ACC0 + j).to_abi(out + ((j & 1) * D + (j >> 1)) * Fq::ABI_WORDS);
 }
-#define HC_VM_TABLES(C) VmTables{&vmgen::C##_progs[0][0], &vmgen::C##_steps[0][0], vmgen::C##_code, &vmgen::C##_consts[0][0]}
+#define HC_VM_TABLES(C) VmTables{&vmgen::C##_progs[0][0], &vmgen::C##_steps[0][0], vmgen::C##_code, &vmgen::C##_consts[0][0], 0, 0, 0}
 extern "C" int hc_vm_pairing(int curve, const uint32_t* g1, const uint32_t* g2, int n, uint32_t* out) {
   switch (curve) {
     case 0: vm_pairing_host<PC_MNT4_298, vmgen::MNT4_298>(HC_VM_TABLES(MNT4_298), g1, g2, n, out); break;

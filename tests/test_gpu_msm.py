@@ -56,7 +56,31 @@ def test_vs_oracle(co, gpu_ctx, cid, grp, sizes, dist):
         check(co, gpu_ctx, cid, grp, pts, sc)
 
 
-@pytest.mark.parametrize("cid,grp", [(0, 1), (1, 2), (2, 1)])
+@pytest.mark.parametrize("cid,grp", GROUPS)
+def test_ones_bucket_merge(co, gpu_ctx, cid, grp):
+    """scalars equal to one go to a pseudo bucket that msm_merge_ones_kernel adds to bucket (window 0, digit 1): with scalars 1 and
+    2^c + 1 both operands of that addition are finite points (the case the mailbox form of the Fq3-753 addition got wrong in that
+    kernel: it computes in the plain form since); also only ones, ones next to an empty bucket 1, and a copy of the same point"""
+    fr = co.CURVE_FR[cid]
+    L = co.FIELD_N64[fr]
+    pts = co.gen_points(cid, grp, 64, seed=171)
+    for c in (8, 11):
+        for other in (2, (1 << c) + 1, (1 << c) + 2, 1):
+            for n in (2, 8, 64):
+                sc = np.zeros((n, L), dtype=np.uint64)
+                sc[:, 0] = 1
+                sc[1::2, 0] = other
+                p = pts[:n].copy()
+                if other == 1:
+                    p[1] = p[0]                       # the pseudo bucket holds a point twice
+                gpu_ctx.msm_config(c, 0)
+                try:
+                    check(co, gpu_ctx, cid, grp, p, sc, modes=(-1,))
+                finally:
+                    gpu_ctx.msm_config(0, 0)
+
+
+@pytest.mark.parametrize("cid,grp", [(0, 1), (1, 2), (2, 1), (2, 2), (3, 2)])
 def test_edge_cases(co, gpu_ctx, cid, grp):
     """ragged / degenerate inputs: duplicate bases (doubling branch), flagged infinities, scalars 0, 1, r-1,
     2^c - 1, 2^c around every plausible window size, one giant bucket, sub-ranges of a resident query."""
