@@ -1657,15 +1657,16 @@ int pcdhip_groth16_setup(pcdhip_ctx* ctx, int curve_id, const pcdhip_csr* A, con
 
 // ------------------------------------------------------------------------------------------------ pairing
 // groups x per pairs -> groups GT elements
+// g1_z (nullable; honoured by the wave-per-pairing kernels only -- callers pass it only while ctx->pairing_vm): Z of Jacobian G1 points
 static int pairing_groups(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, const uint8_t* g1_inf, const uint64_t* g2_xy,
-                          const uint8_t* g2_inf, size_t groups, size_t per, uint64_t* gt_out) {
+                          const uint8_t* g2_inf, size_t groups, size_t per, uint64_t* gt_out, const uint64_t* g1_z = nullptr) {
   const size_t n_pairs = groups * per;
   if (!ctx || !valid_curve(curve_id) || (n_pairs && (!g1_xy || !g2_xy)) || !gt_out || n_pairs >= (1u << 24) || (groups && !per)) return PCDHIP_E_ARG;
   BIND();
   const PairingEntry& pe = pairing_entry(curve_id);
   const size_t w1 = (size_t)pcdhip_point_limbs(curve_id, 1) * 8, w2 = (size_t)pcdhip_point_limbs(curve_id, 2) * 8;
   const size_t gb = (size_t)pe.gt_words * 4, gi = (size_t)pe.gt_internal_words * 4;
-  const size_t gt_off = n_pairs * (w1 + w2 + gi), flag_off = gt_off + std::max<size_t>(groups, 1) * gb;
+  const size_t gt_off = n_pairs * (w1 + w2 + gi), z_off = gt_off + std::max<size_t>(groups, 1) * gb, flag_off = z_off + n_pairs * (w1 / 2);
   TRY(ctx->aux_ws.ensure(AUX_MISC, flag_off + 2 * n_pairs + 256));
   char* d = (char*)ctx->aux_ws.buf[AUX_MISC];
   uint32_t* g1d = (uint32_t*)d;
@@ -1680,7 +1681,12 @@ static int pairing_groups(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, 
     TRY(zero_flagged(ctx->stream, g2d, (uint8_t*)d + flag_off + n_pairs, g2_inf, n_pairs, w2));
   }
   if (!ctx->vm_block[curve_id] && ctx->pairing_vm) TRY(pe.vm_upload(ctx->stream, &ctx->vm_block[curve_id], &ctx->vm_tables[curve_id]));
-  TRY(pe.multi_pairing(ctx->stream, g1d, g2d, (uint32_t)groups, (uint32_t)per, scr, out, ctx->pairing_vm ? &ctx->vm_tables[curve_id] : nullptr));
+  uint32_t* g1zd = nullptr;
+  if (g1_z && n_pairs) {
+    g1zd = (uint32_t*)(d + z_off);
+    TRY(hipMemcpyAsync(g1zd, g1_z, n_pairs * (w1 / 2), hipMemcpyHostToDevice, ctx->stream));
+  }
+  TRY(pe.multi_pairing(ctx->stream, g1d, g1zd, g2d, (uint32_t)groups, (uint32_t)per, scr, out, ctx->pairing_vm ? &ctx->vm_tables[curve_id] : nullptr));
   TRY(hipMemcpyAsync(gt_out, out, groups * gb, hipMemcpyDeviceToHost, ctx->stream));
   TRY(hipStreamSynchronize(ctx->stream));
   return PCDHIP_OK;
@@ -1699,7 +1705,7 @@ int pcdhip_multi_pairing(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, c
     const PairingEntry& pe = pairing_entry(curve_id);
     TRY(ctx->aux_ws.ensure(AUX_MISC, (size_t)pe.gt_words * 4 + 256));
     uint32_t* out = (uint32_t*)ctx->aux_ws.buf[AUX_MISC];
-    TRY(pe.multi_pairing(ctx->stream, out, out, 1, 0, out, out, nullptr));  // (the lane-per-pairing kernels: one lane, no pairs)
+    TRY(pe.multi_pairing(ctx->stream, out, nullptr, out, 1, 0, out, out, nullptr));  // (the lane-per-pairing kernels: one lane, no pairs)
     TRY(hipMemcpyAsync(gt_out, out, (size_t)pe.gt_words * 4, hipMemcpyDeviceToHost, ctx->stream));
     TRY(hipStreamSynchronize(ctx->stream));
     return PCDHIP_OK;
@@ -1765,7 +1771,10 @@ void scalar_lincomb(int fr, const uint64_t* const* a, const uint64_t* const* b, 
   }
 }
 // acc_i = gamma_abc[0] + sum_j x_ij gamma_abc[j] for k proofs (Jacobian C-ABI image -> affine + flags), through the resident bases
-int prepare_inputs(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_t k, const uint64_t* public_inputs, std::vector<uint64_t>* acc_a, std::vector<uint8_t>* acc_inf) {
+// acc_z (nullable): when given, non-empty on return iff the accumulations came back in Jacobian form -- (X, Y) in acc_a, Z in acc_z -- which
+// happens with window tables and the wave-per-pairing kernels on (they take Jacobian G1 points: no inversion anywhere in a verification)
+int prepare_inputs(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_t k, const uint64_t* public_inputs, std::vector<uint64_t>* acc_a, std::vector<uint8_t>* acc_inf,
+                   std::vector<uint64_t>* acc_z = nullptr) {
   const int cid = pvk->curve_id;
   const size_t l1 = (size_t)pcdhip_point_limbs(cid, 1), sl = (size_t)kFieldLimbs[kCurveFr[cid]], ni = pvk->num_inputs;
   std::vector<uint64_t> acc_j(k * (l1 / 2 * 3)), scal(ni * sl);
@@ -1774,14 +1783,17 @@ int prepare_inputs(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_t k, const uint6
   if (pvk->abc_dev) {  // window tables: every proof's accumulation in one launch, no doubling chains
     const GroupEntry& ge = group_entry(cid, 1);
     const size_t jw = (size_t)ge.point_words / 2 * 3, sb = (ni - 1) * sl * 8;
-    TRY(ctx->aux_ws.ensure(AUX_FB_JAC, k * (64 * jw * 4 + sb + l1 * 8 + 1) + 64));
+    const bool jac = acc_z && ctx->pairing_vm;
+    TRY(ctx->aux_ws.ensure(AUX_FB_JAC, k * (64 * jw * 4 + sb + l1 * 8 + l1 * 4 + 1) + 64));
     char* d = (char*)ctx->aux_ws.buf[AUX_FB_JAC];
     uint32_t* scratch = (uint32_t*)d;
     uint32_t* scal_d = (uint32_t*)(d + k * 64 * jw * 4);
     uint32_t* out_d = (uint32_t*)((char*)scal_d + k * sb);
-    uint8_t* inf_d = (uint8_t*)out_d + k * l1 * 8;
+    uint32_t* z_d = (uint32_t*)((char*)out_d + k * l1 * 8);
+    uint8_t* inf_d = (uint8_t*)z_d + k * l1 * 4;
     if (sb) TRY(hipMemcpyAsync(scal_d, public_inputs, k * sb, hipMemcpyHostToDevice, ctx->stream));
-    TRY(ge.fb_inputs(ctx->stream, pvk->abc_dev + pvk->abc_tables_off, pvk->abc_dev, (uint32_t)ni, scal_d, (uint32_t)k, scratch, out_d, inf_d));
+    TRY(ge.fb_inputs(ctx->stream, pvk->abc_dev + pvk->abc_tables_off, pvk->abc_dev, (uint32_t)ni, scal_d, (uint32_t)k, scratch, out_d, inf_d, jac ? z_d : nullptr));
+    if (jac) { acc_z->assign(k * (l1 / 2), 0); TRY(hipMemcpyAsync(acc_z->data(), z_d, k * l1 * 4, hipMemcpyDeviceToHost, ctx->stream)); }
     TRY(hipMemcpyAsync(acc_a->data(), out_d, k * l1 * 8, hipMemcpyDeviceToHost, ctx->stream));
     TRY(hipMemcpyAsync(acc_inf->data(), inf_d, k, hipMemcpyDeviceToHost, ctx->stream));
     TRY(hipStreamSynchronize(ctx->stream));
@@ -1865,12 +1877,16 @@ int pcdhip_groth16_verify_prepared(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_
   BIND();
   const int cid = pvk->curve_id;
   const size_t l1 = (size_t)pcdhip_point_limbs(cid, 1), l2 = (size_t)pcdhip_point_limbs(cid, 2), pl = 2 * l1 + l2, k = n_proofs;
-  std::vector<uint64_t> acc_a;
+  std::vector<uint64_t> acc_a, acc_z;
   std::vector<uint8_t> acc_inf;
-  int rc = prepare_inputs(ctx, pvk, k, public_inputs_canonical, &acc_a, &acc_inf);
+  int rc = prepare_inputs(ctx, pvk, k, public_inputs_canonical, &acc_a, &acc_inf, &acc_z);
   if (rc) return rc;
-  const size_t gw = pvk->alpha_beta.size();
-  std::vector<uint64_t> gt(k * gw), g1s(3 * k * l1), g2s(3 * k * l2);
+  const size_t gw = pvk->alpha_beta.size(), lz = l1 / 2;
+  std::vector<uint64_t> gt(k * gw), g1s(3 * k * l1), g2s(3 * k * l2), g1z;
+  if (!acc_z.empty()) {  // Z = 1 (the first coefficient of GT's one) for the proof's own points, the accumulation's Z for the middle pair
+    g1z.resize(3 * k * lz);
+    for (size_t i = 0; i < 3 * k; i++) memcpy(&g1z[i * lz], i % 3 == 1 ? &acc_z[(i / 3) * lz] : pvk->gt_one.data(), lz * 8);
+  }
   std::vector<uint8_t> inf1(3 * k, 0), inf2(3 * k, 0);
   for (size_t i = 0; i < k; i++) {
     const uint64_t* pr = proofs + i * pl;
@@ -1883,7 +1899,7 @@ int pcdhip_groth16_verify_prepared(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_
     inf1[3 * i + 1] = acc_inf[i];
     if (proofs_inf) { inf1[3 * i] = proofs_inf[3 * i]; inf2[3 * i] = proofs_inf[3 * i + 1]; inf1[3 * i + 2] = proofs_inf[3 * i + 2]; }
   }
-  rc = pairing_groups(ctx, cid, g1s.data(), inf1.data(), g2s.data(), inf2.data(), k, 3, gt.data());
+  rc = pairing_groups(ctx, cid, g1s.data(), inf1.data(), g2s.data(), inf2.data(), k, 3, gt.data(), g1z.empty() ? nullptr : g1z.data());
   if (rc) return rc;
   for (size_t i = 0; i < k; i++) ok[i] = memcmp(&gt[i * gw], pvk->alpha_beta.data(), gw * 8) == 0 ? 1 : 0;
   return PCDHIP_OK;

@@ -105,7 +105,7 @@ struct pcdhip_ctx {
   int pipe_next = 0;
   // program tables of the wave-per-pairing VM (pairing_vm.hip.h), uploaded per curve on first use
   void* vm_block[4] = {nullptr, nullptr, nullptr, nullptr};
-  pcd::VmTables vm_tables[4] = {};
+  pcd::VmCurveTables vm_tables[4] = {};
   bool pairing_vm = true;  // small batches of pairings run one wave per pairing (pcdhip_pairing_set_mode)
   hipEvent_t xstream_ev = nullptr;  // pcdhip_stream_wait: ordering against a caller-owned stream (e.g. the RCCL stream)
   std::string last_hip_error;
@@ -141,10 +141,11 @@ struct GroupEntry {
   hipError_t (*fixed_base)(hipStream_t, const uint32_t* base_abi, const uint32_t* scalars, uint32_t n, uint32_t* table_scratch,
                            uint32_t* jac_scratch, uint32_t* out_abi, uint8_t* out_inf);
   // prepared public inputs (fixed_base.hip.h): window tables of the bases 1 .. ni - 1 (fb_table_words each, consecutive), then
-  // acc_i = base_0 + sum_j x_ij base_j for k proofs in one launch (scratch: k x 64 Jacobians), C-ABI affine out
+  // acc_i = base_0 + sum_j x_ij base_j for k proofs in one launch (scratch: k x 64 Jacobians), C-ABI affine out -- or, with out_z_abi,
+  // the Jacobian (X, Y) in out_abi and Z in out_z_abi (no inversion)
   hipError_t (*fb_tables)(hipStream_t, const uint32_t* bases_abi, uint32_t ni, uint32_t* tables);
   hipError_t (*fb_inputs)(hipStream_t, const uint32_t* tables, const uint32_t* base0_abi, uint32_t ni, const uint32_t* scalars, uint32_t k,
-                          uint32_t* scratch, uint32_t* out_abi, uint8_t* out_inf);
+                          uint32_t* scratch, uint32_t* out_abi, uint8_t* out_inf, uint32_t* out_z_abi);
 };
 const GroupEntry& group_entry(int curve_id, int group_id);  // group_id 1 / 2
 
@@ -205,9 +206,10 @@ struct PairingEntry {
   int gt_internal_words;  // ... in the device image (scratch sizing)
   // gt_out[g] = final_exp(prod_{i < per} miller(P_{g per + i}, Q_{g per + i})) for g < groups; scratch: groups * per GT elements;
   // vm: this device's copy of the curve's VM program tables (pairing_vm.hip.h; null = the lane-per-pairing kernels only)
-  hipError_t (*multi_pairing)(hipStream_t, const uint32_t* g1_dev, const uint32_t* g2_dev, uint32_t groups, uint32_t per,
-                              uint32_t* scratch, uint32_t* gt_out, const VmTables* vm);
-  hipError_t (*vm_upload)(hipStream_t, void** block, VmTables* out);
+  // g1z_dev (nullable; wave-per-pairing form only): the Z coordinates of the G1 points, which are then Jacobian (X, Y in g1_dev)
+  hipError_t (*multi_pairing)(hipStream_t, const uint32_t* g1_dev, const uint32_t* g1z_dev, const uint32_t* g2_dev, uint32_t groups, uint32_t per,
+                              uint32_t* scratch, uint32_t* gt_out, const VmCurveTables* vm);
+  hipError_t (*vm_upload)(hipStream_t, void** block, VmCurveTables* out);
 };
 const PairingEntry& pairing_entry(int curve_id);
 

@@ -109,7 +109,7 @@ template <class G>
 __global__ void __launch_bounds__(64) fb_inputs_kernel(const uint32_t* __restrict__ tables, size_t tab_words, const uint32_t* __restrict__ abc0_abi, uint32_t ni,
                                                        const uint32_t* __restrict__ scalars /* k x (ni - 1) canonical */, int nwin, int w,
                                                        uint32_t* __restrict__ scratch /* k x 64 Jacobians */, uint32_t* __restrict__ out_abi,
-                                                       uint8_t* __restrict__ out_inf) {
+                                                       uint8_t* __restrict__ out_inf, uint32_t* __restrict__ out_z_abi /* nullable */) {
   typedef typename G::F F;
   constexpr int SW = G::FR::N32, JW = Jac<F>::WORDS;
   const uint32_t proof = blockIdx.x, lane = threadIdx.x;
@@ -136,9 +136,15 @@ __global__ void __launch_bounds__(64) fb_inputs_kernel(const uint32_t* __restric
     __syncthreads();
   }
   if (lane == 0) {
-    const Aff<F> a = EC<G>::to_affine(acc);
-    a.to_abi(out_abi + (size_t)proof * Aff<F>::ABI_WORDS);
     out_inf[proof] = acc.is_inf() ? 1 : 0;
+    if (out_z_abi) {  // Jacobian result (X, Y | Z): the pairing VM takes it as it is -- no inversion (pairing_vm.hip.h)
+      if (acc.is_inf()) acc = Jac<F>::infinity();
+      const Aff<F> xy = {acc.X, acc.Y};
+      xy.to_abi(out_abi + (size_t)proof * Aff<F>::ABI_WORDS);
+      acc.Z.to_abi(out_z_abi + (size_t)proof * F::ABI_WORDS);
+    } else {
+      EC<G>::to_affine(acc).to_abi(out_abi + (size_t)proof * Aff<F>::ABI_WORDS);
+    }
   }
 }
 // tables of the bases 1 .. ni - 1 (C-ABI affine image, consecutive), `tab_words` apart: each slot = the table, then the nwin Jacobians
@@ -156,9 +162,9 @@ hipError_t fb_tables_build(hipStream_t st, const uint32_t* bases_abi, uint32_t n
 }
 template <class G>
 hipError_t fb_inputs_run(hipStream_t st, const uint32_t* tables, size_t tab_words, const uint32_t* abc0_abi, uint32_t ni, const uint32_t* scalars,
-                         uint32_t k, uint32_t* scratch, uint32_t* out_abi, uint8_t* out_inf) {
+                         uint32_t k, uint32_t* scratch, uint32_t* out_abi, uint8_t* out_inf, uint32_t* out_z_abi) {
   constexpr int w = FB_WINDOW, nwin = (G::FR::BITS + w - 1) / w;
-  if (k) hipLaunchKernelGGL((fb_inputs_kernel<G>), dim3(k), dim3(64), 0, st, tables, tab_words, abc0_abi, ni, scalars, nwin, w, scratch, out_abi, out_inf);
+  if (k) hipLaunchKernelGGL((fb_inputs_kernel<G>), dim3(k), dim3(64), 0, st, tables, tab_words, abc0_abi, ni, scalars, nwin, w, scratch, out_abi, out_inf, out_z_abi);
   return hipGetLastError();
 }
 

@@ -36,6 +36,7 @@ namespace pcd {
     static constexpr uint32_t INV = PFX28##_INV;                                                              \
     static constexpr int EST_SHIFT = PFX28##_EST_SHIFT;                                                       \
     static constexpr uint32_t EST_RECIP = PFX28##_EST_RECIP;                                                  \
+    static constexpr double RECIP_D = PFX28##_RECIP_D;                                                        \
     PCD_HD static uint32_t mod(int i) { constexpr uint32_t m[N] = PFX28##_MOD; return m[i]; }                 \
     PCD_HD static uint32_t mod2(int i) { constexpr uint32_t m[N] = PFX28##_MOD2; return m[i]; }               \
     PCD_HD static uint32_t mod4(int i) { constexpr uint32_t m[N] = PFX28##_MOD4; return m[i]; }               \
@@ -528,9 +529,10 @@ struct Fp {
     return norm_reduce<false>(r);
   }
   // The value of a signed limb-wise sum of small multiples of field elements: s[i] = sum_t c_t a_t[i] with every a_t in [0, 2p) and
-  // sum |c_t| <= 124; K = 2 sum |negative c_t| (K p is added so that the integer is non-negative and below 2^8 p).  One carry chain,
-  // a quotient estimate from the two top limbs (never above the true quotient, at most 2 short) and one conditional subtraction
-  // bring it to [0, 2p).  The LIN instruction of the pairing VM and the unit / small-coefficient terms of the mat-vec use it.
+  // sum |c_t| <= 2000; K = 2 sum |negative c_t| (K p is added so that the integer V is non-negative; V < 2^12 p).  One carry chain, a
+  // quotient estimate in double precision from the two top limbs (d = V / 2^(28 (N - 2)) up to a relative 2^-52, times a reciprocal of
+  // p biased down by 2^-30: never above floor(V / p), at most 1 short) and one conditional subtraction bring it to [0, 2p).  The LIN
+  // instruction of the pairing VM and the small-coefficient entries of the mat-vec use it.
   PCD_HD static Fp from_signed_sum(const int64_t* s, int64_t K) {
     uint32_t t28[N];
     int64_t cy = 0;
@@ -540,19 +542,18 @@ struct Fp {
       t28[i] = (uint32_t)cy & MASK;
       cy >>= 28;
     }
-    cy += s[N - 1] + K * (int64_t)P::mod(N - 1);  // top limb, kept whole (>= 0)
-    const uint64_t top2 = ((uint64_t)cy << 28) | t28[N - 2];
-    const uint32_t est = (uint32_t)(top2 >> P::EST_SHIFT);
-    const uint32_t q = (uint32_t)(((uint64_t)est * P::EST_RECIP) >> 32);
+    cy += s[N - 1] + K * (int64_t)P::mod(N - 1);  // top limb, kept whole (>= 0, below 2^40)
+    const double d = (double)cy * 268435456.0 + (double)t28[N - 2];
+    const int64_t q = (int64_t)(d * P::RECIP_D);
     int32_t r[N];
     int64_t cc = 0;
 #pragma unroll
     for (int i = 0; i < N - 1; i++) {
-      cc += (int64_t)t28[i] - (int64_t)((uint64_t)q * P::mod(i));
+      cc += (int64_t)t28[i] - q * (int64_t)P::mod(i);
       r[i] = (int32_t)((uint32_t)cc & MASK);
       cc >>= 28;
     }
-    cc += cy - (int64_t)((uint64_t)q * P::mod(N - 1));
+    cc += cy - q * (int64_t)P::mod(N - 1);
     r[N - 1] = (int32_t)cc;
     return norm_reduce<false>(r);
   }

@@ -228,9 +228,9 @@ hipError_t convert(hipStream_t st, const uint32_t* in, uint32_t* out, uint32_t n
 
 // ---- the three mat-vecs of the witness map: out[i] = <M_i, z> (i < rows);  out[rows + j] = z[j] (j < num_inputs) if append_inputs;
 // 0 up to n.  Entries with small integer coefficients (DevCsr, common.h) cost additions, not products: a lane sums c * z[col] limb-wise
-// in 64 bits for up to SPMV_FLUSH entries (sum |c| <= 124) and reduces once (Fp::from_signed_sum); only the heavy entries take a
+// in 64 bits for up to SPMV_FLUSH entries (sum |c| <= 2000) and reduces once (Fp::from_signed_sum); only the heavy entries take a
 // Montgomery product.  The two kinds are separate loops, so a wave whose rows hold no heavy entry never executes a product.
-constexpr int SPMV_FLUSH = 3;  // light entries per reduction: 3 x 32 <= 124
+constexpr int SPMV_FLUSH = 48;  // light entries per reduction: 48 x 32 <= 2000
 struct SpmvLight {
   int64_t s[FT::N];
   int64_t K = 0;

@@ -59,38 +59,40 @@ constexpr int KK = PE::K, DD = PE::K / 2;
 // flat coefficient j (of v^j) <-> tower position: c_(j mod 2), coefficient j / 2 of the twist field
 PCD_DEV int tower_word(int j, int words) { return ((j & 1) * DD + (j >> 1)) * words; }
 
-// f_i = the Miller value of pair i, UN-INVERTED when the loop count is negative (vm_final_exp_kernel conjugates at the end instead)
-__global__ void __launch_bounds__(64) vm_miller_kernel(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
-                                                       uint32_t* __restrict__ out, const VmTables tb) {
+// f_i = the Miller value of pair i up to a factor in Fq* (the lines are evaluated times pz^3: see tools/gen_pairing_vm.py) and
+// UN-INVERTED when the loop count is negative -- vm_final_exp_kernel kills the one and conjugates for the other.  g1z (nullable):
+// the Z coordinates of the G1 points, which then are Jacobian (X, Y, Z) with X, Y in g1 -- no inversion for a point that was just summed
+__global__ void __launch_bounds__(64) vm_miller_kernel(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g1z, const uint32_t* __restrict__ g2,
+                                                       uint32_t n, uint32_t* __restrict__ out, const VmTables tb) {
   extern __shared__ __attribute__((aligned(16))) uint32_t vm_lds[];
   const uint32_t pair = blockIdx.x, lane = threadIdx.x;
   VM vm;
   vm.init((VM::Lds)vm_lds, tb);
-  // lanes 0, 1: the G1 coordinates; lanes 2 .. 2 + 2 DD - 1: the G2 coefficients (x then y); (0, 0) is the point at infinity
+  // lanes 0, 1: the G1 coordinates, lane 2: its Z; lanes 3 .. 3 + 2 DD - 1: the G2 coefficients (x then y); (0, 0) is the point at infinity
   bool nz = false;
-  if (lane < 2u + 2u * DD) {
-    const uint32_t* src = lane < 2 ? g1 + (size_t)pair * A1A + lane * Fq::ABI_WORDS : g2 + (size_t)pair * A2A + (lane - 2) * Fq::ABI_WORDS;
-    for (int i = 0; i < Fq::ABI_WORDS; i++) nz = nz || src[i] != 0;
-    const Fq v = Fq::from_abi(src);
+  if (lane < 3u + 2u * DD) {
+    const uint32_t* src = lane < 2 ? g1 + (size_t)pair * A1A + lane * Fq::ABI_WORDS
+                        : lane == 2 ? (g1z ? g1z + (size_t)pair * Fq::ABI_WORDS : nullptr) : g2 + (size_t)pair * A2A + (lane - 3) * Fq::ABI_WORDS;
+    Fq v = Fq::one();
+    if (src) {
+      for (int i = 0; i < Fq::ABI_WORDS; i++) nz = nz || src[i] != 0;
+      v = Fq::from_abi(src);
+    } else nz = true;
     int r;
     if (lane == 0) r = VG::R_PX0;
     else if (lane == 1) r = VG::R_PY0;
-    else { const int c = (int)lane - 2; r = (c < DD ? VG::R_QX0 : VG::R_QY0) + (c % DD); }  // (qx0, qx2, .. and qy0, qy2, .. are consecutive registers)
+    else if (lane == 2) r = VG::R_PZ0;
+    else { const int c = (int)lane - 3; r = (c < DD ? VG::R_QX0 : VG::R_QY0) + (c % DD); }  // (qx0, qx2, .. and qy0, qy2, .. are consecutive registers)
     vm.set_reg(r, v);
   }
   const unsigned long long m = __ballot(nz);
-  const bool inf = (m & 3ull) == 0 || (m >> 2) == 0;
+  const bool inf = (m & 3ull) == 0 || (m & 4ull) == 0 || (m >> 3) == 0;   // (0, 0) in G1, Z = 0, or (0, 0) in G2
   __syncthreads();
   if (inf) {  // e(O, Q) = e(P, O) = 1
     if (lane < (uint32_t)KK) (lane == 0 ? Fq::one() : Fq::zero()).store(out + (size_t)pair * GW + tower_word((int)lane, Fq::WORDS));
     return;
   }
-  vm.run(VG::P_SETUP);
-  for (int i = PCT::LOOP_BITS - 2; i >= 0; i--) {
-    vm.run(VG::P_DBL);
-    if (PE::loop_bit(i)) vm.run(VG::P_ADD);
-  }
-  if (PCT::LOOP_NEG) vm.run(VG::P_NEGFIX);
+  vm.run_script();
   if (lane < (uint32_t)KK) vm.get_state(VG::S_F0 + (int)lane).store(out + (size_t)pair * GW + tower_word((int)lane, Fq::WORDS));
 }
 // one wave per group of `per` consecutive Miller values: their product, then the final exponentiation
@@ -109,40 +111,26 @@ __global__ void __launch_bounds__(64) vm_final_exp_kernel(const uint32_t* __rest
   for (uint32_t i = 1; i < per; i++) {
     if (lane < (uint32_t)KK) vm.set_reg(VG::R_G0 + (int)lane, Fq::load(fs + ((size_t)g * per + i) * GW + tower_word((int)lane, Fq::WORDS)));
     __syncthreads();
-    vm.run(VG::P_FE_MUL);
+    vm.run(VM_TABLE(final_exp_P_FE_MUL));
   }
-  vm.run(VG::P_FE_NORM);
-  vm.run(VG::P_FQ_INIT);
-  {  // nrm^(p - 2): the one field inversion of a final exponentiation
-    int top = Fq::Params::N32 * 32 - 1;
-    while (!((Fq::Params::modm2(top >> 5) >> (top & 31)) & 1)) top--;
-    for (int i = top - 1; i >= 0; i--) {
-      vm.run(VG::P_FQ_SQR);
-      if ((Fq::Params::modm2(i >> 5) >> (i & 31)) & 1) vm.run(VG::P_FQ_MUL);
-    }
-  }
-  vm.run(VG::P_FE_EASY);
-  for (int i = PCT::W0_BITS - 2; i >= 0; i--) {
-    vm.run(VG::P_POW_SQR);
-    if ((PCT::w0(i >> 5) >> (i & 31)) & 1) vm.run(VG::P_POW_MUL);
-  }
-  vm.run(VG::P_FE_LAST);
+  vm.run_script();  // norm, the one field inversion (sliding window over p - 2), easy part, w0 power (sliding window), last product
   if (lane < (uint32_t)KK) vm.get_state(VG::S_ACC0 + (int)lane).to_abi(out + (size_t)g * GWA + tower_word((int)lane, Fq::ABI_WORDS));
 }
 
 // gt_out[g] = final_exp(prod_{i < per} miller(P_{g per + i}, Q_{g per + i})), g < groups.
 // Up to VM_MAX_PAIRS pairs: one wave per pairing (a Miller loop's dependent chain is ~15x shorter); beyond, one lane per pairing
-// (64 pairings per wave: the throughput form for batches that fill the chip anyway).
+// (64 pairings per wave: the throughput form for batches that fill the chip anyway).  g1z_dev (nullable, wave form only): Z
+// coordinates of Jacobian G1 points.
 constexpr uint32_t VM_MAX_PAIRS = 4096;
-hipError_t multi_pairing(hipStream_t st, const uint32_t* g1_dev, const uint32_t* g2_dev, uint32_t groups, uint32_t per, uint32_t* scratch,
-                         uint32_t* gt_out, const VmTables* vm) {
+hipError_t multi_pairing(hipStream_t st, const uint32_t* g1_dev, const uint32_t* g1z_dev, const uint32_t* g2_dev, uint32_t groups, uint32_t per,
+                         uint32_t* scratch, uint32_t* gt_out, const VmCurveTables* vm) {
   const uint32_t n = groups * per;
   if (vm && n <= VM_MAX_PAIRS) {
-    const size_t lds = (size_t)VM::lds_words(*vm) * 4;  // register file + the program tables
-    if (n) hipLaunchKernelGGL(vm_miller_kernel, dim3(n), dim3(64), lds, st, g1_dev, g2_dev, n, scratch, *vm);
-    if (groups) hipLaunchKernelGGL(vm_final_exp_kernel, dim3(groups), dim3(64), lds, st, scratch, groups, per, gt_out, *vm);
+    if (n) hipLaunchKernelGGL(vm_miller_kernel, dim3(n), dim3(64), (size_t)VM::lds_words(vm->miller) * 4, st, g1_dev, g1z_dev, g2_dev, n, scratch, vm->miller);
+    if (groups) hipLaunchKernelGGL(vm_final_exp_kernel, dim3(groups), dim3(64), (size_t)VM::lds_words(vm->final_exp) * 4, st, scratch, groups, per, gt_out, vm->final_exp);
     return hipGetLastError();
   }
+  if (g1z_dev) return hipErrorInvalidValue;  // (the lane-per-pairing kernels take affine points)
   if (n) hipLaunchKernelGGL(miller_kernel, dim3((n + 63) / 64), dim3(64), 0, st, g1_dev, g2_dev, n, scratch);
   if (groups) hipLaunchKernelGGL(final_exp_kernel, dim3((groups + 63) / 64), dim3(64), 0, st, scratch, groups, per, gt_out);
   return hipGetLastError();
@@ -175,19 +163,26 @@ hipError_t g1_scale(hipStream_t st, const uint32_t* g1_dev, const uint32_t* k_de
 #define PCD_CAT_(a, b) a##b
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 // the generated program tables of this curve -> one device block; `out` points into it
-static hipError_t vm_upload(hipStream_t st, void** block, VmTables* out) {
-  const size_t b0 = sizeof(VM_TABLE(progs)), b1 = sizeof(VM_TABLE(steps)), b2 = sizeof(VM_TABLE(code)), b3 = sizeof(VM_TABLE(consts));
-  auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-  const size_t o1 = up16(b0), o2 = o1 + up16(b1), o3 = o2 + up16(b2), total = o3 + up16(b3);
-  hipError_t e = hipMalloc(block, total);
+static hipError_t vm_upload(hipStream_t st, void** block, VmCurveTables* out) {
+  struct Part { const void* src; size_t bytes; };
+  const Part parts[] = {
+      {VM_TABLE(miller_progs), sizeof(VM_TABLE(miller_progs))}, {VM_TABLE(miller_steps), sizeof(VM_TABLE(miller_steps))},
+      {VM_TABLE(miller_code), sizeof(VM_TABLE(miller_code))}, {VM_TABLE(miller_script), sizeof(VM_TABLE(miller_script))},
+      {VM_TABLE(final_exp_progs), sizeof(VM_TABLE(final_exp_progs))}, {VM_TABLE(final_exp_steps), sizeof(VM_TABLE(final_exp_steps))},
+      {VM_TABLE(final_exp_code), sizeof(VM_TABLE(final_exp_code))}, {VM_TABLE(final_exp_script), sizeof(VM_TABLE(final_exp_script))},
+      {VM_TABLE(consts), sizeof(VM_TABLE(consts))}};
+  size_t off[10] = {0};
+  for (int i = 0; i < 9; i++) off[i + 1] = off[i] + ((parts[i].bytes + 15) & ~(size_t)15);
+  hipError_t e = hipMalloc(block, off[9]);
   if (e != hipSuccess) return e;
   char* d = (char*)*block;
-  if ((e = hipMemcpyAsync(d, VM_TABLE(progs), b0, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(d + o1, VM_TABLE(steps), b1, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(d + o2, VM_TABLE(code), b2, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(d + o3, VM_TABLE(consts), b3, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-  out->progs = (const uint32_t*)d; out->steps = (const uint32_t*)(d + o1); out->code = (const uint32_t*)(d + o2); out->consts = (const uint32_t*)(d + o3);
-  out->nprogs = (uint32_t)(b0 / 12); out->nsteps = (uint32_t)(b1 / 12); out->ncode = (uint32_t)(b2 / 4);
+  for (int i = 0; i < 9; i++)
+    if ((e = hipMemcpyAsync(d + off[i], parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  auto at = [&](int i) { return (const uint32_t*)(d + off[i]); };
+  out->miller = {at(0), at(1), at(2), at(8), at(3), (uint32_t)(parts[0].bytes / 12), (uint32_t)(parts[1].bytes / 12), (uint32_t)(parts[2].bytes / 4),
+                 VM_TABLE(miller_script_len)};
+  out->final_exp = {at(4), at(5), at(6), at(8), at(7), (uint32_t)(parts[4].bytes / 12), (uint32_t)(parts[5].bytes / 12),
+                    (uint32_t)(parts[6].bytes / 4), VM_TABLE(final_exp_script_len)};
   return hipStreamSynchronize(st);
 }
 const PairingEntry* PCD_CAT(pcd_pairing_entry_, PCD_CURVE_IDX)() {

@@ -34,9 +34,17 @@ struct VmArith {
   static constexpr int STRIDE = (N + 3) & ~3;  // words per register record
   static constexpr uint32_t MASK = F::MASK;
 
-  PCD_HD static uint32_t reg_of(uint32_t op, uint32_t bank) {
+  // operand -> register: space 0 a plain register, 1 / 2 a state slot in its current / other bank (bank bits in the low half of `bank`),
+  // 3 an entry of a table: base + sel * stride + offset with the selector in bits 16.. of `bank`; TB = {base0, stride0, base1, stride1}
+  template <class G>
+  PCD_HD static uint32_t reg_of_g(uint32_t op, uint64_t bank) {
     const uint32_t sp = op >> 14, idx = op & 0x3FFFu;
-    return sp == 0 ? idx : 2 * idx + (((bank >> idx) & 1u) ^ (sp == 2 ? 1u : 0u));
+    if (sp == 0) return idx;
+    if (sp == 3) {
+      const uint32_t sel = (uint32_t)(bank >> 32);
+      return (idx >> 8) ? (uint32_t)G::TAB1_BASE + sel * (uint32_t)G::TAB1_STRIDE + (idx & 0xFFu) : (uint32_t)G::TAB0_BASE + sel * (uint32_t)G::TAB0_STRIDE + (idx & 0xFFu);
+    }
+    return 2 * idx + ((uint32_t)((bank >> idx) & 1u) ^ (sp == 2 ? 1u : 0u));
   }
   template <class PTR>
   PCD_HD static F ld(PTR regs, uint32_t r) {
@@ -51,25 +59,11 @@ struct VmArith {
     for (int i = 0; i < N; i++) regs[r * STRIDE + i] = v.v[i];
   }
 
-  // dst = (sum a_t b_t) / R', operands and result in [0, 2p): T (<= VM_TMAX) products summed column-wise in 64 bits
-  // ((T + 1) N 2^56 < 2^63), then one Montgomery reduction over the columns.  T = 2: 8 p^2 / R' + p < 2p (R' > 8p).
-  template <class PTR>
-  PCD_HD static F mul(const uint32_t* w, PTR regs, uint32_t bank) {
-    const int T = (int)((w[0] >> 8) & 0xFFu);
-    uint64_t col[2 * N];
-#pragma unroll
-    for (int i = 0; i < 2 * N; i++) col[i] = 0;
-    // (unrolled over the term slots with a predicate: the instruction words are indexed statically and stay in registers)
-#pragma unroll
-    for (int t = 0; t < vmgen::VM_TMAX; t++) {
-      if (t < T) {
-        const F a = ld(regs, reg_of(w[1 + t] & 0xFFFFu, bank)), b = ld(regs, reg_of(w[1 + t] >> 16, bank));
-#pragma unroll
-        for (int i = 0; i < N; i++)
-#pragma unroll
-          for (int j = 0; j < N; j++) col[i + j] += (uint64_t)a.v[i] * b.v[j];
-      }
-    }
+  // dst = a b / R', operands and result in [0, 2p): the product's 2N - 1 column sums in 64 bits (N 2^56 < 2^63 with room for the
+  // reduction's terms), then one Montgomery reduction over the columns: 4 p^2 / R' + p < 2p (R' > 8p).  SQR: the same for a = b with
+  // the off-diagonal products taken once, doubled (N (N + 1) / 2 + N^2 multiply-adds instead of 2 N^2).
+  static_assert(vmgen::VM_TMAX == 1, "one product per MUL instruction");
+  PCD_HD static F reduce_columns(uint64_t* col) {
 #pragma unroll
     for (int k = 0; k < N; k++) {
       const uint32_t m = ((uint32_t)col[k] * P::INV) & MASK;
@@ -77,24 +71,47 @@ struct VmArith {
       for (int j = 0; j < N; j++) col[k + j] += (uint64_t)m * P::mod(j);
       col[k + 1] += col[k] >> 28;
     }
-    int32_t r[N];
-#pragma unroll
-    for (int i = 0; i < N - 1; i++) {
-      r[i] = (int32_t)((uint32_t)col[N + i] & MASK);
-      col[N + i + 1] += col[N + i] >> 28;
-    }
-    r[N - 1] = (int32_t)(uint32_t)col[2 * N - 1];
-    if (vmgen::VM_TMAX > 2) return F::template norm_reduce<false>(r);  // up to 4p with more products per instruction
     F o;
 #pragma unroll
-    for (int i = 0; i < N; i++) o.v[i] = (uint32_t)r[i];
+    for (int i = 0; i < N - 1; i++) {
+      o.v[i] = (uint32_t)col[N + i] & MASK;
+      col[N + i + 1] += col[N + i] >> 28;
+    }
+    o.v[N - 1] = (uint32_t)col[2 * N - 1];
     return o;
   }
+  template <class G, class PTR>
+  PCD_HD static F mul(const uint32_t* w, PTR regs, uint64_t bank) {
+    uint64_t col[2 * N];
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) col[i] = 0;
+    const F a = ld(regs, reg_of_g<G>(w[1] & 0xFFFFu, bank)), b = ld(regs, reg_of_g<G>(w[1] >> 16, bank));
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+      for (int j = 0; j < N; j++) col[i + j] += (uint64_t)a.v[i] * b.v[j];
+    return reduce_columns(col);
+  }
+  template <class G, class PTR>
+  PCD_HD static F sqr(const uint32_t* w, PTR regs, uint64_t bank) {
+    uint64_t col[2 * N];
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) col[i] = 0;
+    const F a = ld(regs, reg_of_g<G>(w[1] & 0xFFFFu, bank));
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      col[2 * i] += (uint64_t)a.v[i] * a.v[i];
+      const uint32_t a2 = a.v[i] << 1;
+#pragma unroll
+      for (int j = i + 1; j < N; j++) col[i + j] += (uint64_t)a2 * a.v[j];
+    }
+    return reduce_columns(col);
+  }
 
-  // dst = sum c_t a_t mod p, |c_t| small (sum of |c_t| <= 124), operands and result in [0, 2p).  Negative terms are covered by adding
-  // K p, K = 2 sum |negative c_t| (every operand is below 2p): Fp::from_signed_sum.
-  template <class PTR>
-  PCD_HD static F lin(const uint32_t* w, PTR regs, uint32_t bank) {
+  // dst = sum c_t a_t mod p (up to 16 terms, sum of |c_t| <= VM_LIN_WEIGHT), operands and result in [0, 2p).  Negative terms are covered
+  // by adding K p, K = 2 sum |negative c_t| (every operand is below 2p): Fp::from_signed_sum.  Terms 8 .. 15 sit in the continuation slot w2.
+  template <class G, class PTR>
+  PCD_HD static F lin(const uint32_t* w, const uint32_t* w2, PTR regs, uint64_t bank) {
     const int T = (int)((w[0] >> 8) & 0xFFu);
     int64_t s[N];
 #pragma unroll
@@ -103,9 +120,11 @@ struct VmArith {
 #pragma unroll
     for (int t = 0; t < vmgen::VM_LIN_TERMS; t++) {
       if (t < T) {
-        const uint32_t op = (w[1 + t / 2] >> (16 * (t & 1))) & 0xFFFFu;
-        const int64_t c = (int64_t)(int16_t)((w[5 + t / 2] >> (16 * (t & 1))) & 0xFFFFu);
-        const F a = ld(regs, reg_of(op, bank));
+        const uint32_t* ww = t < 8 ? w : w2;
+        const int tt = t & 7;
+        const uint32_t op = (ww[1 + tt / 2] >> (16 * (tt & 1))) & 0xFFFFu;
+        const int64_t c = (int64_t)(int16_t)((ww[5 + tt / 2] >> (16 * (tt & 1))) & 0xFFFFu);
+        const F a = ld(regs, reg_of_g<G>(op, bank));
         if (c < 0) K -= 2 * c;
 #pragma unroll
         for (int i = 0; i < N; i++) s[i] += c * (int64_t)a.v[i];
@@ -122,20 +141,22 @@ struct VmWave {
   typedef VmArith<F> A;
   typedef __attribute__((address_space(3))) uint32_t* Lds;
   Lds regs;
-  Lds code, steps, progs;  // the program tables, copied into LDS once: an instruction fetch is a ~100-cycle LDS read, not a dependent
-                           // trip to L2 in front of every one of the thousands of steps of a pairing
-  uint32_t bank;
+  Lds code, steps, progs, script;  // this kernel's tables, copied into LDS once: an instruction fetch is a ~100-cycle LDS read, not a
+                                   // dependent trip to L2 in front of every one of the thousands of steps of a pairing
+  uint64_t bank;                   // low half: the bank of every state slot; high half: the table selector
+  uint32_t script_len;
 
   // LDS words: the register file, then the tables
   static constexpr uint32_t REG_WORDS = (uint32_t)G::NREGS * A::STRIDE;
-  __host__ __device__ static uint32_t lds_words(const VmTables& t) { return REG_WORDS + t.ncode + 3 * t.nsteps + 3 * t.nprogs; }
+  __host__ __device__ static uint32_t lds_words(const VmTables& t) { return REG_WORDS + t.ncode + 3 * t.nsteps + 3 * t.nprogs + (t.script_len + 3) / 4; }
 
   PCD_DEV void init(Lds r, const VmTables& t) {
-    regs = r; bank = 0;
-    code = r + REG_WORDS; steps = code + t.ncode; progs = steps + 3 * t.nsteps;
+    regs = r; bank = 0; script_len = t.script_len;
+    code = r + REG_WORDS; steps = code + t.ncode; progs = steps + 3 * t.nsteps; script = progs + 3 * t.nprogs;
     for (uint32_t i = threadIdx.x; i < t.ncode; i += 64) code[i] = t.code[i];
     for (uint32_t i = threadIdx.x; i < 3 * t.nsteps; i += 64) steps[i] = t.steps[i];
     for (uint32_t i = threadIdx.x; i < 3 * t.nprogs; i += 64) progs[i] = t.progs[i];
+    for (uint32_t i = threadIdx.x; i < (t.script_len + 3) / 4; i += 64) script[i] = t.script[i];
     for (uint32_t c = threadIdx.x; c < (uint32_t)G::NCONST; c += 64) {
       F v;
 #pragma unroll
@@ -143,27 +164,46 @@ struct VmWave {
       A::st(regs, G::CONST_BASE + c, v);
     }
   }
-  PCD_DEV F get_state(int slot) const { return A::ld(regs, A::reg_of((1u << 14) | (uint32_t)slot, bank)); }
-  PCD_DEV void set_state(int slot, const F& v) { A::st(regs, A::reg_of((1u << 14) | (uint32_t)slot, bank), v); }
+  PCD_DEV F get_state(int slot) const { return A::ld(regs, A::template reg_of_g<G>((1u << 14) | (uint32_t)slot, bank)); }
+  PCD_DEV void set_state(int slot, const F& v) { A::st(regs, A::template reg_of_g<G>((1u << 14) | (uint32_t)slot, bank), v); }
   PCD_DEV F get_reg(int r) const { return A::ld(regs, (uint32_t)r); }
   PCD_DEV void set_reg(int r, const F& v) { A::st(regs, (uint32_t)r, v); }
 
-  // one program: steps in order, a barrier (one wave: a fence) after each; lanes beyond a step's instruction count idle
+  // one program: steps in order, a barrier (one wave: a fence) after each; lanes beyond a step's slot count, and the lanes of
+  // continuation slots, idle
   __device__ __noinline__ void run(int pid) {
     const uint32_t first = progs[3 * pid], cnt = progs[3 * pid + 1];
     const uint32_t lane = threadIdx.x;
     for (uint32_t s = first; s < first + cnt; s++) {
       const uint32_t kind = steps[3 * s], off = steps[3 * s + 1], n = steps[3 * s + 2];
       if (lane < n) {
-        uint32_t w[12];
+        uint32_t w[12], w2[12];
 #pragma unroll
         for (int i = 0; i < 12; i++) w[i] = code[(off + lane) * 12 + i];
-        const F o = kind ? A::mul(w, regs, bank) : A::lin(w, regs, bank);
-        A::st(regs, A::reg_of(w[0] >> 16, bank), o);   // (every lane has read its operands before any lane stores: lockstep)
+        if ((w[0] & 0xFFu) != 0xFFu) {
+          F o;
+          if (kind == 1) o = A::template mul<G>(w, regs, bank);
+          else if (kind == 2) o = A::template sqr<G>(w, regs, bank);
+          else {
+            const bool wide = ((w[0] >> 8) & 0xFFu) > 8;
+#pragma unroll
+            for (int i = 0; i < 12; i++) w2[i] = wide ? code[(off + lane + 1) * 12 + i] : 0u;
+            o = A::template lin<G>(w, w2, regs, bank);
+          }
+          A::st(regs, A::template reg_of_g<G>(w[0] >> 16, bank), o);   // (every lane has read its operands before any lane stores: lockstep)
+        }
       }
       __syncthreads();
     }
-    bank ^= progs[3 * pid + 2];
+    bank ^= (uint64_t)progs[3 * pid + 2];
+  }
+  // the kernel's script: program ids in order; entries from 0xF0 up select a table entry for the programs that follow
+  PCD_DEV void run_script() {
+    for (uint32_t i = 0; i < script_len; i++) {
+      const uint32_t e = (script[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+      if (e >= 0xF0u) bank = (bank & 0xFFFFFFFFull) | ((uint64_t)(e - 0xF0u) << 32);
+      else run((int)e);
+    }
   }
 };
 #endif

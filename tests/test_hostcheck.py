@@ -118,14 +118,14 @@ def test_vm_pairing(hc, golden, co, cid):
     g = golden("pairing")
     p, q = np.ascontiguousarray(g[f"c{cid}_p"]), np.ascontiguousarray(g[f"c{cid}_q"])
     out = np.zeros_like(g[f"c{cid}_gt"])
-    assert hc.hc_vm_pairing(cid, P(p), P(q), 1, P(out)) == 0
+    assert hc.hc_vm_pairing(cid, P(p), None, P(q), 1, P(out)) == 0
     assert np.array_equal(out, g[f"c{cid}_gt"])
     fr = co.CURVE_FR[cid]
     k = co.gen_scalars(fr, 3, seed=91 + cid)
     g1, g2 = co.generator(cid, 1), co.generator(cid, 2)
     ps = np.stack([co.to_affine(cid, 1, co.scalar_mul(cid, 1, g1, k[i]))[0][0] for i in range(3)])
     qs = np.stack([co.to_affine(cid, 2, co.scalar_mul(cid, 2, g2, k[(i + 1) % 3]))[0][0] for i in range(3)])
-    assert hc.hc_vm_pairing(cid, P(ps), P(qs), 3, P(out)) == 0
+    assert hc.hc_vm_pairing(cid, P(ps), None, P(qs), 3, P(out)) == 0
     want = np.zeros_like(out)
     assert hc.hc_pairing(cid, P(ps[0]), P(qs[0]), P(want)) == 0          # (the lane-per-pairing templates: golden-checked above)
     assert np.array_equal(co.pairing(cid, ps[0], qs[0]), want)
@@ -133,11 +133,45 @@ def test_vm_pairing(hc, golden, co, cid):
     # is symmetric under swapping the roles of the scalars
     ps2 = np.stack([ps[1], ps[2], ps[0]]); qs2 = np.stack([qs[2], qs[0], qs[1]])
     out2 = np.zeros_like(out)
-    assert hc.hc_vm_pairing(cid, P(ps2), P(qs2), 3, P(out2)) == 0
+    assert hc.hc_vm_pairing(cid, P(ps2), None, P(qs2), 3, P(out2)) == 0
     assert np.array_equal(out, out2) and out.any()
-    assert hc.hc_vm_pairing(cid, P(ps), P(qs), 0, P(out2)) == 0           # the empty product: one
+    assert hc.hc_vm_pairing(cid, P(ps), None, P(qs), 0, P(out2)) == 0     # the empty product: one
     one = out2.reshape(-1, co.FIELD_N64[co.CURVE_FQ[cid]])
     assert one[1:].any() == False and one[0].any()  # noqa: E712
+    # Jacobian G1 points (X, Y | Z) = (x z^2, y z^3 | z): the same pairing without any inversion for P
+    fq = co.CURVE_FQ[cid]
+    L = co.FIELD_N64[fq]
+    z = co.gen_field(fq, 3, seed=17 + cid)
+    z2 = co.fp_op(fq, "mul", z, z)
+    xs = co.fp_op(fq, "mul", np.ascontiguousarray(ps[:, :L]), z2)
+    ys = co.fp_op(fq, "mul", np.ascontiguousarray(ps[:, L:]), co.fp_op(fq, "mul", z2, z))
+    pj = np.ascontiguousarray(np.concatenate([xs, ys], axis=1))
+    assert hc.hc_vm_pairing(cid, P(pj), P(np.ascontiguousarray(z)), P(qs), 3, P(out2)) == 0
+    assert np.array_equal(out, out2)
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+def test_signed_sum_reduction(hc, fid):
+    """Fp::from_signed_sum (the LIN instruction of the pairing VM, the small-coefficient entries of the mat-vec): sums of up to 16
+    terms with coefficient weight up to 2000 -- all positive, all negative, alternating, on operands 0, 1, p - 1 and random ones --
+    against Python integers"""
+    from oracle import pyoracle as O
+    f = O.FIELDS[fid]
+    rnd = random.Random(40 + fid)
+    cases = []
+    for T in (1, 2, 8, 16):
+        for mode in ("pos", "neg", "alt", "rand"):
+            for vals in ("max", "rand", "small"):
+                a = [f.p - 1 if vals == "max" else rnd.randrange(f.p) if vals == "rand" else rnd.randrange(3) for _ in range(T)]
+                w = 2000 // T
+                c = [w if mode == "pos" else -w if mode == "neg" else (w if i % 2 else -w) if mode == "alt" else rnd.randrange(-w, w + 1) for i in range(T)]
+                cases.append((a, c))
+    for a, c in cases:
+        A = O.pack_fp(f, a)
+        cc = np.array(c, dtype=np.int32)
+        out = np.zeros(f.n64, dtype=np.uint64)
+        assert hc.hc_signed_sum(fid, P(A), P(cc), len(a), P(out)) == 0
+        assert O.unpack_fp(f, out.reshape(1, -1))[0] == sum(x * y for x, y in zip(a, c)) % f.p, (a, c)
 
 
 @pytest.mark.parametrize("cid", [0, 1])

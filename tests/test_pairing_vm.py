@@ -66,16 +66,22 @@ def test_bounds_the_interpreter_relies_on(gen, envs):
         nregs = 2 * len(env.slots) + len(env.const_values) + len(env.regs) + env.ntemp
         assert len(env.slots) <= 32 and nregs < (1 << 14)
         stride = (env.N + 3) // 4 * 4
-        assert nregs * stride * 4 <= 64 * 1024          # LDS of one workgroup
+        for setname, names in env.sets.items():            # what one kernel stages in LDS: registers + its own programs + script
+            slots = steps = 0
+            for n in names:
+                for kind, instrs in env.compiled[n]["steps"]:
+                    steps += 1
+                    slots += sum(2 if (kind == gen.K_LIN and len(t) > 8) else 1 for _, t, _ in instrs)
+            assert nregs * stride * 4 + slots * 48 + steps * 12 + len(names) * 12 + len(env.scripts[setname]) <= 64 * 1024, (env.name, setname)
+            assert all(isinstance(e, tuple) or e in names for e in env.scripts[setname])
         for name, c in env.compiled.items():
             for kind, instrs in c["steps"]:
-                assert 1 <= len(instrs) <= 64
+                assert 1 <= sum(2 if (kind == gen.K_LIN and len(t) > 8) else 1 for _, t, _ in instrs) <= 64
                 for dst, terms, k in instrs:
                     assert k == kind
-                    if kind == gen.K_MUL:
-                        assert 1 <= len(terms) <= gen.TMAX
-                    else:
+                    if kind == gen.K_LIN:
                         assert 1 <= len(terms) <= gen.LIN_TERMS and sum(abs(cf) for cf, _ in terms) <= gen.LIN_WEIGHT
-        # MUL closes on [0, 2p) without a final subtraction only while TMAX * 4 p^2 / R' + p < 2p
-        Rp = 1 << (28 * env.N)
-        assert gen.TMAX * 4 * env.p < Rp or gen.TMAX > 2
+                    else:
+                        assert len(terms) == 1 and (kind == gen.K_MUL or terms[0][0] == terms[0][1])
+        # a product closes on [0, 2p) without a final subtraction while 4 p^2 / R' + p < 2p; a LIN reduces values below 2^12 p
+        assert 4 * env.p < (1 << (28 * env.N)) and gen.TMAX == 1 and 2 * gen.LIN_WEIGHT < (1 << 12)

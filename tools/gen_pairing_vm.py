@@ -25,13 +25,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B28 = 28
-TMAX = 2          # products per MUL instruction
-LIN_TERMS = 8     # terms per LIN instruction
-LIN_WEIGHT = 124  # sum of |coefficients| a LIN may carry (inputs below 2p: the device reduces values below 2^8 p)
+TMAX = 1          # products per MUL instruction (1: every product on a lane of its own; a step then costs 2 N^2 multiply-adds, not 3 N^2)
+LIN_TERMS = 16    # terms per LIN instruction (more than 8: the instruction takes a second, continuation slot)
+LIN_WEIGHT = 2000  # sum of |coefficients| a LIN may carry (inputs below 2p: Fp::from_signed_sum reduces values below 2^12 p)
 LANES = 64
 
-K_LIN, K_MUL = 0, 1
-SP_REG, SP_IN, SP_OUT = 0, 1, 2   # operand spaces: plain register, state slot (current bank), state slot (other bank)
+K_LIN, K_MUL, K_SQR = 0, 1, 2   # (K_SQR: a MUL step whose instructions are all squares: N (N + 1) / 2 + N^2 multiply-adds)
+SP_REG, SP_IN, SP_OUT, SP_TAB = 0, 1, 2, 3   # operand spaces: plain register, state slot (current / other bank), entry `sel` of a table
+SET_SEL = 0xF0   # script entries >= SET_SEL are not programs: they set the table selector to (entry - SET_SEL)
 
 
 def params():
@@ -64,6 +65,10 @@ class Prog:
 
     def const(self, value):
         return self.leaf(SP_REG, self.env.const(value))
+
+    def tab(self, table, off):
+        """coefficient `off` of the entry the script selected in `table` (0: powers of nrm, 1: powers of the w0 base)"""
+        return self.leaf(SP_TAB, (table, off))
 
     def mul(self, terms):
         terms = [(a, b) for a, b in terms if a is not None and b is not None]
@@ -222,6 +227,7 @@ class Env:
         w = pow(self.nr, (self.p - 1) // self.k, self.p)
         self.frob_w = [pow(w, i, self.p) for i in range(self.k)]
         self.slots, self.regs, self.consts = {}, {}, {}
+        self.scripts = {}
         self.const_values = []   # plain registers 0 .. : constants first, then named registers
         self.progs = {}
 
@@ -280,27 +286,36 @@ def build(cid):
     # ---------------- Miller loop (one wave per pair) ----------------
     # plain registers: px0, py0 (G1 point), qx*, qy* (G2 point, even positions), derived once by `setup`:
     #   qyo* = qy / twist, l1c* = px - qx / twist, qy2* = qy^2      (twist = u = v^2;  1 / u = u^(d-1) / nr)
+    # The G1 point arrives in JACOBIAN form (px, py, pz): x = px / pz^2, y = py / pz^3 (pz = 1 for an affine point).  Every line is
+    # evaluated times pz^3 -- an element of Fq*, which the final exponentiation kills -- so no inversion is ever needed for P:
+    #   doubling line  (c_l - 4c) pz^3 - c_j (px pz) u,   c_h py u          addition line  oz py u,  -(qyo pz^3 oz + (px pz - qxo pz^3) l1)
     P = env.prog("setup")
-    px, py = P.reg("px0"), P.reg("py0")
+    px, py, pz = P.reg("px0"), P.reg("py0"), P.reg("pz0")
     qx, qy = env.rg(P, "qx", EV), env.rg(P, "qy", EV)
     inv_nr = pow(nr, -1, env.p)
+    pz2 = P.mul([(pz, pz)])
+    pz3 = P.mul([(pz2, pz)])
+    pxz = P.mul([(px, pz)])
     # x / u = x * v^(k-2) / nr
     def over_twist(x):
         sh = x.shift(k - 2)
         return X(P, [None if a is None else P.mul([(a, P.const(inv_nr))]) for a in sh.c])
     qxo, qyo = over_twist(qx), over_twist(qy)
-    l1c = X(P, [px] + [None] * (k - 1)) - qxo
-    env.put_reg(P, "qyo", qyo, EV)
+    scale = lambda x, f: X(P, [None if a is None else P.mul([(a, f)]) for a in x.c])
+    l1c = X(P, [pxz] + [None] * (k - 1)) - scale(qxo, pz3)
+    env.put_reg(P, "qyo", scale(qyo, pz3), EV)
     env.put_reg(P, "l1c", l1c, EV)
     env.put_reg(P, "qy2", qy.sqr(), EV)
+    P.out_reg("pxz0", pxz)
+    P.out_reg("pz30", pz3)
     # state: r = (x, y, z, t) <- (qx, qy, 1, 1), f <- 1
     env.put(P, "rx", qx, EV); env.put(P, "ry", qy, EV)
     env.put(P, "rz", one(P), EV); env.put(P, "rt", one(P), EV)
     env.put(P, "f", one(P), ALL)
 
     def line_regs(P):
-        pxt = X(P, [None, None, P.reg("px0")] + [None] * (k - 3))   # px * twist
-        pyt = X(P, [None, None, P.reg("py0")] + [None] * (k - 3))
+        pxt = X(P, [None, None, P.reg("pxz0")] + [None] * (k - 3))   # px pz * twist
+        pyt = X(P, [None, None, P.reg("py0")] + [None] * (k - 3))    # py * twist
         return pxt, pyt
 
     P = env.prog("dbl")
@@ -319,7 +334,9 @@ def build(cid):
     c_h = (oz + t).sqr() - ot - a
     c_j = (fq + t).sqr() - g - a
     c_l = (fq + x).sqr() - g - b
-    g_rr = (c_l - c.times(4) - c_j * pxt) + (c_h * pyt).shift(1)
+    pz3 = P.reg("pz30")
+    c_l4 = c_l - c.times(4)
+    g_rr = (X(P, [None if a_ is None else P.mul([(a_, pz3)]) for a_ in c_l4.c]) - c_j * pxt) + (c_h * pyt).shift(1)
     fn = f.sqr() * g_rr
     for n, v in (("rx", ox), ("ry", oy), ("rz", oz), ("rt", ot)):
         env.put(P, n, v, EV)
@@ -361,6 +378,11 @@ def build(cid):
 
     # ---------------- final exponentiation (one wave per product of Miller values) ----------------
     # state: acc (the product, then powers), plain registers: g (the next factor), v, vi, fst, fsti, nrm (Fq), ninv (Fq)
+    for j in range(1, 1 << WIN_FQ, 2):      # the two tables the scripts select from: consecutive registers, entry (j - 1) / 2 = power j
+        env.reg(f"ft{j}_0")
+    for j in range(1, 1 << WIN_POW, 2):
+        for c_ in range(k):
+            env.reg(f"pb{j}_{c_}")
     P = env.prog("fe_mul")      # acc *= g
     env.put(P, "acc", env.st(P, "acc", ALL) * env.rg(P, "g", ALL), ALL)
 
@@ -386,12 +408,22 @@ def build(cid):
         P.out_reg(f"cof{2 * j}", cof[j])                # inverse of n_e = cof / nrm
     env.put_reg(P, "v", v, ALL)
 
-    P = env.prog("fq_sqr")      # Fermat inversion of nrm: pw <- pw^2, pw <- pw * nrm
+    # Fermat inversion of nrm by a sliding window over p - 2: odd powers nrm^1, nrm^3, .. in the registers ft<j>_0 (a table the
+    # script selects from: operand space SP_TAB), then pw <- pw^2 and pw <- pw * table[sel] as the schedule (env.scripts) says
+    P = env.prog("fq_tab")
+    x1 = P.reg("nrm0")
+    P.out_reg("ft1_0", x1)
+    x2 = P.mul([(x1, x1)])
+    cur = x1
+    for j in range(3, 1 << WIN_FQ, 2):
+        cur = P.mul([(cur, x2)])
+        P.out_reg(f"ft{j}_0", cur)
+    P = env.prog("fq_sqr")
     P.out("pw0", P.mul([(P.state("pw0"), P.state("pw0"))]))
     P = env.prog("fq_mul")
-    P.out("pw0", P.mul([(P.state("pw0"), P.reg("nrm0"))]))
+    P.out("pw0", P.mul([(P.state("pw0"), P.tab(0, 0))]))
     P = env.prog("fq_init")
-    P.out("pw0", P.reg("nrm0"))
+    P.out("pw0", P.tab(0, 0))
 
     P = env.prog("fe_easy")     # vi = conj_v(v) * (cof * ninv); first = v^(q^(k/2)) * vi ...
     v = env.rg(P, "v", ALL)
@@ -407,20 +439,72 @@ def build(cid):
         aa, ai = v.frob(3) * vi, vi.frob(3) * v
         first, first_inv = aa.frob(1) * aa, ai.frob(1) * ai
     base = first_inv if env.w0_neg else first
-    env.put_reg(P, "pb", base, ALL)                     # the base of the w0 power
+    env.put_reg(P, "pb1_", base, ALL)                   # the base of the w0 power
     env.put_reg(P, "ff", first.frob(1), ALL)            # first^q
-    env.put(P, "acc", base, ALL)                        # the power accumulator starts at the base (top bit of w0)
 
+    P = env.prog("pow_tab")     # odd powers of the base for the sliding window over w0 (table 1)
+    b1 = env.rg(P, "pb1_", ALL)
+    b2 = b1.sqr()
+    cur = b1
+    for j in range(3, 1 << WIN_POW, 2):
+        cur = cur * b2
+        env.put_reg(P, f"pb{j}_", cur, ALL)
     P = env.prog("pow_sqr")
     env.put(P, "acc", env.st(P, "acc", ALL).sqr(), ALL)
+    sel = lambda P: X(P, [P.tab(1, j) for j in range(k)])
     P = env.prog("pow_mul")
-    env.put(P, "acc", env.st(P, "acc", ALL) * env.rg(P, "pb", ALL), ALL)
+    env.put(P, "acc", env.st(P, "acc", ALL) * sel(P), ALL)
+    P = env.prog("pow_init")
+    env.put(P, "acc", sel(P), ALL)
     P = env.prog("fe_last")     # result = first^q * pow;  conjugated when the Miller values were left un-inverted (loop count < 0)
     res = env.rg(P, "ff", ALL) * env.st(P, "acc", ALL)
     if env.ate_neg:
         res = res.conj()
     env.put(P, "acc", res, ALL)
+
+    # ---------------- scripts: the order in which the kernels run the programs (everything data-dependent in a pairing is constant)
+    bits = bin(env.ate_loop)[3:]
+    mil = ["setup"]
+    for bch in bits:
+        mil.append("dbl")
+        if bch == "1":
+            mil.append("add")
+    if env.ate_neg:
+        mil.append("negfix")
+    env.scripts["miller"] = mil
+    env.scripts["final_exp"] = (["fe_norm", "fq_tab"] + window_schedule(env.p - 2, WIN_FQ, "fq_init", "fq_sqr", "fq_mul") + ["fe_easy", "pow_tab"]
+                                + window_schedule(env.w0, WIN_POW, "pow_init", "pow_sqr", "pow_mul") + ["fe_last"])
+    # which kernel needs which programs (each kernel stages only its own in LDS)
+    env.sets = {"miller": ["setup", "dbl", "add", "negfix"],
+                "final_exp": ["fe_mul"] + [n for n in env.progs if n.startswith(("fe_n", "fq_", "fe_e", "pow_", "fe_l"))]}
+    # the table registers are consecutive: entry (j - 1) / 2 of table 0 is ft<j>_0, of table 1 is pb<j>_0 .. pb<j>_(k-1)
     return env
+
+
+WIN_FQ, WIN_POW = 4, 3
+
+
+def window_schedule(e, WIN, init, sqr, mul):
+    """left-to-right sliding window (odd digits below 2^WIN) for x^e: program names; ("sel", i) selects table entry i = (digit - 1) / 2
+    for the `init` / `mul` that follows"""
+    bits = bin(e)[2:]
+    out, i, first = [], 0, True
+    while i < len(bits):
+        if bits[i] == "0":
+            out.append(sqr)
+            i += 1
+            continue
+        j = min(i + WIN, len(bits))
+        while bits[j - 1] == "0":
+            j -= 1
+        val = int(bits[i:j], 2)
+        if first:
+            out += [("sel", (val - 1) // 2), init]
+            first = False
+        else:
+            out += [sqr] * (j - i) + [("sel", (val - 1) // 2), mul]
+        i = j
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ scheduling / allocation
@@ -526,15 +610,24 @@ def compile_prog(env, P, nconst_regs):
                 loc[n] = (SP_REG, ("t", r))
                 expiring.setdefault(last_use.get(n, s), []).append(n)
             if kind == "mul":
-                instrs.append((loc[n], [(loc[a], loc[b]) for a, b in pay], K_MUL))
+                instrs.append((loc[n], [(loc[a], loc[b]) for a, b in pay], K_MUL if any(a != b for a, b in pay) else K_SQR))
             else:
                 instrs.append((loc[n], [(c, loc[a]) for c, a in pay], K_LIN))
         if not instrs:
             continue
-        kind = instrs[0][2]
-        assert all(i[2] == kind for i in instrs)
-        for q in range(0, len(instrs), LANES):
-            steps.append((kind, instrs[q:q + LANES]))
+        kinds = {i[2] for i in instrs}
+        kind = K_LIN if kinds == {K_LIN} else K_SQR if kinds == {K_SQR} else K_MUL   # (a squaring among products runs as a product)
+        assert K_LIN not in kinds or kinds == {K_LIN}
+        instrs = [(d, t, kind) for d, t, _ in instrs]
+        chunk, used = [], 0
+        for ins in instrs:   # a LIN of more than 8 terms occupies two instruction slots (= lanes)
+            need = 2 if (kind == K_LIN and len(ins[1]) > 8) else 1
+            if used + need > LANES:
+                steps.append((kind, chunk))
+                chunk, used = [], 0
+            chunk.append(ins)
+            used += need
+        steps.append((kind, chunk))
     written = sorted({d[1] for d, _, _ in sum((i for _, i in steps), []) if d[0] == SP_OUT})
     return dict(steps=steps, written=written, ntemp=ntemp)
 
@@ -553,6 +646,8 @@ def reg_index(env, op):
     space, idx = op
     if space in (SP_IN, SP_OUT):
         return space, idx
+    if space == SP_TAB:
+        return space, (idx[0] << 8) | idx[1]
     tag, i = idx
     base = 2 * len(env.slots)
     if tag == "c":
@@ -575,11 +670,19 @@ class Machine:
         for i, v in enumerate(env.const_values):
             self.r[base + i] = v
         self.steps_run = 0
+        self.sel = 0
+
+    def tab_base(self, table):
+        name, stride = (("ft1_0", 1), ("pb1_0", self.env.k))[table]
+        return self.addr((SP_REG, ("r", self.env.regs[name]))), stride
 
     def addr(self, op, writing=False):
         space, idx = reg_index(self.env, op)
         if space == SP_REG:
             return idx
+        if space == SP_TAB:
+            base, stride = self.tab_base(idx >> 8)
+            return base + self.sel * stride + (idx & 0xFF)
         cur = (self.bank >> idx) & 1
         return 2 * idx + (cur ^ (1 if space == SP_OUT else 0))
 
@@ -595,13 +698,21 @@ class Machine:
     def get_state(self, name):
         return self.r[self.addr((SP_IN, self.env.slots[name]))]
 
+    def run_script(self, name):
+        for e in self.env.scripts[name]:
+            if isinstance(e, tuple):
+                self.sel = e[1]
+            else:
+                self.run(e)
+
     def run(self, name):
         p = self.env.p
         c = self.env.compiled[name]
         for kind, instrs in c["steps"]:
             vals = []
             for dst, terms, _ in instrs:       # every lane reads ...
-                if kind == K_MUL:
+                if kind != K_LIN:
+                    assert kind == K_MUL or all(a == b for a, b in terms)
                     vals.append(sum(self.r[self.addr(a)] * self.r[self.addr(b)] for a, b in terms) % p)
                 else:
                     vals.append(sum(cf * self.r[self.addr(a)] for cf, a in terms) % p)
@@ -615,17 +726,10 @@ class Machine:
 def eval_miller(env, P1, Q2):
     """P1 = (x, y) in Fq, Q2 = (x coefficients, y coefficients) over u -> the k flat coefficients of the (un-inverted) Miller value"""
     M = Machine(env)
-    M.set_reg("px0", P1[0]); M.set_reg("py0", P1[1])
+    M.set_reg("px0", P1[0]); M.set_reg("py0", P1[1]); M.set_reg("pz0", P1[2] if len(P1) > 2 else 1)
     for j in range(env.k // 2):
         M.set_reg(f"qx{2 * j}", Q2[0][j]); M.set_reg(f"qy{2 * j}", Q2[1][j])
-    M.run("setup")
-    bits = bin(env.ate_loop)[3:]
-    for b in bits:
-        M.run("dbl")
-        if b == "1":
-            M.run("add")
-    if env.ate_neg:
-        M.run("negfix")
+    M.run_script("miller")
     return [M.get_state(f"f{j}") for j in range(env.k)], M.steps_run
 
 
@@ -638,19 +742,7 @@ def eval_final_exp(env, fs):
         for j in range(env.k):
             M.set_reg(f"g{j}", g[j])
         M.run("fe_mul")
-    M.run("fe_norm")
-    M.run("fq_init")
-    e = env.p - 2
-    for b in bin(e)[3:]:
-        M.run("fq_sqr")
-        if b == "1":
-            M.run("fq_mul")
-    M.run("fe_easy")
-    for b in bin(env.w0)[3:]:
-        M.run("pow_sqr")
-        if b == "1":
-            M.run("pow_mul")
-    M.run("fe_last")
+    M.run_script("final_exp")
     return [M.get_state(f"acc{j}") for j in range(env.k)], M.steps_run
 
 
@@ -668,58 +760,85 @@ def enc_operand(env, op):
 def emit(envs):
     L = ["// GENERATED by tools/gen_pairing_vm.py -- do not edit.  Programs of the wave-wide field VM (pairing_vm.hip.h).",
          "#pragma once", "#include <stdint.h>", "", "namespace pcd { namespace vmgen {", "",
-         f"constexpr int VM_TMAX = {TMAX}, VM_LIN_TERMS = {LIN_TERMS};",
-         "// instruction = 12 words: w0 = kind | terms << 8 | dst << 16;  MUL: w[1 + t] = a_t | b_t << 16;  LIN: w[1 + t / 2] holds operand t in its",
-         "// low / high half, w[5 + t / 2] the signed 16-bit coefficient.  Operand = space << 14 | index (space 0: register, 1: state slot in its",
-         "// current bank, 2: state slot in the other bank).", ""]
+         f"constexpr int VM_TMAX = {TMAX}, VM_LIN_TERMS = {LIN_TERMS}, VM_LIN_WEIGHT = {LIN_WEIGHT};",
+         "// instruction = 12 words: w0 = kind | terms << 8 | dst << 16;  MUL / SQR: w[1 + t] = a_t | b_t << 16;  LIN: w[1 + t / 2] holds operand t in its",
+         "// low / high half, w[5 + t / 2] the signed 16-bit coefficient; a LIN of more than 8 terms continues in the next slot (w0 = 0xFF, whose lane",
+         "// idles).  Operand = space << 14 | index (space 0: register, 1: state slot in its current bank, 2: state slot in the other bank).",
+         "// kind: 0 LIN, 1 MUL, 2 SQR (a step of squarings only).  Scripts: the program ids a kernel runs, in order.", ""]
     for env in envs:
         N = env.N
         Rp = 1 << (B28 * N)
         nm = env.name
-        words, steps, progs = [], [], []
-        for pname, c in env.compiled.items():
-            first = len(steps)
-            for kind, instrs in c["steps"]:
-                steps.append((kind, len(words) // 12, len(instrs)))
-                for dst, terms, _ in instrs:
-                    w = [0] * 12
-                    w[0] = kind | (len(terms) << 8) | (enc_operand(env, dst) << 16)
-                    if kind == K_MUL:
-                        for t, (a, b) in enumerate(terms):
-                            w[1 + t] = enc_operand(env, a) | (enc_operand(env, b) << 16)
-                    else:
-                        for t, (cf, a) in enumerate(terms):
-                            assert -32768 <= cf < 32768
-                            w[1 + t // 2] |= enc_operand(env, a) << (16 * (t % 2))
-                            w[5 + t // 2] |= (cf & 0xFFFF) << (16 * (t % 2))
-                    words += w
-            mask = 0
-            for s in c["written"]:
-                mask |= 1 << s
-            progs.append((pname, first, len(steps) - first, mask))
         assert len(env.slots) <= 32
         nregs = 2 * len(env.slots) + len(env.const_values) + len(env.regs) + env.ntemp
+        named = 2 * len(env.slots) + len(env.const_values)
         L.append(f"// ---- {nm}: {len(env.slots)} state slots, {len(env.const_values)} constants, {len(env.regs)} named registers, {env.ntemp} temporaries")
         L.append(f"struct {nm} {{")
         L.append(f"  static constexpr int NSLOTS = {len(env.slots)}, NCONST = {len(env.const_values)}, NNAMED = {len(env.regs)}, NTEMP = {env.ntemp}, NREGS = {nregs};")
-        L.append(f"  static constexpr int CONST_BASE = {2 * len(env.slots)}, NAMED_BASE = {2 * len(env.slots) + len(env.const_values)};")
-        for pi, (pname, first, cnt, mask) in enumerate(progs):
-            L.append(f"  static constexpr int P_{pname.upper()} = {pi};")
+        L.append(f"  static constexpr int CONST_BASE = {2 * len(env.slots)}, NAMED_BASE = {named};")
+        L.append(f"  // operand space 3: register = TAB_BASE[table] + sel * TAB_STRIDE[table] + offset (the script sets sel)")
+        L.append(f"  static constexpr int TAB0_BASE = {named + env.regs['ft1_0']}, TAB0_STRIDE = 1, TAB1_BASE = {named + env.regs['pb1_0']}, TAB1_STRIDE = {env.k};")
         for sname, si in env.slots.items():
             L.append(f"  static constexpr int S_{sname.upper()} = {si};")
         for rname, ri in env.regs.items():
-            L.append(f"  static constexpr int R_{rname.upper()} = {2 * len(env.slots) + len(env.const_values) + ri};")
+            L.append(f"  static constexpr int R_{rname.upper()} = {named + ri};")
         L.append("};")
-        L.append(f"static const uint32_t {nm}_progs[{len(progs)}][3] = {{  // first step, steps, mask of the state slots written")
-        L.append("  " + ", ".join(f"{{{first}, {cnt}, 0x{mask:08x}u}}" for _, first, cnt, mask in progs) + "};")
-        L.append(f"static const uint32_t {nm}_steps[{len(steps)}][3] = {{  // kind, first instruction, instructions")
-        for q in range(0, len(steps), 8):
-            L.append("  " + ", ".join(f"{{{k_}, {o}, {n_}}}" for k_, o, n_ in steps[q:q + 8]) + ",")
-        L.append("};")
-        L.append(f"static const uint32_t {nm}_code[{len(words)}] = {{")
-        for q in range(0, len(words), 12):
-            L.append("  " + ", ".join(f"0x{w:08x}u" for w in words[q:q + 12]) + ",")
-        L.append("};")
+        for setname, names in env.sets.items():
+            words, steps, progs = [], [], []
+            for pname in names:
+                c = env.compiled[pname]
+                first = len(steps)
+                for kind, instrs in c["steps"]:
+                    first_word = len(words)
+                    for dst, terms, _ in instrs:
+                        w = [0] * 12
+                        w[0] = kind | (len(terms) << 8) | (enc_operand(env, dst) << 16)
+                        if kind != K_LIN:
+                            for t, (a, b) in enumerate(terms):
+                                w[1 + t] = enc_operand(env, a) | (enc_operand(env, b) << 16)
+                            words += w
+                            continue
+                        w2 = [0] * 12
+                        w2[0] = 0xFF   # continuation slot: its lane idles, the lane before it reads terms 8 .. 15 here
+                        for t, (cf, a) in enumerate(terms):
+                            assert -32768 <= cf < 32768
+                            ww, tt = (w, t) if t < 8 else (w2, t - 8)
+                            ww[1 + tt // 2] |= enc_operand(env, a) << (16 * (tt % 2))
+                            ww[5 + tt // 2] |= (cf & 0xFFFF) << (16 * (tt % 2))
+                        words += w
+                        if len(terms) > 8:
+                            words += w2
+                    nslots = (len(words) - first_word) // 12
+                    assert nslots <= LANES
+                    steps.append((kind, first_word // 12, nslots))
+                mask = 0
+                for sl in c["written"]:
+                    mask |= 1 << sl
+                progs.append((pname, first, len(steps) - first, mask))
+            pid = {pname: i for i, (pname, _, _, _) in enumerate(progs)}
+            assert len(progs) < SET_SEL
+            ids = [(SET_SEL + e[1]) if isinstance(e, tuple) else pid[e] for e in env.scripts[setname] if isinstance(e, tuple) or e in pid]
+            assert len(ids) == len(env.scripts[setname])
+            packed = [sum(ids[q + j] << (8 * j) for j in range(4) if q + j < len(ids)) for q in range(0, len(ids), 4)]
+            T = f"{nm}_{setname}"
+            L.append(f"// {T}: " + ", ".join(f"{i} {pname}" for i, (pname, _, _, _) in enumerate(progs)))
+            for i, (pname, _, _, _) in enumerate(progs):
+                L.append(f"static const int {T}_P_{pname.upper()} = {i};")
+            L.append(f"static const uint32_t {T}_script_len = {len(ids)};")
+            L.append(f"static const uint32_t {T}_script[{len(packed)}] = {{  // program ids in running order, four per word; 0xF0 + i: select table entry i")
+            for q in range(0, len(packed), 12):
+                L.append("  " + ", ".join(f"0x{w:08x}u" for w in packed[q:q + 12]) + ",")
+            L.append("};")
+            L.append(f"static const uint32_t {T}_progs[{len(progs)}][3] = {{  // first step, steps, mask of the state slots written")
+            L.append("  " + ", ".join(f"{{{first}, {cnt}, 0x{mask:08x}u}}" for _, first, cnt, mask in progs) + "};")
+            L.append(f"static const uint32_t {T}_steps[{len(steps)}][3] = {{  // kind, first instruction slot, slots")
+            for q in range(0, len(steps), 8):
+                L.append("  " + ", ".join(f"{{{k_}, {o}, {n_}}}" for k_, o, n_ in steps[q:q + 8]) + ",")
+            L.append("};")
+            L.append(f"static const uint32_t {T}_code[{len(words)}] = {{")
+            for q in range(0, len(words), 12):
+                L.append("  " + ", ".join(f"0x{w:08x}u" for w in words[q:q + 12]) + ",")
+            L.append("};")
         L.append(f"static const uint32_t {nm}_consts[{len(env.const_values)}][{N}] = {{  // Montgomery form (R' = 2^{B28 * N}), 28-bit limbs")
         for v in env.const_values:
             L.append("  {" + ", ".join(f"0x{x:07x}u" for x in limbs28(v * Rp % env.p, N)) + "},")
@@ -733,6 +852,10 @@ def main():
     envs = [compile_env(build(c)) for c in range(4)]
     for env in envs:
         # the kernels address these families as base + j
+        for j in range(3, 1 << WIN_FQ, 2):
+            assert env.regs[f"ft{j}_0"] == env.regs["ft1_0"] + (j - 1) // 2
+        for j in range(1, 1 << WIN_POW, 2):
+            assert all(env.regs[f"pb{j}_{c}"] == env.regs["pb1_0"] + (j - 1) // 2 * env.k + c for c in range(env.k))
         for fam, step in (("qx", 2), ("qy", 2), ("g", 1), ("v", 1)):
             assert all(env.regs[f"{fam}{step * j}"] == env.regs[f"{fam}0"] + j for j in range(env.k // step)), fam
         for fam in ("f", "acc"):

@@ -37,6 +37,8 @@ def main():
            "hbm_bytes_per_launch": int(2 * f_kb * 1024 + w_kb * 1024), "algorithmic_bytes_per_launch": (1 << 20) * 120,
            "source_sha16": source_sha16()}
     json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_msm_accumulate.json"), "w"), indent=1)
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):   # (on the GPU box only gpurun_out/ travels back)
+        json.dump(out, open(os.path.join(ROOT, "gpurun_out", "traffic_msm_accumulate.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
