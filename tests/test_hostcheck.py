@@ -14,16 +14,35 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HC = os.path.join(ROOT, "tests", "hostcheck")
 
 
+class _Libs:
+    """symbols of the two harness libraries (compiled side by side) under one object"""
+
+    def __init__(self, libs):
+        self._libs = libs
+
+    def __getattr__(self, name):
+        for lib in self._libs:
+            try:
+                return getattr(lib, name)
+            except AttributeError:
+                pass
+        raise AttributeError(name)
+
+
 @pytest.fixture(scope="module")
 def hc():
-    so = os.path.join(HC, "libhostcheck.so")
-    srcs = [os.path.join(HC, "hostcheck.hip")] + [os.path.join(ROOT, "pcd_amd", "csrc", f) for f in
-                                                  ("fp.hip.h", "ec.hip.h", "pairing.hip.h", "pairing_vm.hip.h", "pairing_vm_gen.h", "params_gen.h",
-                                                   "params28_gen.h")]
-    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared", "-DPCD_LZ_CHECK",
-                               os.path.join(HC, "hostcheck.hip"), "-o", so], stderr=subprocess.DEVNULL)
-    return C.CDLL(so)
+    csrc = os.path.join(ROOT, "pcd_amd", "csrc")
+    hdrs = [os.path.join(csrc, f) for f in ("fp.hip.h", "ec.hip.h", "pairing.hip.h", "pairing_vm.hip.h", "pairing_vm_gen.h", "vm_tables.h",
+                                            "params_gen.h", "params28_gen.h")]
+    jobs = []
+    for stem in ("hostcheck", "hostcheck_pairing"):
+        so, src = os.path.join(HC, f"lib{stem}.so"), os.path.join(HC, f"{stem}.hip")
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in [src] + hdrs):
+            jobs.append(subprocess.Popen(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared", "-DPCD_LZ_CHECK", src, "-o", so],
+                                         stderr=subprocess.DEVNULL))
+    for j in jobs:
+        assert j.wait() == 0
+    return _Libs([C.CDLL(os.path.join(HC, "libhostcheck.so")), C.CDLL(os.path.join(HC, "libhostcheck_pairing.so"))])
 
 
 def P(a):
