@@ -285,8 +285,10 @@ int pcdhip_groth16_verify(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g
 /* ---- `process_vk` and the verifications that use it --------------------------------------------------
  * pcdhip_process_vk replaces ark-groth16 `prepare_verifying_key` (`SNARK::process_vk`, reference call sites
  * src/ec_cycle_pcd/mod.rs:71,371,445,495,553): e(alpha, beta) is computed ONCE and kept, gamma and delta are negated, gamma_abc_g1
- * becomes a resident base vector.  (The G2 line coefficients upstream also precomputes are not stored: the Miller-loop kernel fuses
- * the G2 steps with the line evaluations, one lane per pair, and a coefficient stream would be three times its own state.) */
+ * becomes a resident base vector with one 8-bit window table per point (0.86 / 5.2 MB each at 298 / 753 bits, keys of up to 256 public
+ * inputs; larger keys keep the plain vector): the input accumulation of a verification is then a few dozen table additions per proof
+ * on one workgroup, not a chain of hundreds of doublings.  (The G2 line coefficients upstream also precomputes are not stored: the
+ * Miller-loop kernels fuse the G2 steps with the line evaluations, and a coefficient stream would be three times their state.) */
 typedef struct pcdhip_pvk pcdhip_pvk;
 int pcdhip_process_vk(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, const uint64_t* beta_g2, const uint64_t* gamma_g2,
                       const uint64_t* delta_g2, const uint64_t* gamma_abc_g1, const uint8_t* gamma_abc_inf, size_t num_inputs, pcdhip_pvk** out);

@@ -438,8 +438,11 @@ PCD_DEV uint32_t msm_entry(const MsmEntrySource& src, bool compact, const MsmCur
 // u32 words between consecutive base points in a `pcdhip_bases` array.  The affine image of a 298-bit G1 point is 88 B;
 // PCD_BASE_ALIGN pads the record to 128 B so that the gather of one point touches exactly one 128-B line (it straddles two for
 // most 88-B offsets: 4.4 GB of fetch traffic per 2^20 MSM against 1.4 GB of payload, profiles/r01_pmc_fetch_summary_final.csv).
+// Round 2 measured it on a lone MSM (-0.3 %) and left it off; round 3 measured it where HBM is shared -- the five concurrent MSM
+// streams of a proof: -2.2 % (profiles/r03_ab_base_align_concurrent.txt) -- and with four MSMs in flight: 416 -> 430 Mscalar-mul/s;
+// the padding costs 45 % more key memory for the 298-bit G1 queries (2.0 instead of 1.4 GB per 2^20-point query with its copies).
 #ifndef PCD_BASE_ALIGN
-#define PCD_BASE_ALIGN 0
+#define PCD_BASE_ALIGN 1
 #endif
 template <class G>
 struct MsmBaseStride {

@@ -93,10 +93,10 @@ def test_config4_arity8_branches_then_sharded_merge(co, gpu_ctx):
     assert np.array_equal(got, want) and np.array_equal(inf, winf)
 
 
-@pytest.mark.parametrize("cid,log_n,budget_mb,expect", [(0, 20, 400, 4), (2, 20, 2500, 9)])
+@pytest.mark.parametrize("cid,log_n,budget_mb,expect", [(0, 20, 600, 4), (2, 20, 2500, 9)])
 def test_precompute_fallback_forced(co, gpu_ctx, cid, log_n, budget_mb, expect):
     """pcdhip_set_precompute_budget makes a vector take the fewer-copies path a device short of memory takes: 15 -> 8 -> 4 copies
-    (MNT4-298 G1, 92 MB each) / 36 -> 18 -> 9 (MNT4-753 G1, 226 MB each); windows that share a copy come back as bucket windows +
+    (MNT4-298 G1, 134 MB each: 128-byte records) / 36 -> 18 -> 9 (MNT4-753 G1, 226 MB each); windows that share a copy come back as bucket windows +
     the Horner combine.  Same result, and pcdhip_bases_info reports what the handle holds.  Also through a two-shard context
     (the budget is per vector PER DEVICE) and with an explicit copy count."""
     from pcd_amd import capi

@@ -1,0 +1,26 @@
+"""Developer A/B: the main MNT4-298 proof at 2^20 (five MSMs on five streams + the witness map, all concurrent) -- median wall of 7
+proves and the device stage times; run once per library (PCDHIP_LIB=...) on the same box.  Used for questions that only show under
+concurrency, e.g. whether the 88-byte base records (a gather touches 1.7 lines) cost anything when five MSM streams share HBM."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+torch.zeros(1, device="cuda:0")
+from oracle import coracle as co
+from pcd_amd import capi
+curve = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+nc = (1 << int(sys.argv[2])) - 8 if len(sys.argv) > 2 else (1 << 20) - 8
+ctx = capi.Context(0)
+fr = co.CURVE_FR[curve]
+r = co.skewed_r1cs(fr, nc, 2, seed=77)
+keys = co.synthetic_keys(curve, r, seed=78, mt=True)
+rs = co.gen_field(fr, 2, seed=79)
+pk = ctx.g16_pk_upload(keys.host_struct(), curve)
+ctx.g16_pk_set_r1cs(pk, r)
+r.z = capi.pinned_like(r.z)
+for _ in range(3):
+    ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
+walls = []
+for _ in range(7):
+    t0 = time.perf_counter(); ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True); walls.append((time.perf_counter() - t0) * 1e3)
+print(f"lib={os.environ.get('PCDHIP_LIB', 'in-tree')} curve={curve} prove wall ms median {np.median(walls):.3f} min {min(walls):.3f}; device {ctx.groth16_last_timings()}", flush=True)
