@@ -6,7 +6,8 @@
 // mod.rs:71 (`process_vk`).  Same algorithm as upstream: G2 in extended Jacobian coordinates
 // (X, Y, Z, T = Z^2) stepping through |q - r| with doubling / mixed-addition line coefficients, lines
 // evaluated at the twisted G1 point ("flipped" Miller loop), final exponentiation
-// (q^(k/2) - 1)[(q + 1)] then q + w0.  One lane per (P, Q) pair: the G2 steps are fused with the line
+// (q^(k/2) - 1)[(q + 1)] then q + w0.  One lane per (P, Q) pair (the THROUGHPUT form, used for batches above 4096 pairs; smaller batches
+// run one wave per pairing: pairing_vm.hip.h): the G2 steps are fused with the line
 // evaluations instead of being precomputed; independent pairs fill a wave.
 #pragma once
 #include "ec.hip.h"
