@@ -58,6 +58,37 @@ struct VmArith {
 #pragma unroll
     for (int i = 0; i < N; i++) regs[r * STRIDE + i] = v.v[i];
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the LDS register file: records are 16-byte aligned, so a register moves as STRIDE / 4 ds_read_b128 / ds_write_b128
+  typedef __attribute__((address_space(3))) uint32_t* LdsPtr;
+  typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) V4* LdsV4;
+  PCD_DEV static F ld(LdsPtr regs, uint32_t r) {
+    F v;
+    const LdsV4 p = (LdsV4)(regs + r * STRIDE);
+#pragma unroll
+    for (int k = 0; k < STRIDE / 4; k++) {
+      const V4 w = p[k];
+      v.v[4 * k] = w.x;
+      if (4 * k + 1 < N) v.v[4 * k + 1] = w.y;
+      if (4 * k + 2 < N) v.v[4 * k + 2] = w.z;
+      if (4 * k + 3 < N) v.v[4 * k + 3] = w.w;
+    }
+    return v;
+  }
+  PCD_DEV static void st(LdsPtr regs, uint32_t r, const F& v) {
+    const LdsV4 p = (LdsV4)(regs + r * STRIDE);
+#pragma unroll
+    for (int k = 0; k < STRIDE / 4; k++) {
+      V4 w;
+      w.x = v.v[4 * k];
+      w.y = 4 * k + 1 < N ? v.v[4 * k + 1] : 0u;
+      w.z = 4 * k + 2 < N ? v.v[4 * k + 2] : 0u;
+      w.w = 4 * k + 3 < N ? v.v[4 * k + 3] : 0u;
+      p[k] = w;
+    }
+  }
+#endif
 
   // dst = a b / R', operands and result in [0, 2p): the product's 2N - 1 column sums in 64 bits (N 2^56 < 2^63 with room for the
   // reduction's terms), then one Montgomery reduction over the columns: 4 p^2 / R' + p < 2p (R' > 8p).  SQR: the same for a = b with
