@@ -867,21 +867,16 @@ __global__ void __launch_bounds__(64) msm_tail_level_kernel(const uint32_t* __re
 // are pure latency (a handful of lanes), so the extra doubling is free:
 //   z = 0:  A'_{j-1} = 2 (A_{2j} + A_{2j+1})        z = 1:  L_j = A_{2j} + 2 A_{2j+1} -> C'[JC + j]        z = 2:  C'_j = C_{2j} + C_{2j+1}
 // (items and operations: MsmPairItems / MsmPairOps above)
+// one piece of a pair level: role 0 / 1 / 2 for item j of window w (the lanes of the item call it together)
 template <class G>
-__global__ void __launch_bounds__(64) msm_tail_pair_kernel(const uint32_t* __restrict__ A_in, uint32_t mA, size_t strideA_in,
-                                                           const uint32_t* __restrict__ C_in, uint32_t mC, size_t strideC_in,
-                                                           uint32_t* __restrict__ A_out, size_t strideA_out,
-                                                           uint32_t* __restrict__ C_out, size_t strideC_out) {
+PCD_DEV void msm_tail_pair_item(int role, uint32_t j, uint32_t w, const uint32_t* A_in, uint32_t mA, size_t strideA_in, const uint32_t* C_in,
+                                uint32_t mC, size_t strideC_in, uint32_t* A_out, size_t strideA_out, uint32_t* C_out, size_t strideC_out) {
   typedef MsmPairOps<G> O;
   typedef typename O::GA GA;
   typedef typename GA::F F;
   typedef MsmPairItems<G> IT;
   constexpr int PW = Jac<F>::WORDS;
-  if (IT::idle()) return;
   const uint32_t JA = (mA + 1) >> 1, JC = (mC + 1) >> 1;
-  const uint32_t j = IT::item();
-  const uint32_t w = blockIdx.y;
-  const int role = blockIdx.z;
   if (role < 2) {
     if (j >= JA) return;
     const uint32_t* A = A_in + w * strideA_in * PW;
@@ -902,6 +897,52 @@ __global__ void __launch_bounds__(64) msm_tail_pair_kernel(const uint32_t* __res
     Jac<F> acc = Jac<F>::load(Cw + (size_t)(2 * j) * PW);
     if (2 * j + 1 < mC) acc = O::add(acc, Jac<F>::load(Cw + (size_t)(2 * j + 1) * PW));
     if (IT::writer()) acc.store(C_out + (w * strideC_out + j) * PW);
+  }
+}
+template <class G>
+__global__ void __launch_bounds__(64) msm_tail_pair_kernel(const uint32_t* __restrict__ A_in, uint32_t mA, size_t strideA_in,
+                                                           const uint32_t* __restrict__ C_in, uint32_t mC, size_t strideC_in,
+                                                           uint32_t* __restrict__ A_out, size_t strideA_out,
+                                                           uint32_t* __restrict__ C_out, size_t strideC_out) {
+  typedef MsmPairItems<G> IT;
+  if (IT::idle()) return;
+  msm_tail_pair_item<G>((int)blockIdx.z, IT::item(), blockIdx.y, A_in, mA, strideA_in, C_in, mC, strideC_in, A_out, strideA_out, C_out, strideC_out);
+}
+// The LAST pair levels in one launch: once a level's 2 JA + JC pieces fit the item slots of one workgroup of eight waves, a single
+// workgroup per window runs every remaining level -- the same pieces, the same ping-pong buffers (L2-resident by then), a workgroup
+// barrier where the per-level kernels had a dependent launch (~8 us each, ten of them at c = 20).  Not for the mailbox field variants
+// (their LDS slots are per lane of ONE wave): the 753-bit groups keep a launch per level.
+constexpr uint32_t MSM_FUSED_WAVES = 8;
+template <class G>
+struct MsmFusedTail {
+  static constexpr bool ENABLED = !MsmPairOps<G>::GA::F::Base::MAILBOX;
+  static constexpr uint32_t SLOTS = MSM_FUSED_WAVES * MsmPairItems<G>::PER_WAVE;
+  static bool fits(uint32_t mA, uint32_t mC) { return ENABLED && 2 * ((mA + 1) >> 1) + ((mC + 1) >> 1) <= SLOTS; }
+};
+template <class G>
+__global__ void __launch_bounds__(64 * MSM_FUSED_WAVES) msm_tail_fused_kernel(const uint32_t* A_in, uint32_t mA, size_t strideA_in, const uint32_t* C_in,
+                                                                              uint32_t mC, size_t strideC_in, uint32_t* A0, uint32_t* A1, uint32_t* C0,
+                                                                              uint32_t* C1, size_t strideAC, int flip) {
+  typedef MsmPairItems<G> IT;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const bool idle = lane >= IT::PER_WAVE * IT::LANES;
+  const uint32_t slot = wave * IT::PER_WAVE + lane / IT::LANES;
+  const uint32_t w = blockIdx.x;
+  while (mA > 0 || mC > 1) {
+    const uint32_t JA = (mA + 1) >> 1, JC = (mC + 1) >> 1;
+    uint32_t* A_out = flip ? A1 : A0;
+    uint32_t* C_out = flip ? C1 : C0;
+    if (!idle && slot < 2 * JA + JC) {
+      const int role = slot < JA ? 0 : slot < 2 * JA ? 1 : 2;
+      const uint32_t j = role == 0 ? slot : role == 1 ? slot - JA : slot - 2 * JA;
+      msm_tail_pair_item<G>(role, j, w, A_in, mA, strideA_in, C_in, mC, strideC_in, A_out, strideAC, C_out, strideAC);
+    }
+    __syncthreads();  // (also makes this level's global stores visible to the whole workgroup)
+    mA = JA ? JA - 1 : 0;
+    mC = JC + JA;
+    A_in = A_out; strideA_in = strideAC;
+    C_in = C_out; strideC_in = strideAC;
+    flip ^= 1;
   }
 }
 
@@ -1272,6 +1313,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     size_t strideC_in = 0;
     uint32_t mA = B, mC = 0;
     int flip = 0, level = 0;
+    bool fused = false;
     while (mA > 0 || mC > 1) {
       // blocks of 8 at the first (throughput-bound) level, then pairs: the later levels are pure latency, and per halving
       // of the array a pair level costs 2 additions + 1 doubling against 3.6 / 5.3 addition-equivalents for blocks of 4 / 8
@@ -1282,7 +1324,14 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
       uint32_t* A_out = (uint32_t*)ws.buf[flip ? WS_A1 : WS_A0];
       uint32_t* C_out = (uint32_t*)ws.buf[flip ? WS_C1 : WS_C0];
       uint32_t threads = JA + JC;
-      if (k == 1)
+      if (!fused && level > 0 && MsmFusedTail<G>::fits(mA, mC)) {  // every remaining level in one workgroup per window
+        hipLaunchKernelGGL((msm_tail_fused_kernel<G>), dim3(Wg), dim3(64 * MSM_FUSED_WAVES), 0, st, A_in, mA, strideA_in, C_in, mC, strideC_in,
+                           (uint32_t*)ws.buf[WS_A0], (uint32_t*)ws.buf[WS_A1], (uint32_t*)ws.buf[WS_C0], (uint32_t*)ws.buf[WS_C1], strideAC, flip);
+        fused = true;
+      }
+      if (fused) {
+        // (the host only follows the level sequence to know where the result ends up)
+      } else if (k == 1)
         hipLaunchKernelGGL((msm_tail_pair_kernel<G>), dim3(MsmPairItems<G>::grid(std::max(JA, JC)), Wg, 3), dim3(64), 0, st, A_in, mA, strideA_in, C_in,
                            mC, strideC_in, A_out, strideAC, C_out, strideAC);
       else if (threads <= (1u << 15))
