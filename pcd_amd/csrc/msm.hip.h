@@ -908,16 +908,19 @@ __global__ void __launch_bounds__(64) msm_tail_pair_kernel(const uint32_t* __res
   if (IT::idle()) return;
   msm_tail_pair_item<G>((int)blockIdx.z, IT::item(), blockIdx.y, A_in, mA, strideA_in, C_in, mC, strideC_in, A_out, strideA_out, C_out, strideC_out);
 }
-// The LAST pair levels in one launch: once a level's 2 JA + JC pieces fit the item slots of one workgroup of eight waves, a single
-// workgroup per window runs every remaining level -- the same pieces, the same ping-pong buffers (L2-resident by then), a workgroup
-// barrier where the per-level kernels had a dependent launch (~8 us each, ten of them at c = 20).  Not for the mailbox field variants
-// (their LDS slots are per lane of ONE wave): the 753-bit groups keep a launch per level.
-constexpr uint32_t MSM_FUSED_WAVES = 8;
+// The LAST pair levels in one launch: once a level's 2 JA + JC pieces fit the item slots of one workgroup of FOUR waves -- one wave per
+// SIMD of a CU: with eight, two waves share a SIMD and every level takes 1.6x as long, more than the launch it saves (measured: tail
+// 0.66 -> 0.78 ms) -- a single workgroup per window runs every remaining level: the same pieces, the same ping-pong buffers
+// (L2-resident by then), a workgroup barrier where the per-level kernels had a dependent launch (~8 us each, eight of them at c = 20).
+// Not for the mailbox field variants (their LDS slots are per lane of ONE wave): the 753-bit groups keep a launch per level.
+constexpr uint32_t MSM_FUSED_WAVES = 4;
 template <class G>
 struct MsmFusedTail {
   static constexpr bool ENABLED = !MsmPairOps<G>::GA::F::Base::MAILBOX;
-  static constexpr uint32_t SLOTS = MSM_FUSED_WAVES * MsmPairItems<G>::PER_WAVE;
-  static bool fits(uint32_t mA, uint32_t mC) { return ENABLED && 2 * ((mA + 1) >> 1) + ((mC + 1) >> 1) <= SLOTS; }
+  // the three kinds of pieces of a level (A' = 2 (A0 + A1), L = A0 + 2 A1, C' = C0 + C1) take WHOLE waves each: lanes of one wave that ran
+  // different kinds would execute all three code paths one after the other
+  static uint32_t waves(uint32_t items) { return (items + MsmPairItems<G>::PER_WAVE - 1) / MsmPairItems<G>::PER_WAVE; }
+  static bool fits(uint32_t mA, uint32_t mC) { return ENABLED && 2 * waves((mA + 1) >> 1) + waves((mC + 1) >> 1) <= MSM_FUSED_WAVES; }
 };
 template <class G>
 __global__ void __launch_bounds__(64 * MSM_FUSED_WAVES) msm_tail_fused_kernel(const uint32_t* A_in, uint32_t mA, size_t strideA_in, const uint32_t* C_in,
@@ -926,17 +929,16 @@ __global__ void __launch_bounds__(64 * MSM_FUSED_WAVES) msm_tail_fused_kernel(co
   typedef MsmPairItems<G> IT;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const bool idle = lane >= IT::PER_WAVE * IT::LANES;
-  const uint32_t slot = wave * IT::PER_WAVE + lane / IT::LANES;
   const uint32_t w = blockIdx.x;
   while (mA > 0 || mC > 1) {
     const uint32_t JA = (mA + 1) >> 1, JC = (mC + 1) >> 1;
     uint32_t* A_out = flip ? A1 : A0;
     uint32_t* C_out = flip ? C1 : C0;
-    if (!idle && slot < 2 * JA + JC) {
-      const int role = slot < JA ? 0 : slot < 2 * JA ? 1 : 2;
-      const uint32_t j = role == 0 ? slot : role == 1 ? slot - JA : slot - 2 * JA;
-      msm_tail_pair_item<G>(role, j, w, A_in, mA, strideA_in, C_in, mC, strideC_in, A_out, strideAC, C_out, strideAC);
-    }
+    // waves [0, wa): kind 0, [wa, 2 wa): kind 1, the rest: kind 2 (uniform per wave)
+    const uint32_t wa = (JA + IT::PER_WAVE - 1) / IT::PER_WAVE;
+    const int role = wave < wa ? 0 : wave < 2 * wa ? 1 : 2;
+    const uint32_t j = (wave - (uint32_t)role * wa) * IT::PER_WAVE + lane / IT::LANES;
+    if (!idle) msm_tail_pair_item<G>(role, j, w, A_in, mA, strideA_in, C_in, mC, strideC_in, A_out, strideAC, C_out, strideAC);
     __syncthreads();  // (also makes this level's global stores visible to the whole workgroup)
     mA = JA ? JA - 1 : 0;
     mC = JC + JA;
