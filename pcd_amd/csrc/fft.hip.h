@@ -110,8 +110,12 @@ template <class F>
 __global__ void __launch_bounds__(256) fft_pass_kernel(const uint32_t* __restrict__ x, uint32_t* __restrict__ y,
                                                        const uint32_t* __restrict__ tw, int logn, int d, int logT, int logs,
                                                        const uint32_t* __restrict__ pre, const uint32_t* __restrict__ post,
-                                                       int use_scale, const F scale_c) {
+                                                       int use_scale, const F scale_c, size_t batch_stride) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  // blockIdx.y: which of several equal transforms laid out `batch_stride` words apart (the rows of a mixed-radix domain go through
+  // their radix-2 passes in ONE launch per pass: a 2^14-point row alone is 16 workgroups on a 256-CU chip)
+  x += (size_t)blockIdx.y * batch_stride;
+  y += (size_t)blockIdx.y * batch_stride;
   typedef FftArith<F> A;
   typedef typename A::E E;
   constexpr int EW = F::WORDS;

@@ -75,8 +75,9 @@ hipError_t make_tables(hipStream_t st, int log_n, FftTables* t) {
 }
 
 // transform x in place (tmp = ping-pong partner).  inverse: w^-1 and 1/n;  coset: see fft.hip.h header.
-hipError_t run(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t* tmp, int log_n, int inverse, int coset,
-               float* pass_ms, int* npasses) {
+// batch > 1: `batch` transforms of 2^log_n elements each, laid out back to back in x (and in tmp), in one launch per pass
+hipError_t run_batched(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t* tmp, int log_n, int inverse, int coset,
+                       float* pass_ms, int* npasses, uint32_t batch) {
   std::vector<FftPass> plan = fft_plan(log_n);
   const int P = (int)plan.size();
   const uint32_t* tw = inverse ? t.tw_inv : t.tw_fwd;
@@ -102,14 +103,14 @@ hipError_t run(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t* tmp, i
     const uint32_t* post = (last && coset && inverse) ? t.coset_inv_scaled : nullptr;
     const uint32_t blocks = 1u << (log_n - d - logT);
     const size_t lds = ((size_t)1 << (d + logT)) * EW * 4;
-    hipLaunchKernelGGL(fft_pass_kernel<FT>, dim3(blocks), dim3(256), lds, st, src, dst, tw, log_n, d, logT, logs, pre, post,
-                       (last ? use_scale : 0), scale);
+    hipLaunchKernelGGL(fft_pass_kernel<FT>, dim3(blocks, batch), dim3(256), lds, st, src, dst, tw, log_n, d, logT, logs, pre, post,
+                       (last ? use_scale : 0), scale, ((size_t)EW) << log_n);
     if (pass_ms) PCD_HIP_TRY(hipEventRecord(ev[i + 1], st));
     logs += d;
     std::swap(src, dst);
   }
   PCD_HIP_TRY(hipGetLastError());
-  if (src != x) PCD_HIP_TRY(hipMemcpyAsync(x, src, ((size_t)1 << log_n) * EW * 4, hipMemcpyDeviceToDevice, st));
+  if (src != x) PCD_HIP_TRY(hipMemcpyAsync(x, src, ((size_t)batch << log_n) * EW * 4, hipMemcpyDeviceToDevice, st));
   if (pass_ms) {
     PCD_HIP_TRY(hipStreamSynchronize(st));
     for (int i = 0; i < P && i < 8; i++) (void)hipEventElapsedTime(&pass_ms[i], ev[i], ev[i + 1]);
@@ -117,6 +118,9 @@ hipError_t run(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t* tmp, i
   }
   if (npasses) *npasses = P;
   return hipSuccess;
+}
+hipError_t run(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t* tmp, int log_n, int inverse, int coset, float* pass_ms, int* npasses) {
+  return run_batched(st, t, x, tmp, log_n, inverse, coset, pass_ms, npasses, 1);
 }
 
 // ---- mixed-radix domain n = m * 2^a
@@ -183,8 +187,8 @@ hipError_t mixed_run(hipStream_t st, const FftTables& t, const FftTables& t2, ui
   const uint32_t* pre = (coset && !inverse) ? t.coset : nullptr;
   hipLaunchKernelGGL(fft_mixed_columns_kernel<FT>, dim3((N2 + 63) / 64), dim3(64), 0, st, x, tmp, inverse ? t.tw_inv : t.tw_fwd, N2, m,
                      inverse ? c.wm_inv : c.wm, pre);
-  for (uint32_t k1 = 0; k1 < m; k1++)  // rows through the radix-2 passes; x serves as their ping-pong space
-    PCD_HIP_TRY(run(st, t2, tmp + (size_t)k1 * N2 * EW, x + (size_t)k1 * N2 * EW, a, inverse ? 3 : 0, 0, nullptr, nullptr));
+  // the m rows through the radix-2 passes, all rows in one launch per pass; x serves as their ping-pong space
+  PCD_HIP_TRY(run_batched(st, t2, tmp, x, a, inverse ? 3 : 0, 0, nullptr, nullptr, m));
   const uint32_t* post = (coset && inverse) ? t.coset_inv_scaled : nullptr;
   const int use_scale = (inverse && !coset) ? 1 : 0;
   hipLaunchKernelGGL(fft_mixed_interleave_kernel<FT>, dim3((n + 255) / 256), dim3(256), 0, st, tmp, x, N2, m, post, use_scale, c.ninv);
