@@ -1705,7 +1705,8 @@ int pcdhip_multi_pairing(pcdhip_ctx* ctx, int curve_id, const uint64_t* g1_xy, c
     const PairingEntry& pe = pairing_entry(curve_id);
     TRY(ctx->aux_ws.ensure(AUX_MISC, (size_t)pe.gt_words * 4 + 256));
     uint32_t* out = (uint32_t*)ctx->aux_ws.buf[AUX_MISC];
-    TRY(pe.multi_pairing(ctx->stream, out, nullptr, out, 1, 0, out, out, nullptr));  // (the lane-per-pairing kernels: one lane, no pairs)
+    if (!ctx->vm_block[curve_id] && ctx->pairing_vm) TRY(pe.vm_upload(ctx->stream, &ctx->vm_block[curve_id], &ctx->vm_tables[curve_id]));
+    TRY(pe.multi_pairing(ctx->stream, out, nullptr, out, 1, 0, out, out, ctx->pairing_vm ? &ctx->vm_tables[curve_id] : nullptr));
     TRY(hipMemcpyAsync(gt_out, out, (size_t)pe.gt_words * 4, hipMemcpyDeviceToHost, ctx->stream));
     TRY(hipStreamSynchronize(ctx->stream));
     return PCDHIP_OK;
