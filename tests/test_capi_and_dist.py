@@ -125,7 +125,16 @@ lo, hi = shard_range(n, rank, world)
 bases = ctx.bases_upload(cid, grp, pts[lo:hi])             # this rank's point range of the key is resident on ITS device
 sbuf = ctx.buf_upload(fr, sc[lo:hi])
 if two:
-    full = DeviceExchange(ctx, cid, grp, torch.device("cuda", dev)).msm(bases, sbuf)   # partial -> RCCL all-gather -> EC sum, on device
+    ex = DeviceExchange(ctx, cid, grp, torch.device("cuda", dev))
+    full = ex.msm(bases, sbuf)                                # partial -> RCCL all-gather -> EC sum, on device
+    pending, outs = [], []                                    # and the pipelined form bench.py times: four shard MSMs in flight
+    for _ in range(6):
+        pending.append(ex.submit(bases, sbuf))
+        if len(pending) == 4:
+            outs.append(ex.collect(pending.pop(0)))
+    while pending:
+        outs.append(ex.collect(pending.pop(0)))
+    assert all(np.array_equal(o, full) for o in outs)
 else:
     full = sharded_msm(lambda a, b: ctx.msm(bases, sbuf), lambda parts: ctx.points_sum(cid, grp, parts), n)
 want = co.msm(cid, grp, pts, sc, nthreads=4)
