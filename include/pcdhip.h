@@ -305,7 +305,10 @@ int pcdhip_groth16_verify_prepared(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_
  * caller's challenges rho (n_proofs x 2 u64 limbs = 128 bits each, non-zero; the library draws no randomness):
  *   prod_i e(rho_i A_i, B_i) e(sum rho_i acc_i, -gamma) e(sum rho_i C_i, -delta) e(-(sum rho_i) alpha, beta) == 1
  * -- n_proofs + 3 Miller loops in one launch, one final exponentiation.  *all_ok = 1 iff the product is one: every proof valid,
- * or an invalid batch that slipped through with probability 2^-128 over rho.  On 0, pcdhip_groth16_verify_prepared finds the culprit. */
+ * or an invalid batch that slipped through with probability 2^-128 over rho.  On 0, pcdhip_groth16_verify_prepared finds the culprit.
+ * A batch whose 3 n_proofs pairings all find a SIMD at once (wave-per-pairing mode, n_proofs <= 341) is answered by the n_proofs
+ * deterministic checks side by side instead -- they take the time of one, less than the combination's scalings -- with the same
+ * meaning of *all_ok (and no slip probability); rho is validated either way. */
 int pcdhip_groth16_verify_batch_rlc(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_t n_proofs, const uint64_t* public_inputs_canonical,
                                     const uint64_t* proofs, const uint8_t* proofs_inf, const uint64_t* rho, int* all_ok);
 
