@@ -45,7 +45,7 @@ EXPORTS = [
     "pcdhip_field_limbs", "pcdhip_curve_base_field", "pcdhip_curve_scalar_field", "pcdhip_point_limbs",
     "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
     "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config", "pcdhip_msm_submit", "pcdhip_msm_collect", "pcdhip_msm_submit_partial", "pcdhip_msm_ticket_wait", "pcdhip_bases_info", "pcdhip_stream_wait",
-    "pcdhip_set_precompute", "pcdhip_set_precompute_budget", "pcdhip_msm_set_sort", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
+    "pcdhip_set_precompute", "pcdhip_set_precompute_budget", "pcdhip_msm_set_sort", "pcdhip_msm_set_accumulate", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
     "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_g16_witness_map_resident", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
     "pcdhip_serialized_size", "pcdhip_serialize_points", "pcdhip_deserialize_points", "pcdhip_deserialize_points_unchecked", "pcdhip_proof_serialized_size", "pcdhip_proof_serialize",
@@ -216,6 +216,10 @@ class Context:
     def msm_set_sort(self, mode):
         """0: LDS partition sort (default); 1: single-pass binning with on-device fallback; 2: two-pass counting sort."""
         self._check(lib().pcdhip_msm_set_sort(self._ctx, int(mode)))
+
+    def msm_set_accumulate(self, mode, chunk=0, min_pairs=0):
+        """0 by size, 1 running sums, 2 pair tree of affine additions (753-bit G1); chunk / min_pairs: tuning and test knobs"""
+        self._check(lib().pcdhip_msm_set_accumulate(self._ctx, int(mode), int(chunk), int(min_pairs)))
 
     def msm_profile(self, on=True):
         self._check(lib().pcdhip_msm_profile(self._ctx, int(on)))

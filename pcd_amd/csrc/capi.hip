@@ -488,7 +488,12 @@ int pcdhip_msm_config(pcdhip_ctx* ctx, int window_bits, int chunk) {
 }
 int pcdhip_msm_set_sort(pcdhip_ctx* ctx, int mode) {
   if (!ctx || mode < 0 || mode > 2) return PCDHIP_E_ARG;
-  ctx->msm_sort = mode;
+  ctx->msm_sort = (ctx->msm_sort & ~15) | mode;  // (the higher bits carry pcdhip_msm_set_accumulate's choice: msm.hip.h msm_run)
+  return PCDHIP_OK;
+}
+int pcdhip_msm_set_accumulate(pcdhip_ctx* ctx, int mode, int chunk, int min_pairs) {
+  if (!ctx || mode < 0 || mode > 2 || chunk < 0 || chunk > 4095 || (chunk && chunk < 2) || min_pairs < 0 || min_pairs > 255) return PCDHIP_E_ARG;
+  ctx->msm_sort = (ctx->msm_sort & 15) | (mode << 4) | (chunk << 8) | (min_pairs << 20);
   return PCDHIP_OK;
 }
 int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode) {

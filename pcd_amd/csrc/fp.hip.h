@@ -557,8 +557,11 @@ struct Fp {
     r[N - 1] = (int32_t)cc;
     return norm_reduce<false>(r);
   }
-  // a^(p-2) (inverse; zero maps to zero)
-  PCD_HD Fp inv() const {
+  // the inverse (zero maps to zero): divsteps -- 25x (753 bits) / 7x (298 bits) fewer instructions than a^(p-2), which matters wherever
+  // ONE lane inverts on the critical path: the affine images of a proof's three points, batch normalisations, the pairing's inverses
+  PCD_HD Fp inv() const { return inv_gcd(); }
+  // a^(p-2): the cross-check of inv_gcd (tests/hostcheck)
+  PCD_HD Fp inv_fermat() const {
     Fp r = one();
     bool started = false;
     for (int i = P::N32 * 32 - 1; i >= 0; i--) {
@@ -566,6 +569,80 @@ struct Fp {
       if ((P::modm2(i >> 5) >> (i & 31)) & 1) { r = started ? r * *this : *this; started = true; }
     }
     return r;
+  }
+  // The inverse by divsteps (Bernstein-Yang, "Fast constant-time gcd computation and modular inversion", 2019): 28 division steps at a
+  // time on the low limbs of (f, g) = (p, a) give a 2x2 transition matrix with entries of at most 28 bits, which is then applied to
+  // the full-width f, g (exactly: the low 28 bits cancel) and to d, e with d a = f, e a = g (mod p) (a multiple of p makes those
+  // divisible by 2^28 as well).  After (49 bits + 57) / 17 steps g = 0 and f = +-1, so a^-1 = +-d.  No branch depends on the data:
+  // every lane of a wave walks the same ~1 000 instructions per batch -- 45 field products' worth for 753 bits, against 940 for
+  // a^(p-2) -- which is what makes one inversion per lane and per few dozen additions affordable (msm.hip.h, the pair tree).
+  // Montgomery form in and out: the integer inverse of a R is a^-1 R^-1, one product with R^3 puts R back.  Zero maps to zero.
+  PCD_HD Fp inv_gcd() const {
+    constexpr int STEPS = (49 * P::BITS + 57) / 17, BATCHES = (STEPS + 27) / 28;
+    constexpr uint32_t PINV = (0u - P::INV) & MASK;  // p^-1 mod 2^28
+    const Fp xc = canonical();
+    int32_t f[N], g[N], d[N], e[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { f[i] = (int32_t)P::mod(i); g[i] = (int32_t)xc.v[i]; d[i] = 0; e[i] = 0; }
+    e[0] = 1;
+    int32_t eta = -1;  // -delta
+    for (int b = 0; b < BATCHES; b++) {
+      uint32_t u = 1, v = 0, q = 0, r = 1, ff = (uint32_t)f[0], gg = (uint32_t)g[0];
+#pragma unroll 4
+      for (int i = 0; i < 28; i++) {
+        uint32_t c1 = (uint32_t)(eta >> 31);
+        const uint32_t c2 = 0u - (gg & 1u);
+        const uint32_t x = (ff ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;
+        gg += x & c2; q += y & c2; r += z & c2;
+        c1 &= c2;
+        eta = (eta ^ (int32_t)c1) - (int32_t)(c1 + 1u);
+        ff += gg & c1; u += q & c1; v += r & c1;
+        gg >>= 1; u <<= 1; v <<= 1;
+      }
+      const int64_t U = (int32_t)u, V = (int32_t)v, Q = (int32_t)q, R = (int32_t)r;
+      {  // (f, g) <- t (f, g) / 2^28
+        int64_t cf = U * f[0] + V * g[0], cg = Q * f[0] + R * g[0];
+        cf >>= 28; cg >>= 28;
+#pragma unroll
+        for (int i = 1; i < N; i++) {
+          cf += U * f[i] + V * g[i];
+          cg += Q * f[i] + R * g[i];
+          f[i - 1] = (int32_t)((uint32_t)cf & MASK); cf >>= 28;
+          g[i - 1] = (int32_t)((uint32_t)cg & MASK); cg >>= 28;
+        }
+        f[N - 1] = (int32_t)cf; g[N - 1] = (int32_t)cg;
+      }
+      {  // (d, e) <- t (d, e) / 2^28 mod p, kept in (-2p, p)
+        const int32_t sd = d[N - 1] >> 31, se = e[N - 1] >> 31;
+        int32_t md = ((int32_t)u & sd) + ((int32_t)v & se), me = ((int32_t)q & sd) + ((int32_t)r & se);
+        int64_t cd = U * d[0] + V * e[0], ce = Q * d[0] + R * e[0];
+        md -= (int32_t)((PINV * (uint32_t)cd + (uint32_t)md) & MASK);
+        me -= (int32_t)((PINV * (uint32_t)ce + (uint32_t)me) & MASK);
+        cd += (int64_t)P::mod(0) * md; ce += (int64_t)P::mod(0) * me;
+        cd >>= 28; ce >>= 28;
+#pragma unroll
+        for (int i = 1; i < N; i++) {
+          cd += U * d[i] + V * e[i] + (int64_t)P::mod(i) * md;
+          ce += Q * d[i] + R * e[i] + (int64_t)P::mod(i) * me;
+          d[i - 1] = (int32_t)((uint32_t)cd & MASK); cd >>= 28;
+          e[i - 1] = (int32_t)((uint32_t)ce & MASK); ce >>= 28;
+        }
+        d[N - 1] = (int32_t)cd; e[N - 1] = (int32_t)ce;
+      }
+    }
+    // +-d with the sign of f, from (-2p, 2p) into [0, 2p)
+    const int32_t sf = f[N - 1] >> 31;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) { const int32_t x = ((d[i] ^ sf) - sf) + c; d[i] = (int32_t)((uint32_t)x & MASK); c = x >> 28; }
+    d[N - 1] = ((d[N - 1] ^ sf) - sf) + c;
+    const uint32_t neg = (uint32_t)(d[N - 1] >> 31);
+    Fp o;
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) { const int32_t x = d[i] + (int32_t)(P::mod2(i) & neg) + c; o.v[i] = (uint32_t)x & MASK; c = x >> 28; }
+    o.v[N - 1] = (uint32_t)(d[N - 1] + (int32_t)(P::mod2(N - 1) & neg) + c);
+    return o * (r2() * r2());
   }
   PCD_HD Fp pow_u64(uint64_t e) const {
     Fp r = one(), b = *this;

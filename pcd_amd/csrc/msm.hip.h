@@ -646,6 +646,293 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
   else acc.flush(buckets + (size_t)cur.key * RW);
 }
 
+// ------------------------------------------------------------------------------------------------ accumulate, pair-tree form
+// The same stage for the 753-bit G1 groups when the list is long, with AFFINE additions whose inversions are shared (upstream's
+// `batch_addition` idea: ark-ec 0.3 has it in its bucketed `BatchGroupArithmetic` branch; the reference's own MSM does not).  A lane
+// owns a chunk of several hundred sorted entries and halves it level by level: neighbours of the same bucket form a pair,
+// P + Q = (l^2 - x1 - x2, l (x1 - x3) - y1) with l = (y2 - y1) / (x2 - x1), and the denominators of ALL the lane's pairs of a level
+// are inverted together -- a running product on the way forth (kept in HBM, lane-interleaved), ONE inversion (Fp::inv_gcd, 45
+// products' worth), and on the way back each pair's inverse peels off with two products: 5M + 1S per addition against 7M + 4S for the
+// Jacobian mixed addition, no Z coordinate, results written back as affine points (216 B) that the next level pairs again.  Levels
+// stop when the widest lane of the wave has fewer than `min_pairs` pairs left (an inversion no longer pays); what remains of every
+// bucket run -- usually one point -- goes through the ordinary running sum and is flushed exactly as msm_accumulate_kernel does, so
+// the fix-up pass and everything behind it are unchanged.  Equal points (doubling: denominator 2y), opposite points, operands at
+// infinity and points with x = 0 are classified on the way forth in a branch that is normally skipped.
+// One wave per workgroup, workgroups persistent (a wave walks chunk groups blockIdx.x, + gridDim.x, ...): the scratch areas belong
+// to the resident wave, not to the chunk.  Everything a lane keeps in HBM is indexed [item][word][lane]: a wave's access to "its k-th
+// pair" is one 256-byte line per word.
+constexpr uint32_t MSM_TREE_CHUNK_MAX = 640, MSM_TREE_MIN_PAIRS = 12;
+constexpr uint32_t MSM_SCR = 0x40000000u;  // item location: slot of the lane's point scratch (else a base entry, MSM_NEG = negated)
+template <class G>
+struct MsmTreeCapable {
+  typedef typename AccOf<G>::type::F F;
+  static constexpr bool value = F::DEG == 1 && AccOf<G>::LANES == 1 && F::Base::N > 11;
+};
+struct MsmTreeBufs {
+  uint32_t* list;    // per wave: 2 lists x cap items x (key, loc) x 64 lanes
+  uint32_t* pairs;   // per wave: (cap / 2 + 1) x (loc a, loc b, kind) x 64
+  uint32_t* prefix;  // per wave: (cap / 2 + 1) field elements x 64
+  uint32_t* pts;     // per wave: cap affine points x 64
+  uint32_t cap;      // entries per chunk
+  uint32_t phases;   // 3: trip count of the first product loop of the way back (a kernel argument so that the loops stay loops)
+  PCD_HD static size_t list_words(uint32_t cap) { return (size_t)4 * cap * 64; }
+  PCD_HD static size_t pair_words(uint32_t cap) { return (size_t)3 * (cap / 2 + 1) * 64; }
+  PCD_HD static size_t prefix_words(uint32_t cap, int fw) { return (size_t)((fw + 3) / 4 * 4) * (cap / 2 + 1) * 64; }
+  // (slots are handed out per level for the whole wave -- the widest lane's pair count -- so that "pair k" is the same slot in every lane:
+  //  a level with L pairs at most cap / (2^(l-1) + 1) wide, summed over the levels < 1.23 cap)
+  PCD_HD static size_t pts_words(uint32_t cap, int fw) { return (size_t)2 * ((fw + 3) / 4 * 4) * (cap + cap / 4 + 8) * 64; }
+};
+PCD_DEV uint32_t msm_wave_max(uint32_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, m, 64));
+  return v;
+}
+enum { MSM_PK_ADD = 0, MSM_PK_TAKE_B = 1, MSM_PK_TAKE_A = 2, MSM_PK_INF = 3, MSM_PK_DBL = 4 };
+
+// entries per lane: the list spread over the lanes of the persistent grid, in as many rounds as keep a chunk within the scratch capacity
+static __global__ void msm_tree_plan_kernel(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t lanes, uint32_t cap, uint32_t forced,
+                                            uint32_t* __restrict__ chunk_out) {
+  if (blockIdx.x || threadIdx.x) return;
+  const uint64_t M = off[nkeys];
+  const uint64_t rounds = (M + (uint64_t)lanes * cap - 1) / ((uint64_t)lanes * cap);
+  uint32_t chunk = rounds ? (uint32_t)((M + lanes * rounds - 1) / (lanes * rounds)) : 32u;
+  chunk = min(max(chunk, 32u), cap);
+  *chunk_out = forced ? forced : chunk;
+}
+template <class G>
+__global__ void __launch_bounds__(64, 1) msm_pair_tree_kernel(const uint32_t* __restrict__ bases, const MsmEntrySource src,
+                                                              const uint32_t* __restrict__ off, uint32_t nkeys, const uint32_t* __restrict__ chunk_dev,
+                                                              const MsmTreeBufs tb, uint32_t min_pairs, uint32_t* __restrict__ buckets,
+                                                              uint32_t* __restrict__ piece_first, uint32_t* __restrict__ piece_last) {
+  typedef typename AccOf<G>::type GA;
+  typedef typename GA::F F;
+  constexpr int RW = MsmStored<GA>::WORDS, FW = F::WORDS;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t M = off[nkeys];
+  const uint32_t chunk = *chunk_dev;  // msm_tree_plan_kernel: from the ACTUAL list length (a witness's list is a fraction of n W)
+  const uint32_t nwaves = (uint32_t)((((uint64_t)M + chunk - 1) / chunk + 63) / 64);
+  const bool compact = !(src.slots && src.flag && *src.flag == 0);
+  const uint32_t ones_start = off[src.ones_key];
+  uint32_t* const LS = tb.list + (size_t)blockIdx.x * MsmTreeBufs::list_words(tb.cap) + lane;
+  uint32_t* const PR = tb.pairs + (size_t)blockIdx.x * MsmTreeBufs::pair_words(tb.cap) + lane;
+  constexpr int ECH = (FW + 3) / 4, EW = 4 * ECH;  // 16-byte pieces / padded words of one element in the scratch areas
+  uint32_t* const PX = tb.prefix + (size_t)blockIdx.x * MsmTreeBufs::prefix_words(tb.cap, FW) + lane * 4;
+  uint32_t* const PT = tb.pts + (size_t)blockIdx.x * MsmTreeBufs::pts_words(tb.cap, FW) + lane * 4;
+  // one element = ECH 16-byte pieces, piece c of lane l at words (c * 64 + l) * 4 of its row: a wave moves 1 KB per instruction
+  typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+  auto fld_ld = [&](const uint32_t* p) { F r;
+#pragma unroll
+    for (int c = 0; c < ECH; c++) {
+      const V4 v = *reinterpret_cast<const V4*>(p + (size_t)c * 256);
+      r.v[4 * c] = v.x;
+      if (4 * c + 1 < FW) r.v[4 * c + 1] = v.y;
+      if (4 * c + 2 < FW) r.v[4 * c + 2] = v.z;
+      if (4 * c + 3 < FW) r.v[4 * c + 3] = v.w;
+    }
+    return r; };
+  auto fld_st = [&](uint32_t* p, const F& a) {
+#pragma unroll
+    for (int c = 0; c < ECH; c++) {
+      V4 v;
+      v.x = a.v[4 * c];
+      v.y = 4 * c + 1 < FW ? a.v[4 * c + 1] : 0u;
+      v.z = 4 * c + 2 < FW ? a.v[4 * c + 2] : 0u;
+      v.w = 4 * c + 3 < FW ? a.v[4 * c + 3] : 0u;
+      *reinterpret_cast<V4*>(p + (size_t)c * 256) = v;
+    } };
+  // (the wave-uniform cases first: at level 1 every operand is a base entry -- contiguous records, wide loads -- and later nearly
+  //  every one a scratch point; the compiler turns a per-lane choice of the two into ONE sequence of 4-byte loads with selected
+  //  addresses, 27 x 64 separate lines per element through the CU's one address path)
+  auto x_of = [&](uint32_t loc) {
+    const bool scr = (loc & MSM_SCR) != 0;
+    if (!__any(scr)) return F::load(bases + (size_t)(loc & ~MSM_NEG) * MsmBaseStride<G>::value);
+    if (__all(scr)) return fld_ld(PT + (size_t)(loc & ~MSM_SCR) * (2 * EW * 64));
+    F r = F::zero();
+    if (scr) r = fld_ld(PT + (size_t)(loc & ~MSM_SCR) * (2 * EW * 64));
+    else r = F::load(bases + (size_t)(loc & ~MSM_NEG) * MsmBaseStride<G>::value);
+    return r; };
+  auto base_point = [&](uint32_t loc) {
+    Aff<F> q = Aff<F>::load(bases + (size_t)(loc & ~MSM_NEG) * MsmBaseStride<G>::value);
+    const F ny = q.y.neg();
+    if (loc & MSM_NEG) q.y = ny;
+    return q; };
+  auto scratch_point = [&](uint32_t loc) {
+    const uint32_t* p = PT + (size_t)(loc & ~MSM_SCR) * (2 * EW * 64);
+    Aff<F> q;
+    q.x = fld_ld(p); q.y = fld_ld(p + (size_t)EW * 64);
+    return q; };
+  auto point_of = [&](uint32_t loc) {
+    const bool scr = (loc & MSM_SCR) != 0;
+    if (!__any(scr)) return base_point(loc);
+    if (__all(scr)) return scratch_point(loc);
+    Aff<F> q = {F::zero(), F::zero()};
+    if (scr) q = scratch_point(loc);
+    else q = base_point(loc);
+    return q; };
+  for (uint32_t w = blockIdx.x; w < nwaves; w += gridDim.x) {
+    const uint32_t t = w * 64 + lane;
+    const uint64_t start64 = (uint64_t)t * chunk;
+    const uint32_t start = start64 < M ? (uint32_t)start64 : M;
+    const uint32_t n0 = min(M - start, chunk), end = start + n0;
+    // level 0: the chunk's entries with their buckets
+    uint32_t key_first = 0;
+    bool open_start = false;
+    if (n0) {
+      MsmCursor cur;
+      cur.seek(off, nkeys, start);
+      key_first = cur.key;
+      open_start = cur.key_start < start;
+      for (uint32_t i = 0; i < n0; i++) {
+        const uint32_t p = start + i;
+        if (p >= cur.key_end) cur.advance_to(off, nkeys, p);
+        uint32_t e;
+        if (compact) e = (src.ones_idx && p >= ones_start) ? src.ones_idx[p - ones_start] : src.sorted_idx[p];
+        else e = msm_entry(src, false, cur, p);
+        LS[(size_t)(2 * i) * 64] = cur.key;
+        LS[(size_t)(2 * i + 1) * 64] = e;
+      }
+    }
+    uint32_t cnt = n0, which = 0, slot_base = 0;
+    for (;;) {
+      uint32_t* const in = LS + (size_t)which * (2 * tb.cap * 64);
+      uint32_t* const out = LS + (size_t)(which ^ 1) * (2 * tb.cap * 64);
+      uint32_t np = 0, j = 0;
+      for (uint32_t i = 0; i < cnt; j++) {
+        const uint32_t k0 = in[(size_t)(2 * i) * 64], l0 = in[(size_t)(2 * i + 1) * 64];
+        if (i + 1 < cnt && in[(size_t)(2 * i + 2) * 64] == k0) {
+          PR[(size_t)(3 * np) * 64] = l0;
+          PR[(size_t)(3 * np + 1) * 64] = in[(size_t)(2 * i + 3) * 64];
+          out[(size_t)(2 * j) * 64] = k0;
+          out[(size_t)(2 * j + 1) * 64] = MSM_SCR | (slot_base + np);
+          np++; i += 2;
+        } else {
+          out[(size_t)(2 * j) * 64] = k0;
+          out[(size_t)(2 * j + 1) * 64] = l0;
+          i++;
+        }
+      }
+      const uint32_t np_max = msm_wave_max(np);
+      if (np_max < min_pairs) break;
+      // forth: the kinds, the denominators and their running product.  The product is INLINED here (and the five of the way back
+      // run through one inlined copy): a call makes the compiler wait for every outstanding load first, and at one wave per SIMD
+      // nothing else hides the 2-3 us of a dependent load -- pair k + 1's operands and pair k + 2's list entries are requested
+      // before pair k's product and arrive behind it.
+      F run = F::one();
+      {
+        uint32_t la = 0, lb = 0, la1 = 0, lb1 = 0;
+        if (0 < np) { la = PR[0]; lb = PR[(size_t)64]; }
+        if (1 < np) { la1 = PR[(size_t)3 * 64]; lb1 = PR[(size_t)4 * 64]; }
+        F x1n = F::zero(), x2n = F::zero();
+        if (0 < np) { x1n = x_of(la); x2n = x_of(lb); }
+        for (uint32_t k = 0; k < np_max; k++) {
+          const F x1 = x1n, x2 = x2n;
+          const uint32_t ca = la, cb = lb;
+          la = la1; lb = lb1;
+          if (k + 2 < np) { la1 = PR[(size_t)(3 * k + 6) * 64]; lb1 = PR[(size_t)(3 * k + 7) * 64]; }
+          if (k + 1 < np) { x1n = x_of(la); x2n = x_of(lb); }
+          F dd = F::one();
+          if (k < np) {
+            uint32_t kind = MSM_PK_ADD;
+            dd = x2 - x1;
+            if (__builtin_expect(x1.is_raw_zero() || x2.is_raw_zero() || dd.is_zero(), 0)) {
+              const Aff<F> a = point_of(ca), b = point_of(cb);
+              if (a.is_inf()) { kind = MSM_PK_TAKE_B; dd = F::one(); }
+              else if (b.is_inf()) { kind = MSM_PK_TAKE_A; dd = F::one(); }
+              else if (dd.is_zero()) {
+                if ((a.y + b.y).is_zero()) { kind = MSM_PK_INF; dd = F::one(); }
+                else { kind = MSM_PK_DBL; dd = a.y.dbl(); }
+              }
+            }
+            PR[(size_t)(3 * k + 2) * 64] = kind;
+            fld_st(PX + (size_t)k * (EW * 64), run);
+          }
+          run = F::mul_impl(run, dd);
+        }
+      }
+      F inv = run.inv_gcd();
+      // back: 1 / d_k = inv * (d_0 .. d_{k-1}), inv *= d_k
+      {
+        Aff<F> an = {F::zero(), F::zero()}, bn = an;
+        F pren = F::one();
+        uint32_t kindn = MSM_PK_INF, la = 0, lb = 0;
+        if (np_max - 1 < np) {  // the widest lanes' last pair
+          const uint32_t k = np_max - 1;
+          an = point_of(PR[(size_t)(3 * k) * 64]); bn = point_of(PR[(size_t)(3 * k + 1) * 64]);
+          kindn = PR[(size_t)(3 * k + 2) * 64];
+          pren = fld_ld(PX + (size_t)k * (EW * 64));
+        }
+        if (np_max >= 2 && np_max - 2 < np) { la = PR[(size_t)(3 * (np_max - 2)) * 64]; lb = PR[(size_t)(3 * (np_max - 2) + 1) * 64]; }
+        for (uint32_t k = np_max; k-- > 0;) {
+          const bool live = k < np;
+          const uint32_t kind = live ? kindn : (uint32_t)MSM_PK_ADD;
+          // what the five products need of pair k: x1, y1, x1 + x2, the denominator and the numerator (the second point dies here)
+          const F ax = an.x, ay = an.y, pre = pren;
+          const F sx = an.x + bn.x;
+          F dd = F::one(), num = F::zero();
+          if (live && kind == MSM_PK_ADD) { dd = bn.x - an.x; num = bn.y - an.y; }
+          if (__builtin_expect(__any(kind == MSM_PK_DBL), 0)) {
+            if (kind == MSM_PK_DBL) { const F xx = ax.sqr(); dd = ay.dbl(); num = xx.dbl() + xx + GA::mul_by_a(F::one()); }
+          }
+          // ik = inv * pre; inv *= dd; lam = num * ik through one inlined copy of the product -- then pair k - 1's operands are
+          // requested -- lam^2 and lam * (x1 - x3) straight-line (nothing of the first three is alive any more)
+          F t0 = F::zero(), lam = F::zero();
+#pragma nounroll
+          for (uint32_t ph = 0; ph < tb.phases; ph++) {
+            F u, v;
+            if (ph == 0) { u = inv; v = pre; }
+            else if (ph == 1) { u = inv; v = dd; }
+            else { u = num; v = t0; }
+            const F m = F::mul_impl(u, v);
+            if (ph == 0) t0 = m;
+            else if (ph == 1) inv = m;
+            else lam = m;
+          }
+          if (k >= 1 && k - 1 < np) {  // pair k - 1: its points, its kind, its prefix; pair k - 2: its list entries
+            an = point_of(la); bn = point_of(lb);
+            kindn = PR[(size_t)(3 * (k - 1) + 2) * 64];
+            pren = fld_ld(PX + (size_t)(k - 1) * (EW * 64));
+          }
+          if (k >= 2 && k - 2 < np) { la = PR[(size_t)(3 * (k - 2)) * 64]; lb = PR[(size_t)(3 * (k - 2) + 1) * 64]; }
+          Aff<F> r;
+          r.x = F::sqr_impl(lam) - sx;
+          r.y = F::mul_impl(lam, ax - r.x) - ay;
+          if (__builtin_expect(__any(live && kind != MSM_PK_ADD && kind != MSM_PK_DBL), 0)) {  // one of the two as it is, or the identity
+            if (live && kind == MSM_PK_TAKE_A) r = point_of(PR[(size_t)(3 * k) * 64]);
+            if (live && kind == MSM_PK_TAKE_B) r = point_of(PR[(size_t)(3 * k + 1) * 64]);
+            if (live && kind == MSM_PK_INF) r = {F::zero(), F::zero()};
+          }
+          if (live) {
+            uint32_t* p = PT + (size_t)(slot_base + k) * (2 * EW * 64);
+            fld_st(p, r.x); fld_st(p + (size_t)EW * 64, r.y);
+          }
+        }
+      }
+      slot_base += np_max;
+      cnt = j;
+      which ^= 1;
+    }
+    // what is left of every run: the ordinary running sum, flushed as msm_accumulate_kernel flushes
+    if (n0) {
+      const uint32_t* const in = LS + (size_t)which * (2 * tb.cap * 64);
+      MsmRunPlain<GA> acc;
+      uint32_t key = key_first;
+      for (uint32_t i = 0; i < cnt; i++) {
+        const uint32_t k0 = in[(size_t)(2 * i) * 64], l0 = in[(size_t)(2 * i + 1) * 64];
+        if (k0 != key) {
+          if (open_start) { acc.flush(piece_first + (size_t)t * RW); open_start = false; }
+          else acc.flush(buckets + (size_t)key * RW);
+          key = k0;
+        }
+        acc.add(point_of(l0));
+      }
+      const bool open_end = off[key + 1] > end;
+      if (open_end) acc.flush(piece_last + (size_t)t * RW);
+      else if (open_start) acc.flush(piece_first + (size_t)t * RW);
+      else acc.flush(buckets + (size_t)key * RW);
+    }
+  }
+}
+
 // Work-item indexing of the kernels behind the accumulation (pieces, bucket reduction, window combine).  They compute in the
 // lane-split form of the group too: an Fq2 / Fq3 point operation is shared by 2 / 3 adjacent lanes, which divides the latency of
 // these latency-bound levels and the per-lane scratch footprint (9.9 KB per lane for the unsplit Fq3-753 addition: enough to
@@ -686,7 +973,9 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
                                                        const uint32_t* __restrict__ acc_buckets /* what msm_accumulate flushed whole buckets into */,
                                                        uint32_t* __restrict__ buckets, uint32_t big_limit, uint32_t* __restrict__ big_count,
                                                        uint32_t* __restrict__ big_list /* (key, first segment, #segments) */, uint32_t big_cap,
-                                                       uint32_t* __restrict__ seg_list /* (t_lo, t_hi, t_last) */, uint32_t seg_len) {
+                                                       uint32_t* __restrict__ seg_list /* (t_lo, t_hi, t_last) */, uint32_t seg_len,
+                                                       const uint32_t* __restrict__ chunk_dev /* the pair tree's chunk, decided on the device */) {
+  if (chunk_dev) chunk = *chunk_dev;
   typedef typename MsmItems<G>::GA GA;
   typedef typename GA::F F;
   typedef EC<GA> E;
@@ -1052,8 +1341,8 @@ hipError_t msm_precompute(hipStream_t st, uint32_t* pts, uint32_t n, int groups,
 // ------------------------------------------------------------------------------------------------ host driver
 struct MsmWorkspace {
   // device buffers, grown on demand and reused across calls (no allocation on the hot path once warm)
-  void* buf[24] = {nullptr};
-  size_t cap[24] = {0};
+  void* buf[28] = {nullptr};
+  size_t cap[28] = {0};
   const uint32_t* last_err_dev = nullptr;  // device word raised by the last MSM's digit pass when a scalar was not reduced (null: not checked)
   int cus = 0;                             // compute units of the device this workspace lives on (queried on first use)
   hipError_t ensure(int slot, size_t bytes) {
@@ -1065,7 +1354,7 @@ struct MsmWorkspace {
     cap[slot] = want;
     return hipSuccess;
   }
-  void release() { for (int i = 0; i < 24; i++) if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; } }
+  void release() { for (int i = 0; i < 28; i++) if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; } }
 };
 
 struct MsmTimings {  // milliseconds, filled when events are requested
@@ -1073,7 +1362,7 @@ struct MsmTimings {  // milliseconds, filled when events are requested
 };
 
 enum { WS_CNT = 0, WS_OFF, WS_BSUM, WS_SORTED, WS_BUCKETS, WS_PFIRST, WS_PLAST, WS_BIG, WS_BIGSCR, WS_A0, WS_A1, WS_C0, WS_C1, WS_OUT, WS_SCAL,
-       WS_BIGPART, WS_ONES, WS_SLOTS, WS_CUR, WS_ENTRIES, WS_ACCB };
+       WS_BIGPART, WS_ONES, WS_SLOTS, WS_CUR, WS_ENTRIES, WS_ACCB, WS_TLIST, WS_TPAIR, WS_TPREFIX, WS_TPTS };
 
 #define PCD_HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -1104,6 +1393,11 @@ template <class G>
 hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, const uint32_t* scalars_dev, uint32_t n,
                    uint32_t* out_dev, int c_override, uint32_t chunk_override, int sort_mode, MsmTimings* tm,
                    MsmSharedSort* share = nullptr, int share_role = MSM_SHARE_NONE) {
+  // sort_mode: bits 0-3 the sort (pcdhip_msm_set_sort), bits 4-5 the accumulation form (pcdhip_msm_set_accumulate: 0 by size, 1 running
+  // sums, 2 pair tree), bits 8-19 / 20-27 the pair tree's chunk and smallest batch when given
+  const int acc_mode = (sort_mode >> 4) & 3;
+  const uint32_t tree_chunk = ((uint32_t)sort_mode >> 8) & 0xFFFu, tree_min_pairs = ((uint32_t)sort_mode >> 20) & 0xFFu;
+  sort_mode &= 15;
   const bool single_pass = sort_mode == 1;  // pcdhip_msm_set_sort(ctx, 1)
   const uint32_t* bases_dev = bv.dptr;
   typedef typename G::F F;
@@ -1122,12 +1416,25 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   // 40 .. 56, to the value whose wave count fills whole rounds of the chip: a one-wave-per-SIMD kernel that needs 14.4 rounds idles
   // 60 % of the SIMDs during the last one (G1-753 at 2^20: 48 entries = 12.0 rounds, 55.5 -> 53.7 ms)
   pl.chunk = chunk_override ? chunk_override : 40;
-  if (!chunk_override) {
-    int& cus = ws.cus;  // cached per workspace (= per context and stream: no sharing between host threads, right device)
-    if (!cus) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  int& cus = ws.cus;  // cached per workspace (= per context and stream: no sharing between host threads, right device)
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  // the pair-tree form of the accumulation (msm_pair_tree_kernel): long lists of the 753-bit G1 groups.  One chunk per lane of the
+  // resident waves and as many rounds as keep a chunk below MSM_TREE_CHUNK_MAX entries (the scratch areas grow with the chunk)
+  bool use_tree = false;
+  uint32_t tree_cap = 0;
+  const uint32_t* tree_chunk_dev = nullptr;
+  if constexpr (MsmTreeCapable<G>::value) {
+    use_tree = acc_mode == 2 && (uint64_t)bv.n_total * bv.groups < MSM_SCR;
+    if (use_tree) {
+      // (host side: the CAPACITY of a chunk; the chunk itself is chosen on the device, from the actual list length)
+      tree_cap = tree_chunk ? tree_chunk : MSM_TREE_CHUNK_MAX;
+      pl.chunk = tree_cap;
     }
+  }
+  if (!chunk_override && !use_tree) {
     const double slots = (double)cus * 4 * MsmAccWaves<G>::value, per_wave = 64 / AccOf<G>::LANES;
     double best = 1e300;
     for (uint32_t ch = 40; ch <= 56; ch += 2) {
@@ -1257,7 +1564,14 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   }
   // 4. accumulate.  Nothing below waits for the host: grids are sized for the largest possible list (n W entries;
   //    the actual count M = off[nkeys] is read on the device) so the whole MSM is one asynchronous chain of launches.
-  const uint32_t nchunks = (uint32_t)((maxM + pl.chunk - 1) / pl.chunk);
+  uint32_t nchunks = (uint32_t)((maxM + pl.chunk - 1) / pl.chunk);
+  uint32_t tree_grid = 0;
+  if (use_tree) {
+    // persistent waves; at most lanes x rounds chunks whatever the device picks (msm_tree_plan_kernel), or the forced chunk's count
+    // (every SIMD gets a wave as soon as the list allows chunks of 32: a mid-size list is spread thin rather than over few waves)
+    tree_grid = std::min<uint32_t>(tree_chunk ? (nchunks + 63) / 64 : (uint32_t)((maxM / 32 + 63) / 64), (uint32_t)cus * 4);
+    if (!tree_chunk) nchunks = tree_grid * 64 * (uint32_t)((maxM + (uint64_t)tree_grid * 64 * tree_cap - 1) / ((uint64_t)tree_grid * 64 * tree_cap));
+  }
   typedef MsmStored<typename SplitOf<G>::type> Stored;
   constexpr size_t RB = (size_t)Stored::WORDS * 4;  // bytes of a flushed record
   PCD_HIP_TRY(ws.ensure(WS_PFIRST, (size_t)nchunks * RB));
@@ -1283,13 +1597,37 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     constexpr uint32_t per_wave = 64 / AccOf<G>::LANES;  // chunks per workgroup
     const dim3 acc_grid((nchunks + per_wave - 1) / per_wave);
     // (with per-bucket slots both instantiations are queued: the device's overflow flag decides which of them does the work)
-    if (src.slots) hipLaunchKernelGGL((msm_accumulate_kernel<G, false>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast);
-    hipLaunchKernelGGL((msm_accumulate_kernel<G, true>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast);
+    bool launched = false;
+    if constexpr (MsmTreeCapable<G>::value) {
+      if (use_tree) {
+        constexpr int FW = AccOf<G>::type::F::WORDS;
+        const uint32_t grid = tree_grid;
+        MsmTreeBufs tb;
+        tb.cap = tree_cap;
+        tb.phases = 3;
+        uint32_t* chunk_word = big_count + 2;
+        hipLaunchKernelGGL(msm_tree_plan_kernel, dim3(1), dim3(1), 0, st, off, tkeys, grid * 64, tree_cap, tree_chunk, chunk_word);
+        tree_chunk_dev = chunk_word;
+        PCD_HIP_TRY(ws.ensure(WS_TLIST, MsmTreeBufs::list_words(tb.cap) * 4 * grid));
+        PCD_HIP_TRY(ws.ensure(WS_TPAIR, MsmTreeBufs::pair_words(tb.cap) * 4 * grid));
+        PCD_HIP_TRY(ws.ensure(WS_TPREFIX, MsmTreeBufs::prefix_words(tb.cap, FW) * 4 * grid));
+        PCD_HIP_TRY(ws.ensure(WS_TPTS, MsmTreeBufs::pts_words(tb.cap, FW) * 4 * grid));
+        tb.list = (uint32_t*)ws.buf[WS_TLIST]; tb.pairs = (uint32_t*)ws.buf[WS_TPAIR];
+        tb.prefix = (uint32_t*)ws.buf[WS_TPREFIX]; tb.pts = (uint32_t*)ws.buf[WS_TPTS];
+        hipLaunchKernelGGL((msm_pair_tree_kernel<G>), dim3(grid), dim3(64), 0, st, bases_dev, src, off, tkeys, chunk_word, tb,
+                           tree_min_pairs ? tree_min_pairs : MSM_TREE_MIN_PAIRS, acc_buckets, pfirst, plast);
+        launched = true;
+      }
+    }
+    if (!launched) {
+      if (src.slots) hipLaunchKernelGGL((msm_accumulate_kernel<G, false>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast);
+      hipLaunchKernelGGL((msm_accumulate_kernel<G, true>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast);
+    }
   }
   PCD_HIP_TRY(mark(4));
   // 5. pieces
   hipLaunchKernelGGL((msm_fixup_kernel<G>), dim3(MsmItems<G>::grid(tkeys)), dim3(64), 0, st, off, tkeys, pl.chunk, pfirst, plast, acc_buckets, buckets,
-                     big_limit, big_count, big, big_cap, seg_list, seg_len);
+                     big_limit, big_count, big, big_cap, seg_list, seg_len, tree_chunk_dev);
   {
     const uint32_t big_grid = std::min<uint32_t>(seg_cap, 2048);
     PCD_HIP_TRY(ws.ensure(WS_BIGSCR, (size_t)big_grid * 64 * PB));

@@ -228,12 +228,15 @@ struct VmWave {
     }
     bank ^= (uint64_t)progs[3 * pid + 2];
   }
-  // the kernel's script: program ids in order; entries from 0xF0 up select a table entry for the programs that follow
+  // the kernel's script: program ids in order; entries from 0xF0 up select a table entry for the programs that follow, 0xEF inverts
   PCD_DEV void run_script() {
     for (uint32_t i = 0; i < script_len; i++) {
       const uint32_t e = (script[i >> 2] >> (8 * (i & 3))) & 0xFFu;
       if (e >= 0xF0u) bank = (bank & 0xFFFFFFFFull) | ((uint64_t)(e - 0xF0u) << 32);
-      else run((int)e);
+      else if (e == 0xEFu) {  // SCRIPT_INV: the one field inversion of a final exponentiation, by divsteps on one lane
+        if (threadIdx.x == 0) set_reg(G::R_FT1_0, get_reg(G::R_NRM0).inv());
+        __syncthreads();
+      } else run((int)e);
     }
   }
 };

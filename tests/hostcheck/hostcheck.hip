@@ -22,7 +22,7 @@ static void msm_naive(const uint32_t* bases, const uint32_t* scalars, int n, uin
   acc.to_abi(out);
 }
 
-// field-level checks: out[0..] = a*b, a+b, a-b, inv(a), a*17 (mul_small), canonical words of a  (ABI images)
+// field-level checks: out[0..] = a*b, a+b, a-b, inv(a), a*17 (mul_small), canonical words of a, ..., inv_gcd(a) twice  (ABI images)
 template <class P>
 static void field_ops(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   typedef Fp<P> F;
@@ -31,10 +31,12 @@ static void field_ops(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   (x * y).to_abi(out);
   (x + y).to_abi(out + W);
   (x - y).to_abi(out + 2 * W);
-  x.inv().to_abi(out + 3 * W);
+  x.inv_fermat().to_abi(out + 3 * W);
   x.mul_small(17).to_abi(out + 4 * W);
   x.to_canonical_words(out + 5 * W);
   ((x + y + y - x - x).dbl().neg().mul_small(121) * F::from_canonical_words(out + 5 * W)).to_abi(out + 6 * W);
+  x.inv_gcd().to_abi(out + 7 * W);            // the divstep inverse
+  (x + F::one() - F::one()).inv_gcd().to_abi(out + 8 * W);  // ... of another representative of the same value
 }
 extern "C" int hc_field_ops(int field, const uint32_t* a, const uint32_t* b, uint32_t* out) {
   switch (field) {

@@ -66,6 +66,7 @@ struct HostVm {
     for (uint32_t i = 0; i < tb.script_len; i++) {
       const uint32_t e = (tb.script[i >> 2] >> (8 * (i & 3))) & 0xFFu;
       if (e >= 0xF0u) bank = (bank & 0xFFFFFFFFull) | ((uint64_t)(e - 0xF0u) << 32);
+      else if (e == 0xEFu) set_reg(VG::R_FT1_0, A::ld(regs.data(), (uint32_t)VG::R_NRM0).inv());  // SCRIPT_INV (Fp::inv: divsteps)
       else run((int)e);
     }
   }

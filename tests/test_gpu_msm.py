@@ -131,6 +131,48 @@ def test_sort_strategies_and_slot_overflow(co, gpu_ctx, cid, grp, n):
     gpu_ctx.set_precompute(-1)
 
 
+@pytest.mark.parametrize("cid", [2, 3])
+def test_pair_tree_accumulation(co, gpu_ctx, cid):
+    """pcdhip_msm_set_accumulate(2): the 753-bit G1 accumulation as a pair tree of affine additions with shared inversions
+    (msm.hip.h msm_pair_tree_kernel, Fp::inv_gcd) -- forced at small sizes with small chunks so that runs cross chunk edges, levels
+    stop at different depths and every special pair occurs: equal points (doubling), opposite points (the run cancels), flagged
+    infinities, one giant bucket, all scalars equal to one.  Bit-exact against the oracle and against the running-sum form."""
+    grp, fr = 1, co.CURVE_FR[cid]
+    n = 1500
+    pts = co.gen_points(cid, grp, n, seed=90 + cid)
+    w = pts.shape[1] // 2
+    pts[10:20] = pts[9]                       # ten copies of one point ...
+    pts[21] = pts[20]
+    pts[21, w:] = co.fp_op(co.CURVE_FQ[cid], "neg", pts[20:21, w:])[0]   # ... and P next to -P
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[[0, 50, 51, 1499]] = 1
+    cases = {}
+    sc = co.gen_scalars(fr, n, seed=7)
+    sc[9:22] = sc[9]                          # same scalar on the copies and on P, -P: equal / opposite points meet inside a bucket
+    sc[100:700] = 0; sc[100:700, 0] = 5       # 600 entries in one bucket: a run over several chunks
+    sc[50:52] = sc[49]                        # infinities next to a finite point of the same bucket
+    cases["mixed"] = sc
+    cases["witness"] = co.gen_scalars(fr, n, seed=8, dist=1)
+    one = np.zeros_like(sc); one[:, 0] = 1
+    cases["ones"] = one
+    same = np.zeros_like(sc); same[:] = sc[3]
+    cases["one scalar"] = same
+    try:
+        for name, s in cases.items():
+            want = co.to_affine(cid, grp, co.msm(cid, grp, pts, s, inf=inf, nthreads=8))
+            for pre in (-1, 0):
+                gpu_ctx.set_precompute(pre)
+                b = gpu_ctx.bases_upload(cid, grp, pts, inf)
+                for mode, chunk, min_pairs in ((1, 0, 0), (2, 64, 2), (2, 33, 1), (2, 200, 12), (2, 0, 0)):
+                    gpu_ctx.msm_set_accumulate(mode, chunk, min_pairs)
+                    got = co.to_affine(cid, grp, gpu_ctx.msm(b, s))
+                    assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1]), (name, pre, mode, chunk, min_pairs)
+                b.free()
+    finally:
+        gpu_ctx.msm_set_accumulate(0)
+        gpu_ctx.set_precompute(-1)
+
+
 def test_points_sum_and_device_scalars(co, gpu_ctx):
     cid, grp, n = 0, 1, 3000
     fr = co.CURVE_FR[cid]

@@ -54,16 +54,18 @@ def test_field_ops_and_abi_conversion(hc, fid):
     from oracle import pyoracle as O
     f = O.FIELDS[fid]
     rnd = random.Random(5 + fid)
-    cases = [(0, 0), (f.p - 1, f.p - 1), (1, f.p - 1), (f.p - 1, 0), (2, 1)] + [(rnd.randrange(f.p), rnd.randrange(f.p)) for _ in range(60)]
+    cases = [(0, 0), (f.p - 1, f.p - 1), (1, f.p - 1), (f.p - 1, 0), (2, 1), ((f.p - 1) // 2, 3), ((f.p + 1) // 2, 4), (1 << (f.p.bit_length() - 1), 5)]
+    cases += [(1 << k, 7) for k in range(0, f.p.bit_length() - 1, 37)] + [(rnd.randrange(f.p), rnd.randrange(f.p)) for _ in range(60)]
     for a, b in cases:
         A, B = O.pack_fp(f, [a])[0], O.pack_fp(f, [b])[0]
-        out = np.zeros(7 * f.n64, dtype=np.uint64)
+        out = np.zeros(9 * f.n64, dtype=np.uint64)
         assert hc.hc_field_ops(fid, P(A), P(B), P(out)) == 0
-        got = out.reshape(7, f.n64)
+        got = out.reshape(9, f.n64)
         exp = [a * b % f.p, (a + b) % f.p, (a - b) % f.p, pow(a, -1, f.p) if a else 0, a * 17 % f.p]
         assert O.unpack_fp(f, got[:5]) == exp, (a, b)
         assert O.unpack_fp(f, got[5:6], mont=False)[0] == a
         assert O.unpack_fp(f, got[6:7])[0] == ((-(2 * ((a + b + b - a - a) % f.p))) * 121 * a) % f.p
+        assert O.unpack_fp(f, got[7:9]) == [exp[3], exp[3]], a   # Fp::inv_gcd (divsteps) == a^(p-2)
 
 
 @pytest.mark.parametrize("fid", [0, 1, 2, 3])

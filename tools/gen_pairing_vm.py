@@ -33,6 +33,7 @@ LANES = 64
 K_LIN, K_MUL, K_SQR = 0, 1, 2   # (K_SQR: a MUL step whose instructions are all squares: N (N + 1) / 2 + N^2 multiply-adds)
 SP_REG, SP_IN, SP_OUT, SP_TAB = 0, 1, 2, 3   # operand spaces: plain register, state slot (current / other bank), entry `sel` of a table
 SET_SEL = 0xF0   # script entries >= SET_SEL are not programs: they set the table selector to (entry - SET_SEL)
+SCRIPT_INV = 0xEF   # script entry: register ft1_0 <- 1 / register nrm0, by lane 0 (Fp::inv), not a program
 
 
 def params():
@@ -408,20 +409,9 @@ def build(cid):
         P.out_reg(f"cof{2 * j}", cof[j])                # inverse of n_e = cof / nrm
     env.put_reg(P, "v", v, ALL)
 
-    # Fermat inversion of nrm by a sliding window over p - 2: odd powers nrm^1, nrm^3, .. in the registers ft<j>_0 (a table the
-    # script selects from: operand space SP_TAB), then pw <- pw^2 and pw <- pw * table[sel] as the schedule (env.scripts) says
-    P = env.prog("fq_tab")
-    x1 = P.reg("nrm0")
-    P.out_reg("ft1_0", x1)
-    x2 = P.mul([(x1, x1)])
-    cur = x1
-    for j in range(3, 1 << WIN_FQ, 2):
-        cur = P.mul([(cur, x2)])
-        P.out_reg(f"ft{j}_0", cur)
-    P = env.prog("fq_sqr")
-    P.out("pw0", P.mul([(P.state("pw0"), P.state("pw0"))]))
-    P = env.prog("fq_mul")
-    P.out("pw0", P.mul([(P.state("pw0"), P.tab(0, 0))]))
+    # The one field inversion, of nrm0, is not a program: the script entry SCRIPT_INV has lane 0 run Fp::inv (divsteps, fp.hip.h:
+    # ~45 products' worth against the ~940 dependent steps of a sliding window over p - 2) from register nrm0 into register ft1_0,
+    # entry 0 of table 0, which "fq_init" then moves into the state slot pw0.
     P = env.prog("fq_init")
     P.out("pw0", P.tab(0, 0))
 
@@ -472,7 +462,7 @@ def build(cid):
     if env.ate_neg:
         mil.append("negfix")
     env.scripts["miller"] = mil
-    env.scripts["final_exp"] = (["fe_norm", "fq_tab"] + window_schedule(env.p - 2, WIN_FQ, "fq_init", "fq_sqr", "fq_mul") + ["fe_easy", "pow_tab"]
+    env.scripts["final_exp"] = (["fe_norm", ("inv", 0), ("sel", 0), "fq_init", "fe_easy", "pow_tab"]
                                 + window_schedule(env.w0, WIN_POW, "pow_init", "pow_sqr", "pow_mul") + ["fe_last"])
     # which kernel needs which programs (each kernel stages only its own in LDS)
     env.sets = {"miller": ["setup", "dbl", "add", "negfix"],
@@ -481,7 +471,7 @@ def build(cid):
     return env
 
 
-WIN_FQ, WIN_POW = 4, 3
+WIN_FQ, WIN_POW = 1, 3   # (table 0 is one register now: the inverse that SCRIPT_INV leaves there)
 
 
 def window_schedule(e, WIN, init, sqr, mul):
@@ -700,7 +690,9 @@ class Machine:
 
     def run_script(self, name):
         for e in self.env.scripts[name]:
-            if isinstance(e, tuple):
+            if isinstance(e, tuple) and e[0] == "inv":
+                self.set_reg("ft1_0", pow(self.get_reg("nrm0"), self.env.p - 2, self.env.p))
+            elif isinstance(e, tuple):
                 self.sel = e[1]
             else:
                 self.run(e)
@@ -816,8 +808,9 @@ def emit(envs):
                     mask |= 1 << sl
                 progs.append((pname, first, len(steps) - first, mask))
             pid = {pname: i for i, (pname, _, _, _) in enumerate(progs)}
-            assert len(progs) < SET_SEL
-            ids = [(SET_SEL + e[1]) if isinstance(e, tuple) else pid[e] for e in env.scripts[setname] if isinstance(e, tuple) or e in pid]
+            assert len(progs) < SCRIPT_INV
+            ids = [SCRIPT_INV if isinstance(e, tuple) and e[0] == "inv" else (SET_SEL + e[1]) if isinstance(e, tuple) else pid[e]
+                   for e in env.scripts[setname] if isinstance(e, tuple) or e in pid]
             assert len(ids) == len(env.scripts[setname])
             packed = [sum(ids[q + j] << (8 * j) for j in range(4) if q + j < len(ids)) for q in range(0, len(ids), 4)]
             T = f"{nm}_{setname}"
