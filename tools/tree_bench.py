@@ -20,7 +20,7 @@ for cid in (2,):
             sc = co.gen_scalars(fr, n, seed=2, dist=dist)
             sb = ctx.buf_upload(fr, sc)
             ref = None
-            variants = [(1, 0, 0), (2, 0, 0), (2, 0, 255)]
+            variants = [(1, 0, 0), (2, 0, 0), (2, 0, 24), (2, 288, 0)]
             for mode, chunk, mp in variants:
                 ctx.msm_set_accumulate(mode, chunk, mp)
                 got = co.to_affine(cid, 1, ctx.msm(b, sb))
