@@ -146,11 +146,12 @@ int pcdhip_msm_config(pcdhip_ctx* ctx, int window_bits, int chunk);
  * per-bucket slots with an on-device fallback when a bucket overflows; 2 two-pass counting sort with one global
  * atomic per entry (also what small inputs use). */
 int pcdhip_msm_set_sort(pcdhip_ctx* ctx, int mode);
-/* Form of the bucket accumulation.  mode 0 (default): by size -- long lists of the 753-bit G1 groups (>= 6 Mi entries = pairs x
- * windows) run as a PAIR TREE of affine additions with shared inversions (5M + 1S per addition instead of 7M + 4S; msm.hip.h
- * msm_pair_tree_kernel), everything else as running sums; 1: running sums always; 2: the pair tree wherever the group has it
- * (753-bit G1; other groups ignore the setting).  chunk (0 = by size, else 2 .. 4095 entries per lane) and min_pairs (0 = default 12:
- * the smallest batch an inversion is spent on) are tuning and test knobs.  Results are identical in every mode. */
+/* Form of the bucket accumulation.  mode 0 (default) and 1: running sums (Jacobian / XYZZ mixed additions); 2: for the 753-bit G1
+ * groups a PAIR TREE of affine additions whose inversions are shared (5M + 1S per addition instead of 7M + 4S, one divstep inversion per
+ * lane and level; msm.hip.h msm_pair_tree_kernel) -- measured -9 % on the accumulation and -5 % on an MSM of 2^20 uniform scalars,
+ * +5 % on witness-like ones, hence opt-in; other groups ignore the setting.  chunk (0 = by size, else 2 .. 1024 entries
+ * per lane; the per-wave scratch grows with it: ~12 GB for the whole chip at the default cap of 640) and min_pairs (0 = default 12: the
+ * smallest batch an inversion is spent on) are tuning and test knobs.  Results are identical in every mode. */
 int pcdhip_msm_set_accumulate(pcdhip_ctx* ctx, int mode, int chunk, int min_pairs);
 /* Per-stage device time of the last MSM (HIP events on the context's stream), milliseconds:
  * [digits, scan, scatter, accumulate, fixup, tail, horner, total]; enable with on != 0. */

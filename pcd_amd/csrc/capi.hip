@@ -492,7 +492,7 @@ int pcdhip_msm_set_sort(pcdhip_ctx* ctx, int mode) {
   return PCDHIP_OK;
 }
 int pcdhip_msm_set_accumulate(pcdhip_ctx* ctx, int mode, int chunk, int min_pairs) {
-  if (!ctx || mode < 0 || mode > 2 || chunk < 0 || chunk > 4095 || (chunk && chunk < 2) || min_pairs < 0 || min_pairs > 255) return PCDHIP_E_ARG;
+  if (!ctx || mode < 0 || mode > 2 || chunk < 0 || chunk > 1024 || (chunk && chunk < 2) || min_pairs < 0 || min_pairs > 255) return PCDHIP_E_ARG;
   ctx->msm_sort = (ctx->msm_sort & 15) | (mode << 4) | (chunk << 8) | (min_pairs << 20);
   return PCDHIP_OK;
 }
