@@ -165,12 +165,20 @@ def test_groth16_roundtrip(co, gpu_ctx, cid, nc):
     gpu_ctx.groth16_set_assembly(2)  # ... or as chained one-lane products (0, the default, picks one of the two)
     proof4, inf4 = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
     gpu_ctx.groth16_set_assembly(0)
+    # the G1 accumulations as pair trees of affine additions (753-bit curves; the others ignore the mode): five MSM streams, the
+    # shared sort of the assignment feeding tree kernels, chunks small enough that runs cross chunk edges
+    gpu_ctx.msm_set_accumulate(2, 40, 2)
+    try:
+        proof5, inf5 = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
+    finally:
+        gpu_ctx.msm_set_accumulate(0)
     pk.free()
     want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=16)
     assert np.array_equal(proof, want) and np.array_equal(inf, winf)
     assert np.array_equal(proof2, want) and np.array_equal(inf2, winf)
     assert np.array_equal(proof3, want) and np.array_equal(inf3, winf)
     assert np.array_equal(proof4, want) and np.array_equal(inf4, winf)
+    assert np.array_equal(proof5, want) and np.array_equal(inf5, winf)
     pub = np.ascontiguousarray(r.z[1:r.num_inputs])
     assert co.groth16_verify(keys, pub, proof)
     bad = pub.copy()

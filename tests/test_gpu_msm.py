@@ -262,6 +262,7 @@ def test_c_abi_error_behaviour(co, gpu_ctx):
     assert lib.pcdhip_fft(ctx, 0, P(np.zeros((4, 5), dtype=np.uint64)), 18, 0, 0) == -2                # above the 2-adicity
     assert lib.pcdhip_fft_general(ctx, 1, P(np.zeros((7 * 8, 5), dtype=np.uint64)), C.c_size_t(56), 0, 0) == -2  # no 7-subgroup support on the main field
     assert lib.pcdhip_set_precompute(ctx, 1) == -1 and lib.pcdhip_msm_config(ctx, 99, 0) == -1
+    assert lib.pcdhip_msm_set_accumulate(ctx, 3, 0, 0) == -1 and lib.pcdhip_msm_set_accumulate(ctx, 2, 1, 0) == -1 and lib.pcdhip_msm_set_accumulate(ctx, 2, 2000, 0) == -1
     # n = 0 is legal everywhere: the identity
     xy, inf = gpu_ctx.to_affine(0, 1, gpu_ctx.msm(b, sc[:0], n=0))
     assert inf[0] == 1
