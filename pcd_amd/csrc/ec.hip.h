@@ -197,6 +197,13 @@ typedef G2Cfg3<F298B, F298A, PCD_MNT6_298_A_SMALL, PCD_MNT6_298_NR_SMALL, 1, fal
 template <class F> struct LazyCapable { static constexpr bool value = false; };
 template <class P> struct LazyCapable<Fp<P, true>> { static constexpr bool value = (P::N <= 11); };
 
+// extension fields whose XYZZ mixed addition has lazily reduced internals (EC::madd_x_lz2): Fq2 over the inlined 298-bit prime fields
+#ifndef PCD_LAZY_FQ2
+#define PCD_LAZY_FQ2 1
+#endif
+template <class F> struct LazyFq2 { static constexpr bool value = false; };
+template <class P, unsigned NR> struct LazyFq2<Fp2<Fp<P, true>, NR>> { static constexpr bool value = PCD_LAZY_FQ2 && (P::N <= 11); };
+
 // ------------------------------------------------------------------------------------------------ group law
 template <class G>
 struct EC {
@@ -294,6 +301,10 @@ struct EC {
     return {a.X * a.ZZ, a.Y * a.ZZZ, a.ZZ};
   }
   PCD_HD static AccX madd_x(const AccX& p, const A& q) {
+    if constexpr (LazyFq2<F>::value) return madd_x_lz2(p, q);
+    else return madd_x_plain(p, q);
+  }
+  PCD_HD static AccX madd_x_plain(const AccX& p, const A& q) {
     if (q.is_inf()) return p;
     if (p.is_inf()) return {q.x, q.y, F::one(), F::one()};
     const F U2 = q.x * p.ZZ;
@@ -309,6 +320,59 @@ struct EC {
     o.Y = R * (Q - o.X) - p.Y * PPP;
     o.ZZ = p.ZZ * PP;
     o.ZZZ = p.ZZZ * PPP;
+    return o;
+  }
+
+  // ---- the same addition over Fq2 = Fq[u]/(u^2 - nr) of the 298-bit curves with lazily reduced INTERNALS -----------------------------
+  // All four coordinates stay reduced between steps (unlike G1's madd_lz: a coefficient of a product is a0 b0 + nr a1 b1 with nr = 17
+  // or 13, and R'/p = 2^10 of headroom then allows operand bounds with ca cb <= 1024 / (nr + 1) only, i.e. differences may carry 4p of
+  // bias, not 16p), but every addition / subtraction inside a step is limb-wise, the multiplications by the non-residue are a carrying
+  // scale of the operand that is shared by the products using it (6 per step instead of one per product: 10), X3 = R^2 - PPP - 2Q is ONE
+  // reduction of a signed limb sum, and Y3 = R (Q - X3) - Y1 PPP is one four-term dot product per coefficient.  Bounds (multiples of p):
+  //   U2, S2, PP, RR, PPP, Q < 2      P = U2 - X1 + 4 in (2, 6)   R = S2 - Y1 + 4 in (2, 6)   t = Q - X3 + 4 in (2, 6)   Y1' = 4 - Y1 in (2, 4]
+  //   PP.c0 = P0^2 + nr P1^2: 36 (nr + 1) <= 648   Y3.c0 = R0 t0 + nr R1 t1 + Y0' PPP0 + nr Y1' PPP1: (36 + 8) (nr + 1) <= 792
+  // 56 N^2 multiply-adds against 58 N^2, and about 2 500 other instructions against 4 800 (N = 11).
+  typedef typename F::Base B_;
+  template <class FF = F>
+  PCD_HD static AccX madd_x_lz2(const AccX& p, const A& q) {
+    typedef typename B_::Lz L;
+    constexpr int32_t NRV = (int32_t)FF::NONRESIDUE;
+    if (q.is_inf()) return p;
+    if (p.is_inf()) return {q.x, q.y, F::one(), F::one()};
+    auto mulr = [](const L& a0, const L& a1, const L& b0, const L& b1, const L& nb1) {  // (a0 + a1 u)(b0 + b1 u), nb1 = nr b1
+      FF o; o.c0 = B_::lz_dot2(a0, b0, a1, nb1); o.c1 = B_::lz_dot2(a0, b1, a1, b0); return o; };
+    const L zz0 = p.ZZ.c0.lz(), zz1 = p.ZZ.c1.lz(), zzz0 = p.ZZZ.c0.lz(), zzz1 = p.ZZZ.c1.lz();
+    const L nzz1 = B_::lz_scale_carry(zz1, NRV), nzzz1 = B_::lz_scale_carry(zzz1, NRV);
+    const FF U2 = mulr(q.x.c0.lz(), q.x.c1.lz(), zz0, zz1, nzz1);
+    const FF S2 = mulr(q.y.c0.lz(), q.y.c1.lz(), zzz0, zzz1, nzzz1);
+    const L P0 = B_::lz_carry(B_::template lz_sub<0>(U2.c0.lz(), p.X.c0.lz())), P1 = B_::lz_carry(B_::template lz_sub<0>(U2.c1.lz(), p.X.c1.lz()));
+    const L R0 = B_::lz_carry(B_::template lz_sub<0>(S2.c0.lz(), p.Y.c0.lz())), R1 = B_::lz_carry(B_::template lz_sub<0>(S2.c1.lz(), p.Y.c1.lz()));
+    const L nP1 = B_::lz_scale_carry(P1, NRV), nR1 = B_::lz_scale_carry(R1, NRV);
+    FF PP, RR;
+    PP.c0 = B_::lz_dot2(P0, P0, P1, nP1); PP.c1 = B_::lz_mul(B_::lz_shl(P0, 1), P1);
+    RR.c0 = B_::lz_dot2(R0, R0, R1, nR1); RR.c1 = B_::lz_mul(B_::lz_shl(R0, 1), R1);
+    if (PP.is_zero()) return RR.is_zero() ? x_from(dbl(x_to_jac(p))) : x_infinity();  // same x: the same point, or opposite points
+    const L pp0 = PP.c0.lz(), pp1 = PP.c1.lz(), npp1 = B_::lz_scale_carry(pp1, NRV);
+    const FF PPP = mulr(P0, P1, pp0, pp1, npp1);
+    const FF Q = mulr(p.X.c0.lz(), p.X.c1.lz(), pp0, pp1, npp1);
+    AccX o;
+    {  // X3 = R^2 - PPP - 2Q, reduced: one signed limb sum per coefficient
+      int64_t s0[B_::N], s1[B_::N];
+#pragma unroll
+      for (int i = 0; i < B_::N; i++) {
+        s0[i] = (int64_t)RR.c0.v[i] - (int64_t)PPP.c0.v[i] - 2 * (int64_t)Q.c0.v[i];
+        s1[i] = (int64_t)RR.c1.v[i] - (int64_t)PPP.c1.v[i] - 2 * (int64_t)Q.c1.v[i];
+      }
+      o.X.c0 = B_::from_signed_sum(s0, 6);
+      o.X.c1 = B_::from_signed_sum(s1, 6);
+    }
+    const L t0 = B_::lz_carry(B_::template lz_sub<0>(Q.c0.lz(), o.X.c0.lz())), t1 = B_::lz_carry(B_::template lz_sub<0>(Q.c1.lz(), o.X.c1.lz()));
+    const L y0n = B_::template lz_sub<0>(B_::zero().lz(), p.Y.c0.lz()), y1n = B_::template lz_sub<0>(B_::zero().lz(), p.Y.c1.lz());
+    const L ppp0 = PPP.c0.lz(), ppp1 = PPP.c1.lz(), nppp1 = B_::lz_scale_carry(ppp1, NRV);
+    o.Y.c0 = B_::lz_dot4(R0, t0, nR1, t1, y0n, ppp0, y1n, nppp1);
+    o.Y.c1 = B_::lz_dot4(R0, t1, R1, t0, y0n, ppp1, y1n, ppp0);
+    o.ZZ = mulr(zz0, zz1, pp0, pp1, npp1);
+    o.ZZZ = mulr(zzz0, zzz1, ppp0, ppp1, nppp1);
     return o;
   }
 

@@ -404,6 +404,60 @@ struct Fp {
     r.v[N - 1] = (uint32_t)acc;
     return r;
   }
+  // k a with limbs carried back to 28 bits (the top limb takes the rest): what a product needs of "non-residue times coefficient" --
+  // k = 17 on limbs of up to 29 bits does not fit 32 bits limb-wise
+  PCD_HD static Lz lz_scale_carry(const Lz& a, int32_t k) { Lz r; int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) { const int64_t x = (int64_t)a.v[i] * k + c; r.v[i] = (int32_t)((uint32_t)x & MASK); c = x >> 28; }
+    r.v[N - 1] = (int32_t)((int64_t)a.v[N - 1] * k + c);
+    return r; }
+  // (a0 b0 + a1 b1 + a2 b2 + a3 b3) / R' in [0, 2p): the four-term form of lz_dot (one reduction for a sum of two Fq2 products'
+  // coefficient); the sum of the four value-bound products must stay <= 1024 p^2, limb products per column < 2^63 as there
+  PCD_HD static Fp lz_dot4(const Lz& a0, const Lz& b0, const Lz& a1, const Lz& b1, const Lz& a2, const Lz& b2, const Lz& a3, const Lz& b3) {
+    int32_t m[N];
+    int64_t acc = 0;
+    PCD_LZ_WIDE_DECL
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        acc += (int64_t)a0.v[i] * b0.v[k - i]; PCD_LZ_WIDE_MAC(a0.v[i], b0.v[k - i])
+        acc += (int64_t)a1.v[i] * b1.v[k - i]; PCD_LZ_WIDE_MAC(a1.v[i], b1.v[k - i])
+        acc += (int64_t)a2.v[i] * b2.v[k - i]; PCD_LZ_WIDE_MAC(a2.v[i], b2.v[k - i])
+        acc += (int64_t)a3.v[i] * b3.v[k - i]; PCD_LZ_WIDE_MAC(a3.v[i], b3.v[k - i])
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_LZ_WIDE_MAC(m[i], P::mod(k - i)) }
+      m[k] = (int32_t)(((uint32_t)acc * P::INV) & MASK);
+      acc += (int64_t)m[k] * (int32_t)P::mod(0);
+      PCD_LZ_WIDE_MAC(m[k], P::mod(0))
+      PCD_LZ_WIDE_CHECK();
+      acc >>= 28;
+    }
+    Fp r;
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) {
+        acc += (int64_t)a0.v[i] * b0.v[k - i]; PCD_LZ_WIDE_MAC(a0.v[i], b0.v[k - i])
+        acc += (int64_t)a1.v[i] * b1.v[k - i]; PCD_LZ_WIDE_MAC(a1.v[i], b1.v[k - i])
+        acc += (int64_t)a2.v[i] * b2.v[k - i]; PCD_LZ_WIDE_MAC(a2.v[i], b2.v[k - i])
+        acc += (int64_t)a3.v[i] * b3.v[k - i]; PCD_LZ_WIDE_MAC(a3.v[i], b3.v[k - i])
+      }
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_LZ_WIDE_MAC(m[i], P::mod(k - i)) }
+      r.v[k - N] = (uint32_t)acc & MASK;
+      PCD_LZ_WIDE_CHECK();
+      acc >>= 28;
+    }
+    if (acc < 0 || acc >= ((int64_t)1 << 28)) {
+#if defined(PCD_LZ_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+      abort();
+#endif
+    }
+    r.v[N - 1] = (uint32_t)acc;
+    return r;
+  }
   PCD_HD static Fp lz_mul(const Lz& a, const Lz& b) { return lz_dot<1>(a, b, a, b); }
   PCD_HD static Fp lz_dot2(const Lz& a0, const Lz& b0, const Lz& a1, const Lz& b1) { return lz_dot<2>(a0, b0, a1, b1); }
   PCD_HD static Fp lz_sqr(const Lz& a) {
@@ -718,6 +772,7 @@ struct Fp2 {
   typedef typename F::Params Params;
   typedef F Base;
   static constexpr int DEG = 2;
+  static constexpr unsigned NONRESIDUE = NR;
   static constexpr int WORDS = 2 * F::WORDS;
   static constexpr int ABI_WORDS = 2 * F::ABI_WORDS;
   F c0, c1;

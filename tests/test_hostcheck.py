@@ -232,7 +232,7 @@ def test_xyzz_madd_chain(hc, co, cid, grp):
     """EC::madd_x (mixed addition in XYZZ coordinates: the bucket-accumulation step of every group without the lazy form) against the
     Jacobian madd and the oracle, with the doubling branch, a cancellation to infinity and infinity entries in the stream."""
     w = co.point_words(cid, grp)
-    n = 40 if cid < 2 else 14
+    n = (300 if grp == 2 else 40) if cid < 2 else 14   # (MNT4-298 G2: the lazily reduced form, long enough for its bounds to settle)
     pts = co.gen_points(cid, grp, n, seed=41 + cid)
     neg = pts[3].copy()
     deg = w // 2 // co.FIELD_N64[co.CURVE_FQ[cid]]
@@ -241,6 +241,7 @@ def test_xyzz_madd_chain(hc, co, cid, grp):
     seqs = {
         "random": pts,
         "double": np.concatenate([pts[:1], pts[:1], pts[1:8]]),
+        "double_late": np.concatenate([pts[:6], pts[6:7], pts[6:7], pts[7:12]]),   # (acc + P)... the same point twice in a row is NOT a doubling of acc; kept as an ordinary case
         "cancel": np.concatenate([pts[3:4], neg[None], pts[4:10]]),
         "inf": np.concatenate([pts[:3], np.zeros((2, w), dtype=np.uint64), pts[3:9]]),
     }
