@@ -647,8 +647,8 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate, pair-tree form
-// The same stage for the 753-bit G1 groups when the list is long, with AFFINE additions whose inversions are shared (upstream's
-// `batch_addition` idea: ark-ec 0.3 has it in its bucketed `BatchGroupArithmetic` branch; the reference's own MSM does not).  A lane
+// The same stage for the 753-bit G1 groups as an opt-in mode (pcdhip_msm_set_accumulate(ctx, 2, ..); DESIGN.md 4 has the A/B that
+// keeps the running sums the default), with AFFINE additions whose inversions are shared (the reference's MSM has no such form).  A lane
 // owns a chunk of several hundred sorted entries and halves it level by level: neighbours of the same bucket form a pair,
 // P + Q = (l^2 - x1 - x2, l (x1 - x3) - y1) with l = (y2 - y1) / (x2 - x1), and the denominators of ALL the lane's pairs of a level
 // are inverted together -- a running product on the way forth (kept in HBM, lane-interleaved), ONE inversion (Fp::inv_gcd, 45
@@ -659,8 +659,8 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
 // the fix-up pass and everything behind it are unchanged.  Equal points (doubling: denominator 2y), opposite points, operands at
 // infinity and points with x = 0 are classified on the way forth in a branch that is normally skipped.
 // One wave per workgroup, workgroups persistent (a wave walks chunk groups blockIdx.x, + gridDim.x, ...): the scratch areas belong
-// to the resident wave, not to the chunk.  Everything a lane keeps in HBM is indexed [item][word][lane]: a wave's access to "its k-th
-// pair" is one 256-byte line per word.
+// to the resident wave, not to the chunk.  Everything a lane keeps in HBM is indexed [item][piece][lane] (lists: 4-byte pieces, field
+// elements: 16-byte pieces): a wave's access to "its k-th pair" is one contiguous 256-byte / 1-KB block per piece.
 constexpr uint32_t MSM_TREE_CHUNK_MAX = 640, MSM_TREE_MIN_PAIRS = 12;
 constexpr uint32_t MSM_SCR = 0x40000000u;  // item location: slot of the lane's point scratch (else a base entry, MSM_NEG = negated)
 template <class G>
