@@ -234,6 +234,22 @@ struct Fp {
     }
     return r;
   }
+  // Ordering of the cross-lane exchange (lane-split extension fields: a lane reads slots its PARTNERS wrote, and later overwrites a slot
+  // its partners have read).  In HIP's per-thread memory model those are accesses of different threads to the same LDS words, so
+  // without synchronisation the compiler is free to move them past each other; lockstep execution of a wave makes the hardware order
+  // equal to the program order of the ds_ instructions, so all that is needed is that the COMPILER keeps that order: a release /
+  // acquire fence pair at wavefront scope around a wave barrier (a scheduling barrier; no instruction is emitted for either -- LDS
+  // operations of one wave complete in issue order).  PCD_MB_FENCE=0 builds the round-3 code without it (tools/microbench A/B).
+#ifndef PCD_MB_FENCE
+#define PCD_MB_FENCE 1
+#endif
+  PCD_DEV static void mb_sync() {
+#if PCD_MB_FENCE && defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+  }
   __device__ __noinline__ static void mb_mul_call(MbPtr mb) { mb_put(mb, 0, mul_impl(mb_get(mb, 0), mb_get(mb, 1))); }
   __device__ __noinline__ static void mb_sqr_call(MbPtr mb) { mb_put(mb, 0, sqr_impl(mb_get(mb, 0))); }
   PCD_DEV static Fp mb_mul(const Fp& a, const Fp& b) {
@@ -871,8 +887,10 @@ struct Fp2S {
   __device__ __noinline__ static void mb_mul_call(typename F::MbPtr mb) {
     const unsigned l = threadIdx.x, pl = l ^ 1u;
     const bool odd = (l & 1u) != 0;
+    F::mb_sync();  // the partner's posts (made by the caller) are ordered before this lane's reads of them
     const F a0 = F::mb_get_lane(mb, 0, odd ? pl : l), a1 = F::mb_get_lane(mb, 0, odd ? l : pl);
     const F b = F::mb_get_lane(mb, 1, l), pb = F::mb_get_lane(mb, 1, pl);
+    F::mb_sync();  // every lane of the pair has read both slots before either posts its result over slot 0
     const F y = a1.mul_small_var(odd ? 1u : NR);  // lane 0: nr a1;  lane 1: a1
     F o;
     F::template dot_impl<2>(o, a0, b, y, pb, a0, a0);
@@ -882,7 +900,9 @@ struct Fp2S {
     const typename F::MbPtr mb = F::mb_base();
     F::mb_put(mb, 0, c); F::mb_put(mb, 1, b.c);
     mb_mul_call(mb);
-    return {F::mb_get(mb, 0)};
+    F r = F::mb_get(mb, 0);
+    F::mb_sync();  // (the next posts into these slots stay behind the partners' reads of this result round)
+    return {r};
   }
   PCD_DEV static Fp2S load(const uint32_t* p) { return {F::load(p + parity() * F::WORDS)}; }
   PCD_DEV void store(uint32_t* p) const { c.store(p + parity() * F::WORDS); }
@@ -1016,9 +1036,11 @@ struct Fp3S {
     // reads lane 61's triple instead of indexing past the 64 slots)
     const unsigned l = threadIdx.x & 63u, k = l % 3u, l0 = l == 63u ? 60u : l - k;
     const unsigned k1 = k == 2 ? 0 : k + 1, k2 = k == 0 ? 2 : k - 1;    // (k + 1) mod 3, (k + 2) mod 3
+    F::mb_sync();  // the partners' posts (made by the caller) are ordered before this lane's reads of them
     const F a = F::mb_get_lane(mb, 0, l), an = F::mb_get_lane(mb, 0, l0 + k1), an2 = F::mb_get_lane(mb, 0, l0 + k2);
     // own a_k meets b_0, a_(k+1) meets b_2, a_(k+2) meets b_1 on every lane (the lane formulas above)
     const F y1 = F::mb_get_lane(mb, 1, l0), y2 = F::mb_get_lane(mb, 1, l0 + 2), y3 = F::mb_get_lane(mb, 1, l0 + 1);
+    F::mb_sync();  // every lane of the triple has read all six slots before any posts its result over slot 0
     const F x2 = an.mul_small_var(k < 2 ? NR : 1u), x3 = an2.mul_small_var(k == 0 ? NR : 1u);
     F o;
     F::template dot_impl<3>(o, a, y1, x2, y2, x3, y3);
@@ -1027,7 +1049,9 @@ struct Fp3S {
   __device__ __noinline__ static void mb_sqr_call(typename F::MbPtr mb) {
     const unsigned l = threadIdx.x & 63u, k = l % 3u, l0 = l == 63u ? 60u : l - k;
     const unsigned k1 = k == 2 ? 0 : k + 1, k2 = k == 0 ? 2 : k - 1;
+    F::mb_sync();
     const F a = F::mb_get_lane(mb, 0, l), an = F::mb_get_lane(mb, 0, l0 + k1), an2 = F::mb_get_lane(mb, 0, l0 + k2);
+    F::mb_sync();
     //   lane 0:  a0 a0 + (2 nr a1) a2      lane 1:  (2 a0) a1 + (nr a2) a2      lane 2:  a1 a1 + (2 a0) a2
     const F x1 = sel(k == 0, a, an2).mul_small_var(k == 1 ? 2u : 1u);
     const F y1 = sel(k == 2, an2, a);
@@ -1041,13 +1065,17 @@ struct Fp3S {
     const typename F::MbPtr mb = F::mb_base();
     F::mb_put(mb, 0, c); F::mb_put(mb, 1, b.c);
     mb_mul_call(mb);
-    return {F::mb_get(mb, 0)};
+    F r = F::mb_get(mb, 0);
+    F::mb_sync();  // (the next posts into these slots stay behind the partners' reads of this result round)
+    return {r};
   }
   PCD_DEV Fp3S mb_sqr() const {
     const typename F::MbPtr mb = F::mb_base();
     F::mb_put(mb, 0, c);
     mb_sqr_call(mb);
-    return {F::mb_get(mb, 0)};
+    F r = F::mb_get(mb, 0);
+    F::mb_sync();
+    return {r};
   }
   PCD_DEV Fp3S sqr() const {
     if constexpr (F::MAILBOX) return mb_sqr();

@@ -953,11 +953,18 @@ struct MsmItems {
 //  use for the 753-bit groups: with this kernel's shape -- one item, both operands finite -- the mailbox form of the Fq3-753 addition
 //  returns one wrong limb of Y (localised with tools/probe_fq3_tail.py: "ones and 257"; every other kernel and every other case is
 //  exact in both forms, also with every item slot of the wave kept active here) -- a code-generation problem this sidesteps)
+#ifndef PCD_SINGLE_ITEM_PLAIN
+#define PCD_SINGLE_ITEM_PLAIN 0  // 1: the two single-item kernels (this one, msm_horner_kernel) in the plain lane-split form as in round 3
+#endif
+template <class G> struct MsmSingleItem {
+  typedef typename std::conditional<PCD_SINGLE_ITEM_PLAIN != 0, typename SplitOf<G>::type, typename SplitOfTail<G>::type>::type GA;
+  static constexpr int LANES = PCD_SINGLE_ITEM_PLAIN != 0 ? SplitOf<G>::LANES : SplitOfTail<G>::LANES;
+};
 template <class G>
 __global__ void __launch_bounds__(64) msm_merge_ones_kernel(uint32_t* __restrict__ buckets, uint32_t ones_key) {
-  typedef typename SplitOf<G>::type GA;
+  typedef typename MsmSingleItem<G>::GA GA;
   typedef typename GA::F F;
-  if (blockIdx.x != 0 || threadIdx.x >= SplitOf<G>::LANES) return;
+  if (blockIdx.x != 0 || threadIdx.x >= MsmSingleItem<G>::LANES) return;
   Jac<F> a = Jac<F>::load(buckets + (size_t)1 * Jac<F>::WORDS);
   Jac<F> b = Jac<F>::load(buckets + (size_t)ones_key * Jac<F>::WORDS);
   EC<GA>::add(a, b).store(buckets + (size_t)1 * Jac<F>::WORDS);
@@ -1240,11 +1247,11 @@ __global__ void __launch_bounds__(64 * MSM_FUSED_WAVES) msm_tail_fused_kernel(co
 // total = sum_w 2^(c w) V_w, V_w = C[w * strideC];  plus `extra` points added at the end
 template <class G>
 __global__ void __launch_bounds__(64) msm_horner_kernel(const uint32_t* __restrict__ C, size_t strideC, int W, int c, uint32_t* __restrict__ out) {
-  typedef typename SplitOf<G>::type GA;  // (one item: the plain lane-split form, like msm_merge_ones_kernel)
+  typedef typename MsmSingleItem<G>::GA GA;
   typedef typename GA::F F;
   typedef EC<GA> E;
   constexpr int PW = Jac<F>::WORDS;
-  if (blockIdx.x != 0 || threadIdx.x >= SplitOf<G>::LANES) return;
+  if (blockIdx.x != 0 || threadIdx.x >= MsmSingleItem<G>::LANES) return;
   Jac<F> total = Jac<F>::load(C + (size_t)(W - 1) * strideC * PW);
   for (int w = W - 2; w >= 0; w--) {
     for (int d = 0; d < c; d++) total = E::dbl(total);

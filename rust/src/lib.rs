@@ -16,6 +16,8 @@ use ark_std::rand::{CryptoRng, RngCore};
 pub mod ffi;
 pub mod marshal;
 pub mod prover;
+#[cfg(feature = "s2")]
+pub mod s2;
 
 /// Curves the library supports.  `GroupAffine` exposes its coordinates only on the concrete type, so each curve says how its
 /// points turn into C-ABI limbs (x || y, extension coefficients c0, c1 (, c2) in order) and back.
@@ -30,6 +32,9 @@ pub trait HipCurve: PairingEngine {
     fn push_g2(p: &Self::G2Affine, xy: &mut Vec<u64>, inf: &mut Vec<u8>);
     fn g1_from(xy: &[u64], inf: bool) -> Self::G1Affine;
     fn g2_from(xy: &[u64], inf: bool) -> Self::G2Affine;
+    /// the library's Jacobian X || Y || Z (Z = 0: the identity) as the group's projective type (seam S2: an MSM result)
+    fn g1_projective(xyz: &[u64]) -> Self::G1Projective;
+    fn g2_projective(xyz: &[u64]) -> Self::G2Projective;
 }
 
 macro_rules! impl_hip_curve {
@@ -64,6 +69,21 @@ macro_rules! impl_hip_curve {
                 $( x.$c = next(); )+
                 $( y.$c = next(); )+
                 $krate::G2Affine::new(x, y, false)
+            }
+            fn g1_projective(w: &[u64]) -> Self::G1Projective {
+                let l = $limbs;
+                $krate::G1Projective::new(marshal::fp_from_limbs(&w[..l]), marshal::fp_from_limbs(&w[l..2 * l]), marshal::fp_from_limbs(&w[2 * l..3 * l]))
+            }
+            fn g2_projective(w: &[u64]) -> Self::G2Projective {
+                let l = $limbs;
+                let mut k = 0usize;
+                let mut next = || { let v = marshal::fp_from_limbs(&w[k * l..(k + 1) * l]); k += 1; v };
+                let mut x = <$krate::G2Affine as ark_ec::AffineCurve>::BaseField::zero();
+                let (mut y, mut z) = (x, x);
+                $( x.$c = next(); )+
+                $( y.$c = next(); )+
+                $( z.$c = next(); )+
+                $krate::G2Projective::new(x, y, z)
             }
         }
     };
@@ -144,6 +164,11 @@ impl<E: HipCurve> SNARK<E::Fr> for HipGroth16<E> {
         Groth16::<E>::verify_with_processed_vk(pvk, x, proof)
     }
 }
+
+/// `ECCyclePCD<.., IC>: CircuitSpecificSetupPCD` is bounded on `IC::MainSNARK: CircuitSpecificSetupSNARK<MainField>` and
+/// `IC::HelpSNARK: CircuitSpecificSetupSNARK<HelpField>` (/root/reference src/ec_cycle_pcd/mod.rs:248-254).  The trait's one
+/// method, `setup`, has a default body that calls `SNARK::circuit_specific_setup` -- the marker impl is all it takes.
+impl<E: HipCurve> CircuitSpecificSetupSNARK<E::Fr> for HipGroth16<E> {}
 
 /// `ECCyclePCDConfig::{MainSNARKGadget, HelpSNARKGadget}` must implement `SNARKGadget<F, ConstraintF, ThatSNARK>`
 /// (mod.rs:31-32) and upstream's gadget is implemented for `Groth16<E>` specifically; this newtype implements it for

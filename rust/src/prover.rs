@@ -14,43 +14,57 @@ use std::os::raw::c_int;
 use std::sync::Mutex;
 
 /// One library context per process and device list (PCDHIP_DEVICES="0,1,..": all of them serve every proof, sharded by point
-/// range; default "0"); device keys are cached next to it.  A key is identified by a digest of its verifying key plus the sizes
-/// of its queries -- never by its address (a dropped key's address can be reused by a different key).
-struct DeviceKey { digest: [u8; 32], curve: u32, handle: *mut ffi::pcdhip_g16_pk, has_r1cs: bool }
+/// range; default "0"); device keys are cached next to it.  A key is identified by its IDENTITY BYTES -- the compressed
+/// serialisation of its verifying key plus the lengths of its queries -- never by its address (a dropped key's address can be
+/// reused by a different key) and never by a digest alone: the digest (FNV-1a, not collision resistant) only nominates a cache
+/// entry, the hit is confirmed by comparing the identity bytes in full (a colliding key registered first must not
+/// capture later lookups -- the hit decides which key a proof is made or checked under).
+pub(crate) struct DeviceKey { digest: [u8; 32], ident: Vec<u8>, curve: u32, handle: *mut ffi::pcdhip_g16_pk, has_r1cs: bool, last_use: u64 }
 /// a prepared verifying key on the device (`pcdhip_process_vk`: e(alpha, beta), the negated gamma / delta, the window tables of
-/// gamma_abc_g1), kept for as long as the process lives: a PCD verifies every message under the same key
-struct DeviceVk { digest: [u8; 32], curve: u32, handle: *mut ffi::pcdhip_pvk }
-struct Device { ctx: *mut ffi::pcdhip_ctx, keys: Vec<DeviceKey>, vks: Vec<DeviceVk> }
+/// gamma_abc_g1): a PCD verifies every message under the same key, so it is kept -- up to `MAX_CACHED_KEYS` of them, the least
+/// recently used one is released with `pcdhip_pvk_free` when another arrives
+pub(crate) struct DeviceVk { digest: [u8; 32], ident: Vec<u8>, curve: u32, handle: *mut ffi::pcdhip_pvk, last_use: u64 }
+pub(crate) struct Device {
+    pub(crate) ctx: *mut ffi::pcdhip_ctx, keys: Vec<DeviceKey>, vks: Vec<DeviceVk>, pub(crate) clock: u64,
+    #[cfg(feature = "s2")] pub(crate) bases: Vec<crate::s2::Resident>,
+}
 unsafe impl Send for Device {}
 static DEVICE: Mutex<Option<Device>> = Mutex::new(None);
+/// proving keys / prepared verifying keys kept resident at most (a PCD has two of each; a proving key with its window-shifted
+/// copies is gigabytes of HBM)
+pub const MAX_CACHED_KEYS: usize = 8;
 
-fn with_device<T>(f: impl FnOnce(&mut Device) -> Result<T, Error>) -> Result<T, Error> {
+pub(crate) fn with_device<T>(f: impl FnOnce(&mut Device) -> Result<T, Error>) -> Result<T, Error> {
     let mut guard = DEVICE.lock().unwrap();
     if guard.is_none() {
         let ids: Vec<c_int> = std::env::var("PCDHIP_DEVICES").unwrap_or_else(|_| "0".into())
             .split(',').filter_map(|t| t.trim().parse().ok()).collect();
         let mut ctx = core::ptr::null_mut();
         ffi::check(unsafe { ffi::pcdhip_init_devices(ids.as_ptr(), ids.len() as c_int, &mut ctx) })?;
-        *guard = Some(Device { ctx, keys: Vec::new(), vks: Vec::new() });
+        *guard = Some(Device { ctx, keys: Vec::new(), vks: Vec::new(), clock: 0, #[cfg(feature = "s2")] bases: Vec::new() });
     }
     f(guard.as_mut().unwrap())
 }
 
-/// Digest of what identifies a proving key: its verifying key (compressed serialisation) and the lengths of its queries.
-fn key_digest<E: HipCurve>(pk: &ProvingKey<E>) -> [u8; 32] {
+/// FNV-1a, four lanes: a cache NOMINATOR, not an identity (see `DeviceKey`)
+fn digest_of(bytes: &[u8]) -> [u8; 32] {
+    let mut out = [0u8; 32];
+    for lane in 0..4u64 {
+        let mut h: u64 = 0xcbf29ce484222325 ^ lane.wrapping_mul(0x9e3779b97f4a7c15);
+        for b in bytes { h ^= *b as u64; h = h.wrapping_mul(0x100000001b3); }
+        out[lane as usize * 8..][..8].copy_from_slice(&h.to_le_bytes());
+    }
+    out
+}
+
+/// What identifies a proving key: its verifying key (compressed serialisation) and the lengths of its queries.
+fn key_ident<E: HipCurve>(pk: &ProvingKey<E>) -> Vec<u8> {
     let mut bytes = Vec::new();
     pk.vk.serialize(&mut bytes).expect("serialising into a Vec cannot fail");
     for n in &[pk.a_query.len(), pk.b_g1_query.len(), pk.b_g2_query.len(), pk.h_query.len(), pk.l_query.len()] {
         bytes.extend_from_slice(&(*n as u64).to_le_bytes());
     }
-    // FNV-1a, four lanes: a cache key, not a security boundary (a collision would need two keys with equal verifying keys)
-    let mut out = [0u8; 32];
-    for lane in 0..4u64 {
-        let mut h: u64 = 0xcbf29ce484222325 ^ lane.wrapping_mul(0x9e3779b97f4a7c15);
-        for b in &bytes { h ^= *b as u64; h = h.wrapping_mul(0x100000001b3); }
-        out[lane as usize * 8..][..8].copy_from_slice(&h.to_le_bytes());
-    }
-    out
+    bytes
 }
 
 fn pack_g1<E: HipCurve>(pts: &[E::G1Affine]) -> (Vec<u64>, Vec<u8>) {
@@ -68,8 +82,19 @@ fn pack_g2<E: HipCurve>(pts: &[E::G2Affine]) -> (Vec<u64>, Vec<u8>) {
 
 /// Upload `pk` (once per key: the library also builds its window-shifted copies) and return the cached handle.
 fn device_key<E: HipCurve>(dev: &mut Device, pk: &ProvingKey<E>, num_vars: usize, num_inputs: usize, domain: usize) -> Result<usize, Error> {
-    let digest = key_digest::<E>(pk);
-    if let Some(i) = dev.keys.iter().position(|k| k.digest == digest && k.curve == E::CURVE_ID) { return Ok(i); }
+    let ident = key_ident::<E>(pk);
+    let digest = digest_of(&ident);
+    dev.clock += 1;
+    let now = dev.clock;
+    if let Some(i) = dev.keys.iter().position(|k| k.digest == digest && k.curve == E::CURVE_ID && k.ident == ident) {
+        dev.keys[i].last_use = now;
+        return Ok(i);
+    }
+    if dev.keys.len() >= MAX_CACHED_KEYS {
+        let victim = dev.keys.iter().enumerate().min_by_key(|(_, k)| k.last_use).map(|(i, _)| i).unwrap();
+        let old = dev.keys.swap_remove(victim);
+        unsafe { ffi::pcdhip_g16_pk_free(dev.ctx, old.handle) };
+    }
     let one = |p: &E::G1Affine| pack_g1::<E>(core::slice::from_ref(p)).0;
     let one2 = |p: &E::G2Affine| pack_g2::<E>(core::slice::from_ref(p)).0;
     let (alpha, beta1, delta1) = (one(&pk.vk.alpha_g1), one(&pk.beta_g1), one(&pk.delta_g1));
@@ -89,7 +114,7 @@ fn device_key<E: HipCurve>(dev: &mut Device, pk: &ProvingKey<E>, num_vars: usize
     };
     let mut handle = core::ptr::null_mut();
     ffi::check(unsafe { ffi::pcdhip_g16_pk_upload(dev.ctx, &host, &mut handle) })?;
-    dev.keys.push(DeviceKey { digest, curve: E::CURVE_ID, handle, has_r1cs: false });
+    dev.keys.push(DeviceKey { digest, ident, curve: E::CURVE_ID, handle, has_r1cs: false, last_use: now });
     Ok(dev.keys.len() - 1)
 }
 
@@ -177,29 +202,29 @@ pub fn verify_batch<E: HipCurve>(
     with_device(|dev| {
         let one = |p: &E::G1Affine| pack_g1::<E>(core::slice::from_ref(p)).0;
         let one2 = |p: &E::G2Affine| pack_g2::<E>(core::slice::from_ref(p)).0;
-        // the prepared key is made once per verifying key (digest of its compressed serialisation) and kept: `process_vk` costs a
-        // pairing and the window tables, a prepared verification 5 ms (MNT4-298) / 31 ms (MNT4-753) for one proof or sixty-four
-        let digest = {
-            let mut bytes = Vec::new();
-            vk.serialize(&mut bytes).expect("serialising into a Vec cannot fail");
-            let mut out = [0u8; 32];
-            for lane in 0..4u64 {
-                let mut h: u64 = 0xcbf29ce484222325 ^ lane.wrapping_mul(0x9e3779b97f4a7c15);
-                for b in &bytes { h ^= *b as u64; h = h.wrapping_mul(0x100000001b3); }
-                out[lane as usize * 8..][..8].copy_from_slice(&h.to_le_bytes());
-            }
-            out
-        };
-        let pvk = match dev.vks.iter().find(|k| k.digest == digest && k.curve == E::CURVE_ID) {
-            Some(k) => k.handle,
+        // the prepared key is made once per verifying key and kept: `process_vk` costs a pairing and the window tables, a prepared
+        // verification 5 ms (MNT4-298) / 24 ms (MNT4-753) for one proof or sixty-four.  Identity = the compressed serialisation
+        // of the key, compared IN FULL on a digest hit.
+        let mut ident = Vec::new();
+        vk.serialize(&mut ident).expect("serialising into a Vec cannot fail");
+        let digest = digest_of(&ident);
+        dev.clock += 1;
+        let now = dev.clock;
+        let pvk = match dev.vks.iter_mut().find(|k| k.digest == digest && k.curve == E::CURVE_ID && k.ident == ident) {
+            Some(k) => { k.last_use = now; k.handle }
             None => {
+                if dev.vks.len() >= MAX_CACHED_KEYS {
+                    let victim = dev.vks.iter().enumerate().min_by_key(|(_, k)| k.last_use).map(|(i, _)| i).unwrap();
+                    let old = dev.vks.swap_remove(victim);
+                    unsafe { ffi::pcdhip_pvk_free(dev.ctx, old.handle) };
+                }
                 let (abc, abc_inf) = pack_g1::<E>(&vk.gamma_abc_g1);
                 let mut pvk = core::ptr::null_mut();
                 ffi::check(unsafe {
                     ffi::pcdhip_process_vk(dev.ctx, E::CURVE_ID as c_int, one(&vk.alpha_g1).as_ptr(), one2(&vk.beta_g2).as_ptr(), one2(&vk.gamma_g2).as_ptr(),
                                            one2(&vk.delta_g2).as_ptr(), abc.as_ptr(), abc_inf.as_ptr(), vk.gamma_abc_g1.len(), &mut pvk)
                 })?;
-                dev.vks.push(DeviceVk { digest, curve: E::CURVE_ID, handle: pvk });
+                dev.vks.push(DeviceVk { digest, ident, curve: E::CURVE_ID, handle: pvk, last_use: now });
                 pvk
             }
         };

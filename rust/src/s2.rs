@@ -1,0 +1,161 @@
+//! Seam S2 (Marlin / GM17 / anything that calls ark-ec and ark-poly directly: /root/reference tests/mnt4_marlin.rs:72-75,
+//! tests/mnt4_gm17.rs): the CONCRETE side of the two type-erased hooks the `ark-ec` / `ark-poly` forks expose
+//! (`rust/s2_patch/ark-ec/src/msm/hook.rs`, `rust/s2_patch/ark-poly/src/domain/hook.rs`).
+//!
+//! Dependency direction (checked by tools/check_rust_boundary.py): the forks know no curve crate; THIS crate depends on the forks
+//! and on the four curve crates, recognises the eight affine types / four scalar fields by `TypeId`, marshals through their public
+//! fields and calls libpcdhip.so.  `install()` registers both hooks; a program that wants the S2 seam calls it once before proving
+//! (first line of the test's `main`, or of `ark-pcd`'s `universal_setup` caller).  Feature `s2` (needs the forks via
+//! `[patch."https://github.com/arkworks-rs/algebra"]`); without it this module is not compiled and the crate builds against
+//! unmodified upstream.
+//!
+//! Source only (no Rust toolchain in the build container); the C-ABI call sequence made here -- ONE upload of a base vector, MSMs
+//! over prefixes of it, in-place transforms of host vectors -- is what tests/c_driver/driver.c runs from plain C against the oracle.
+use crate::ffi;
+use crate::marshal;
+use crate::prover::{with_device, Device};
+use crate::HipCurve;
+use ark_ec::AffineCurve;
+use ark_ff::PrimeField;
+use core::any::TypeId;
+use std::os::raw::c_int;
+
+/// below this many pairs the PCIe round trip costs more than the CPU
+pub const MIN_PAIRS: usize = 1 << 12;
+/// below this size a transform stays on the CPU (the vector crosses PCIe both ways)
+pub const MIN_LOG_N: u32 = 14;
+/// resident base vectors kept at most (least recently used goes first; its device memory is released with `pcdhip_bases_free`)
+pub const MAX_RESIDENT: usize = 16;
+
+/// A base vector resident on the device.  `running[i]` = digest of the points 0 ..= i, so a call on a PREFIX of a resident vector
+/// (KZG: `powers_of_g[..deg + 1]`) is recognised by content and served as `pcdhip_msm(handle, 0, .., n)`.  The digest only
+/// NOMINATES a candidate; a hit is confirmed by comparing the packed limbs of the call's bases with the copy kept here (`xy`,
+/// `inf`: what was uploaded), so a digest collision cannot alias two keys.
+pub(crate) struct Resident {
+    curve: u32, group: c_int, n: usize, words: usize,
+    running: Vec<[u64; 2]>, xy: Vec<u64>, inf: Vec<u8>,
+    handle: *mut ffi::pcdhip_bases, last_use: u64,
+}
+
+/// two FNV-1a lanes over every limb and flag, point after point
+fn running_digest(xy: &[u64], inf: &[u8], words: usize) -> Vec<[u64; 2]> {
+    let mut h = [0xcbf29ce484222325u64, 0x84222325cbf29ce4u64];
+    let mut out = Vec::with_capacity(inf.len());
+    for (i, flag) in inf.iter().enumerate() {
+        for (j, w) in xy[i * words..(i + 1) * words].iter().enumerate() {
+            let k = j & 1;
+            h[k] ^= *w;
+            h[k] = h[k].wrapping_mul(0x100000001b3);
+        }
+        h[0] ^= *flag as u64;
+        h[0] = h[0].wrapping_mul(0x100000001b3);
+        out.push(h);
+    }
+    out
+}
+
+/// `pcdhip_msm` over (a prefix of) a resident vector; uploads the vector on first sight.  `None` = let upstream run.
+fn msm_packed(dev: &mut Device, curve: u32, group: c_int, words: usize, xy: Vec<u64>, inf: Vec<u8>, scalars: &[u64], out_words: usize) -> Option<Vec<u64>> {
+    let n = inf.len();
+    let running = running_digest(&xy, &inf, words);
+    let d = running[n - 1];
+    dev.clock += 1;
+    let now = dev.clock;
+    let hit = dev.bases.iter().position(|r| {
+        r.curve == curve && r.group == group && r.n >= n && r.running[n - 1] == d && r.xy[..n * words] == xy[..] && r.inf[..n] == inf[..]
+    });
+    let idx = match hit {
+        Some(i) => i,
+        None => {
+            if dev.bases.len() >= MAX_RESIDENT {
+                let (victim, _) = dev.bases.iter().enumerate().min_by_key(|(_, r)| r.last_use)?;
+                let old = dev.bases.swap_remove(victim);
+                unsafe { ffi::pcdhip_bases_free(dev.ctx, old.handle) };
+            }
+            let mut h = core::ptr::null_mut();
+            if unsafe { ffi::pcdhip_bases_upload(dev.ctx, curve as c_int, group, xy.as_ptr(), inf.as_ptr(), n, &mut h) } != 0 { return None; }
+            dev.bases.push(Resident { curve, group, n, words, running, xy, inf, handle: h, last_use: now });
+            dev.bases.len() - 1
+        }
+    };
+    dev.bases[idx].last_use = now;
+    debug_assert_eq!(dev.bases[idx].words, words);
+    let mut out = vec![0u64; out_words];
+    if unsafe { ffi::pcdhip_msm(dev.ctx, dev.bases[idx].handle, 0, scalars.as_ptr(), n, out.as_mut_ptr()) } != 0 { return None; }
+    Some(out)
+}
+
+fn flat_scalars<B: AsRef<[u64]>>(s: &[B], n: usize, limbs: usize) -> Vec<u64> {
+    let mut sc = Vec::with_capacity(n * limbs);
+    for b in &s[..n] { sc.extend_from_slice(b.as_ref()); }   // `BigInteger`s: canonical limbs, what upstream passes and pcdhip_msm takes
+    sc
+}
+
+fn run_g1<E: HipCurve>(bases: &[E::G1Affine], scalars: &[<E::Fr as PrimeField>::BigInt]) -> Option<E::G1Projective> {
+    let n = bases.len().min(scalars.len());
+    if n < MIN_PAIRS { return None; }
+    let (mut xy, mut inf) = (Vec::with_capacity(n * 2 * E::FQ_LIMBS), Vec::with_capacity(n));
+    for p in &bases[..n] { E::push_g1(p, &mut xy, &mut inf); }
+    let sc = flat_scalars(scalars, n, E::FQ_LIMBS);   // Fr and Fq of a cycle curve have the same limb count
+    let out = with_device(|dev| Ok(msm_packed(dev, E::CURVE_ID, 1, 2 * E::FQ_LIMBS, xy, inf, &sc, 3 * E::FQ_LIMBS))).ok()??;
+    Some(E::g1_projective(&out))
+}
+fn run_g2<E: HipCurve>(bases: &[E::G2Affine], scalars: &[<E::Fr as PrimeField>::BigInt]) -> Option<E::G2Projective> {
+    let n = bases.len().min(scalars.len());
+    if n < MIN_PAIRS { return None; }
+    let w = 2 * E::G2_DEG * E::FQ_LIMBS;
+    let (mut xy, mut inf) = (Vec::with_capacity(n * w), Vec::with_capacity(n));
+    for p in &bases[..n] { E::push_g2(p, &mut xy, &mut inf); }
+    let sc = flat_scalars(scalars, n, E::FQ_LIMBS);
+    let out = with_device(|dev| Ok(msm_packed(dev, E::CURVE_ID, 2, w, xy, inf, &sc, 3 * E::G2_DEG * E::FQ_LIMBS))).ok()??;
+    Some(E::g2_projective(&out))
+}
+
+/// The registered `ark_ec::msm::hook::MsmHook`.  `affine` says which of the eight types the erased pointers are.
+unsafe fn msm_hook(affine: TypeId, bases: *const u8, n_bases: usize, scalars: *const u8, n_scalars: usize, out: *mut u8) -> bool {
+    macro_rules! route {
+        ($engine:ty, $aff:ty, $run:ident) => {
+            if affine == TypeId::of::<$aff>() {
+                // sound: `affine` is the TypeId of the slice element at the (only) call site, ark_ec::msm::hook::try_hook::<G>
+                let b = core::slice::from_raw_parts(bases as *const $aff, n_bases);
+                let s = core::slice::from_raw_parts(scalars as *const <<$aff as AffineCurve>::ScalarField as PrimeField>::BigInt, n_scalars);
+                return match $run::<$engine>(b, s) {
+                    Some(r) => { core::ptr::write(out as *mut <$aff as AffineCurve>::Projective, r); true }
+                    None => false,
+                };
+            }
+        };
+    }
+    route!(ark_mnt4_298::MNT4_298, ark_mnt4_298::G1Affine, run_g1); route!(ark_mnt4_298::MNT4_298, ark_mnt4_298::G2Affine, run_g2);
+    route!(ark_mnt6_298::MNT6_298, ark_mnt6_298::G1Affine, run_g1); route!(ark_mnt6_298::MNT6_298, ark_mnt6_298::G2Affine, run_g2);
+    route!(ark_mnt4_753::MNT4_753, ark_mnt4_753::G1Affine, run_g1); route!(ark_mnt4_753::MNT4_753, ark_mnt4_753::G2Affine, run_g2);
+    route!(ark_mnt6_753::MNT6_753, ark_mnt6_753::G1Affine, run_g1); route!(ark_mnt6_753::MNT6_753, ark_mnt6_753::G2Affine, run_g2);
+    false   // any other curve (the CRH's ed_on_mnt4_298, ...): upstream
+}
+
+/// `field_id` of include/pcdhip.h for the four supported scalar / base fields
+fn field_of(t: TypeId) -> Option<(c_int, usize)> {
+    if t == TypeId::of::<ark_mnt4_298::Fq>() { return Some((0, 5)); }    // = MNT6-298 Fr
+    if t == TypeId::of::<ark_mnt4_298::Fr>() { return Some((1, 5)); }    // = MNT6-298 Fq
+    if t == TypeId::of::<ark_mnt4_753::Fq>() { return Some((2, 12)); }   // = MNT6-753 Fr
+    if t == TypeId::of::<ark_mnt4_753::Fr>() { return Some((3, 12)); }   // = MNT6-753 Fq
+    None
+}
+
+/// The registered `ark_poly::domain::hook::FftHook`: in place on the vector's own storage (an `Fp320` / `Fp768` is its Montgomery
+/// `BigInteger` limbs in memory, the C-ABI's encoding -- `marshal::limbs_of` asserts the size).
+unsafe fn fft_hook(field: TypeId, data: *mut u8, len: usize, log_n: u32, inverse: bool) -> bool {
+    let (field_id, limbs) = match field_of(field) { Some(f) => f, None => return false };
+    if log_n < MIN_LOG_N || len != 1usize << log_n || (data as usize) % core::mem::align_of::<u64>() != 0 { return false; }
+    let _ = limbs;
+    with_device(|dev| ffi::check(ffi::pcdhip_fft(dev.ctx, field_id, data as *mut u64, log_n, inverse as c_int, 0))).is_ok()
+}
+
+/// Register both hooks with the forks.  Idempotent; returns whether THIS call installed them (false: someone else already had).
+pub fn install() -> bool {
+    let a = ark_ec::msm::hook::set_msm_hook(msm_hook);
+    let b = ark_poly::domain::hook::set_fft_hook(fft_hook);
+    // (mention marshal so that a build without the Groth16 seam still type-checks the shared helpers)
+    let _ = marshal::limbs_of::<ark_mnt4_298::Fr>;
+    a && b
+}
