@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-strong", action="store_true", help="skip the fixed-total (strong scaling) section")
     ap.add_argument("--no-pipeline", action="store_true", help="headline = one MSM at a time (no second MSM in flight)")
+    ap.add_argument("--no-merge", action="store_true", help="N > 1: skip the PCD-step section (merge-node proof over all devices + DAG branches)")
+    ap.add_argument("--merge-log-n", type=int, default=20, help="N > 1: log2 of the merge node's domain (20; 22 = BASELINE configs[4], ~10 min of host work)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON result: everything else that libraries print there while we run (RCCL's
@@ -93,6 +95,9 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
+    # a HOST-side barrier for the section in which rank 0 alone drives every device (an NCCL barrier would park a spinning kernel on the
+    # waiting ranks' GPUs, which that section is busy measuring)
+    host_group = dist.new_group(backend="gloo") if use_dist and world > 1 else None
 
     # ---- synthetic inputs (oracle helpers are test infrastructure: used here only to MAKE inputs and, below,
     # ---- as the CPU baseline / checker -- never inside the timed GPU region)
@@ -236,10 +241,29 @@ def main():
                 strong[f"753_2^{lt}"] = strong_run(lt, 5, 2, curve=2)
             strong_cache.clear()
 
+    # ---- BASELINE's first metric at N > 1: the PCD step with the merge node's proof sharded over ALL devices, and N DAG branches one per
+    # ---- device.  Rank 0 drives every device through ONE multi-device context (what a Rust host does: it has no process group); the other
+    # ---- ranks free their device memory and wait on the host.  PCD_BENCH_DEVICES="0,0" exercises the same code on one GPU.
+    multi_info = None
+    dev_env = os.environ.get("PCD_BENCH_DEVICES")
+    if (world > 1 or dev_env) and not args.no_merge and not args.no_753:
+        bases.free(); sbuf.free()
+        bases = sbuf = None
+        ctx.sync()
+        torch.cuda.empty_cache()
+        if host_group is not None:
+            dist.barrier(group=host_group)        # every rank has released its device
+        if rank == 0:
+            devices = [int(x) for x in dev_env.split(",")] if dev_env else list(range(world))
+            multi_info = multi_device_step(co, devices, args.merge_log_n)
+        if host_group is not None:
+            dist.barrier(group=host_group)
+
     # ---- PCD step (prover arithmetic of main + help Groth16 proofs), N = 1 only
     step_info = step_753 = fft_info = pairing_info = None
     if rank == 0 and world == 1 and not args.no_step:
-        bases.free(); sbuf.free()
+        if bases is not None:
+            bases.free(); sbuf.free()
         fft_info = fft_section(ctx, co)
         pairing_info = pairing_section(ctx, co, (0,) if args.no_753 else (0, 2))
         step_info = pcd_step(ctx, co, (("main_mnt4_298", 0, (1 << 20) - 8), ("help_mnt6_298", 1, (1 << 16) - 8)), 32)
@@ -303,6 +327,8 @@ def main():
             out["pcd_step"] = step_info
         if step_753:
             out["pcd_step_753"] = step_753
+        if multi_info:
+            out["pcd_step_multi_device"] = multi_info
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
@@ -417,6 +443,94 @@ def pairing_section(ctx, co, curves):
                                        "exponentiation) on the same proofs; 8 proofs on 8 threads, one each"},
             "gpu_over_cpu8_batch8": round(cpu8 / eight, 2)}
     return out
+
+
+def multi_device_step(co, devices, log_n):
+    """BASELINE's "PCD-step prover ms ... 1/2/4/8 GPU": one step of an arity-N merge node over MNT4-753 / MNT6-753 (configs[4] shape).
+      * the MAIN proof (MNT4-753, domain 2^log_n) through ONE multi-device context over `devices` (pcdhip_init_devices: every query
+        sharded by point range, five MSMs per device, the witness map's a / b / c chains on the first three devices, partial sums on
+        device 0) -- next to the same proof on devices[0] alone;
+      * the HELP proof (MNT6-753, mixed-radix domain 5 * 2^14) on devices[0];
+      * len(devices) independent DAG branches (main proof each), one per device: threads x contexts, no exchange.
+    The sharded proof must be BIT-IDENTICAL to the single-device one (which tests/ and the N = 1 line pin to the CPU oracle); otherwise
+    no number is printed.  Wall clock around the C-ABI call, median of 3."""
+    from pcd_amd import capi, dag
+    G = len(devices)
+    info = {"devices": devices, "unit": "ms", "timing": "median of 3 proves, wall clock around pcdhip_groth16_prove",
+            "check": "sharded proof and every branch's proof == the single-device proof, byte for byte (the single-device path is what tests/ and "
+                     "the N = 1 line compare with the CPU oracle; the keys are seeded on-curve points, not a consistent SRS, so there is nothing to verify)"}
+    curve, hcurve = 2, 3
+    fr, hfr = co.CURVE_FR[curve], co.CURVE_FR[hcurve]
+    t0 = time.time()
+    r = co.skewed_r1cs(fr, (1 << log_n) - 8, 2, seed=SEED + 200)
+    keys = co.synthetic_keys(curve, r, seed=SEED + 201)
+    rs = co.gen_field(fr, 2, seed=SEED + 202)
+    hr = co.skewed_r1cs(hfr, (1 << 15) + 20000, 2, seed=SEED + 203)
+    hkeys = co.synthetic_keys(hcurve, hr, seed=SEED + 204)
+    hrs = co.gen_field(hfr, 2, seed=SEED + 205)
+    info["input_gen_s"] = round(time.time() - t0, 1)
+    r.z = capi.pinned_like(r.z)
+
+    def timed(c, pk, rr, rss, reps=3):
+        c.groth16_prove(pk, rr, rss[0], rss[1], resident_r1cs=True)
+        walls, proof = [], None
+        for _ in range(reps):
+            t = time.perf_counter()
+            proof, _ = c.groth16_prove(pk, rr, rss[0], rss[1], resident_r1cs=True)
+            walls.append((time.perf_counter() - t) * 1e3)
+        return float(np.median(walls)), proof, c.groth16_last_timings()
+
+    # one device: the reference proof bytes, the standalone witness map and the help proof
+    one = capi.Context(devices[0])
+    # at 2^22 the full set of window-shifted copies of one MNT4-753 key is ~195 GB: cap every vector (fewer copies, Horner combine back)
+    budget = int(os.environ.get("PCD_BENCH_COPY_BUDGET_GB", "24" if log_n >= 22 else "0")) << 30
+    one.set_precompute_budget(budget)
+    pk = one.g16_pk_upload(keys.host_struct(), curve)
+    one.g16_pk_set_r1cs(pk, r)
+    one_ms, proof_one, one_tm = timed(one, pk, r, rs)
+    wm = [one.witness_map_resident(pk, r, want_h=False)[1] for _ in range(3)][1:]
+    info["witness_map_alone_ms"] = {k: round(float(np.median([w[k] for w in wm])), 3) for k in wm[0]}
+    pk.free()
+    hpk = one.g16_pk_upload(hkeys.host_struct(), hcurve)
+    one.g16_pk_set_r1cs(hpk, hr)
+    help_ms, help_proof, _ = timed(one, hpk, hr, hrs)
+    hpk.free()
+    one.close()
+
+    multi = capi.Context(devices=devices)
+    multi.set_precompute_budget(budget)
+    t0 = time.time()
+    mpk = multi.g16_pk_upload(keys.host_struct(), curve)
+    multi.g16_pk_set_r1cs(mpk, r)
+    info["sharded_key_upload_s"] = round(time.time() - t0, 2)
+    all_ms, proof_all, all_tm = timed(multi, mpk, r, rs)
+    mpk.free()
+    if not np.array_equal(proof_all, proof_one):
+        raise SystemExit("sharded Groth16 proof differs from the single-device proof: refusing to report a number")
+    multi.close()
+    info["main_mnt4_753"] = {"domain": int(keys.domain_size), "one_device_ms": round(one_ms, 2), "all_devices_ms": round(all_ms, 2),
+                             "speedup": round(one_ms / all_ms, 2),
+                             "device0_critical_path_ms": {"witness_map_until_h": round(float(all_tm["witness_map"]), 3), "total": round(float(all_tm["total"]), 3)},
+                             "one_device_stage_ms": {k: round(float(v), 3) for k, v in one_tm.items()}}
+    info["help_mnt6_753"] = {"domain": int(hkeys.domain_size), "one_device_ms": round(help_ms, 2)}
+    info["pcd_step_ms"] = round(all_ms + help_ms, 2)
+    info["pcd_step_ms_one_device"] = round(one_ms + help_ms, 2)
+
+    # independent DAG branches: one main proof per device, each thread uploads its own key (as a real branch would hold its own step's key)
+    def branch(c):
+        c.set_precompute_budget(budget)
+        bpk = c.g16_pk_upload(keys.host_struct(), curve)
+        c.g16_pk_set_r1cs(bpk, r)
+        ms, proof, _ = timed(c, bpk, r, rs)
+        bpk.free()
+        if not np.array_equal(proof, proof_one):
+            raise SystemExit("a DAG branch's proof differs from the single-device proof")
+        return ms
+    t0 = time.perf_counter()
+    per = dag.run_branches([branch] * G, devices)
+    info["dag_branches"] = {"n": G, "ms_each": [round(v, 2) for v in per], "wall_s_including_key_upload": round(time.perf_counter() - t0, 2),
+                            "proofs_per_s": round(G / (max(per) * 1e-3), 3)}
+    return info
 
 
 def median_prove(ctx, pk, r, rs, reps=5):

@@ -242,6 +242,12 @@ int pcdhip_groth16_last_timings(pcdhip_ctx* ctx, float out_ms[8]);
  *   1  folded into two more MSMs over the a / b_g1 bases with every scalar multiplied by s / r;
  *   0  (default) automatic: 2 for large proofs, 1 for small ones (<= 2^17 variables, 2^18 over the 753-bit fields). */
 int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode);
+/* Multi-device contexts with at least three devices: where the three independent chains of the witness map (a = A z, b = B z, c = C z:
+ * mat-vec, ifft, coset fft each -- ark-groth16 `R1CSToQAP::witness_map`, SURVEY.md 8e "a || b || c on 3 GPUs") run.  1 (default): chain a on
+ * device 0, b on device 1, c on device 2 (the matrices are resident on all three, pcdhip_g16_pk_set_r1cs), the two vectors come back
+ * device to device, the pointwise step and the last transform run on device 0 -- about 45 % of the map's time leaves the critical path of
+ * device 0, which also carries its share of the MSMs.  0: everything on device 0.  The proof is the same either way. */
+int pcdhip_groth16_set_witness_split(pcdhip_ctx* ctx, int on);
 
 /* ---- the caller side of the path -- key generation -------------------------------------
  * Replaces ark-ec `FixedBaseMSM::{get_window_table, multi_scalar_mul}` + `batch_normalization_into_affine`:

@@ -285,6 +285,7 @@ void pcdhip_destroy(pcdhip_ctx* ctx) {
     (void)hipFree(kv.second.coset); (void)hipFree(kv.second.coset_inv_scaled);
   }
   if (ctx->xstream_ev) (void)hipEventDestroy(ctx->xstream_ev);
+  if (ctx->wm_ev) (void)hipEventDestroy(ctx->wm_ev);
   for (int c = 0; c < 4; c++) if (ctx->vm_block[c]) (void)hipFree(ctx->vm_block[c]);
   for (int k = 0; k < pcdhip_ctx::PIPE_SLOTS; k++) if (ctx->pipe_done[k]) (void)hipEventDestroy(ctx->pipe_done[k]);
   if (ctx->pipe_host) (void)hipHostFree(ctx->pipe_host);
@@ -501,6 +502,11 @@ int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode) {
   ctx->g16_assembly = mode;
   return PCDHIP_OK;
 }
+int pcdhip_groth16_set_witness_split(pcdhip_ctx* ctx, int on) {
+  if (!ctx) return PCDHIP_E_ARG;
+  ctx->wm_split = on != 0;
+  return PCDHIP_OK;
+}
 int pcdhip_msm_profile(pcdhip_ctx* ctx, int on) {
   if (!ctx) return PCDHIP_E_ARG;
   ctx->msm_profile = on != 0;
@@ -604,8 +610,8 @@ int pcdhip_msm_submit_partial(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t
 int pcdhip_msm_ticket_wait(pcdhip_ctx* ctx, int ticket, void* other_stream) {
   if (!ctx || ticket < 0 || ticket >= pcdhip_ctx::PIPE_SLOTS || !ctx->pipe_busy[ticket]) return PCDHIP_E_ARG;
   BIND();
-  ctx->pipe_busy[ticket] = false;
   TRY(hipStreamWaitEvent((hipStream_t)other_stream, ctx->pipe_done[ticket], 0));
+  ctx->pipe_busy[ticket] = false;  // only once the other stream IS ordered behind the MSM: a failed wait keeps the ticket
   return PCDHIP_OK;
 }
 int pcdhip_msm_collect(pcdhip_ctx* ctx, int ticket, uint64_t* out_xyz) {
@@ -775,6 +781,8 @@ int pcdhip_to_affine(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t
 
 // ------------------------------------------------------------------------------------------------ FFT
 static int fft_dev_general(pcdhip_ctx* ctx, pcdhip_buf* data, const Dom& d, int inverse, int coset) {
+  inverse = inverse ? 1 : 0;  // (the higher bits of this argument are internal flags of the pass driver: never from the ABI)
+  coset = coset ? 1 : 0;
   const FieldEntry& fe = field_entry(data->field_id);
   if (data->n < d.n) return PCDHIP_E_ARG;
   const size_t vb = (size_t)d.n * fe.words * 4;
@@ -936,6 +944,50 @@ int upload_csr(pcdhip_ctx* ctx, int slot, const pcdhip_csr* m, const FieldEntry&
 }
 
 // h (d.n elements, device image) left in aux slot AUX_A; z_dev: m elements on device; mats: A, B, C on device
+// ifft then coset_fft of v (tmp: ping-pong partner), result in v.  On a radix-2 domain the two transforms are chained without the copy back
+// that an odd number of passes otherwise ends with (flag 4 of `inverse`: the first leaves its result in tmp, the second starts there and
+// its last pass lands in v): six such copies of n elements per witness map gone (10 % of a 298-bit transform at 2^20).
+int chain_transforms(pcdhip_ctx* ctx, int field_id, const Dom& d, uint32_t* v, uint32_t* tmp) {
+  int rc;
+  if (d.m != 1) {
+    rc = domain_transform(ctx, field_id, d, v, tmp, 1, 0, nullptr, nullptr); if (rc) return rc;
+    return domain_transform(ctx, field_id, d, v, tmp, 0, 1, nullptr, nullptr);
+  }
+  int P = 0;
+  rc = domain_transform(ctx, field_id, d, v, tmp, 1 | 4, 0, nullptr, &P); if (rc) return rc;
+  uint32_t *s2 = (P & 1) ? tmp : v, *t2 = (P & 1) ? v : tmp;
+  return domain_transform(ctx, field_id, d, s2, t2, 0 | 4, 1, nullptr, &P);  // P odd: ends in v; P even: stays in v
+}
+// One of the three independent chains of the witness map on `ctx`'s device and stream: v = M z (k == 0: plus the input-consistency
+// rows), then ifft and coset_fft over the domain d, in ctx's own AUX_A / AUX_B / AUX_C buffer `slot` (tmp: AUX_FFT_TMP).
+int witness_chain_dev(pcdhip_ctx* ctx, int field_id, const DevCsr& mat, int k, const uint32_t* z_dev, size_t num_inputs, const Dom& d, int slot,
+                      bool transforms = true) {
+  const FieldEntry& fe = field_entry(field_id);
+  const size_t vb = (size_t)d.n * fe.words * 4;
+  TRY(ctx->aux_ws.ensure(slot, vb));
+  TRY(ctx->aux_ws.ensure(AUX_FFT_TMP, vb));
+  uint32_t* v = (uint32_t*)ctx->aux_ws.buf[slot];
+  uint32_t* tmp = (uint32_t*)ctx->aux_ws.buf[AUX_FFT_TMP];
+  TRY(fe.spmv(ctx->stream, mat, z_dev, (uint32_t)num_inputs, k == 0 ? 1 : 0, d.n, v));
+  if (!transforms) return PCDHIP_OK;
+  return chain_transforms(ctx, field_id, d, v, tmp);
+}
+// h = coset_ifft((a o b - c) / Z) from the three transformed chains in ctx's AUX_A, AUX_B, AUX_C; h ends up in AUX_A
+int witness_finish_dev(pcdhip_ctx* ctx, int field_id, const Dom& d) {
+  const FieldEntry& fe = field_entry(field_id);
+  uint32_t *a = (uint32_t*)ctx->aux_ws.buf[AUX_A], *b = (uint32_t*)ctx->aux_ws.buf[AUX_B], *c = (uint32_t*)ctx->aux_ws.buf[AUX_C];
+  uint32_t* tmp = (uint32_t*)ctx->aux_ws.buf[AUX_FFT_TMP];
+  int rc;
+  const FftTables* t;
+  if (d.m == 1) {
+    rc = get_tables(ctx, field_id, d.a, &t); if (rc) return rc;
+    TRY(fe.mul_sub_divz(ctx->stream, *t, a, b, c, d.a));
+  } else {
+    rc = get_mixed_tables(ctx, field_id, d, &t); if (rc) return rc;
+    TRY(fe.mixed_mul_sub_divz(ctx->stream, *t, a, b, c, d.n));
+  }
+  return domain_transform(ctx, field_id, d, a, tmp, 1, 1, nullptr, nullptr);
+}
 int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const uint32_t* z_dev, size_t num_inputs, Dom* dom_out,
                     hipEvent_t after_spmv = nullptr) {
   const FieldEntry& fe = field_entry(field_id);
@@ -957,20 +1009,9 @@ int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const u
     TRY(fe.spmv(st, mats[k], z_dev, (uint32_t)num_inputs, k == 0 ? 1 : 0, n, vecs[k]));
   if (after_spmv) TRY(hipEventRecord(after_spmv, st));
   // 3 x (ifft, coset_fft), pointwise, coset_ifft
-  for (uint32_t* v : vecs) {
-    rc = domain_transform(ctx, field_id, d, v, tmp, 1, 0, nullptr, nullptr); if (rc) return rc;
-    rc = domain_transform(ctx, field_id, d, v, tmp, 0, 1, nullptr, nullptr); if (rc) return rc;
-  }
-  if (d.m == 1) {
-    const FftTables* t;
-    rc = get_tables(ctx, field_id, d.a, &t); if (rc) return rc;
-    TRY(fe.mul_sub_divz(st, *t, a, b, c, d.a));
-  } else {
-    const FftTables* t;
-    rc = get_mixed_tables(ctx, field_id, d, &t); if (rc) return rc;
-    TRY(fe.mixed_mul_sub_divz(st, *t, a, b, c, n));
-  }
-  rc = domain_transform(ctx, field_id, d, a, tmp, 1, 1, nullptr, nullptr); if (rc) return rc;
+  for (uint32_t* v : vecs) { rc = chain_transforms(ctx, field_id, d, v, tmp); if (rc) return rc; }
+  rc = witness_finish_dev(ctx, field_id, d);
+  if (rc) return rc;
   *dom_out = d;
   return PCDHIP_OK;
 }
@@ -1131,7 +1172,14 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
 }
 int pcdhip_g16_pk_set_r1cs(pcdhip_ctx* ctx, pcdhip_g16_pk* pk, const pcdhip_csr* A, const pcdhip_csr* B, const pcdhip_csr* C) {
   if (!ctx || !pk || !A || !B || !C) return PCDHIP_E_ARG;
-  if (!pk->shards.empty()) return pcdhip_g16_pk_set_r1cs(ctx, pk->shards[0], A, B, C);  // the witness map runs on device 0
+  if (!pk->shards.empty()) {
+    // the witness map's three chains (a, b, c: mat-vec, ifft, coset fft each) run on the first three devices of a sharded key
+    // (SURVEY.md 8e), the pointwise step and the last transform on device 0: the matrices are resident wherever a chain runs
+    int rc = pcdhip_g16_pk_set_r1cs(ctx->peers.empty() ? ctx : ctx->peers[0], pk->shards[0], A, B, C);
+    for (size_t g = 1; !rc && g < 3 && g < pk->shards.size() && g < ctx->peers.size(); g++)
+      rc = pcdhip_g16_pk_set_r1cs(ctx->peers[g], pk->shards[g], A, B, C);
+    return rc;
+  }
   if (A->num_rows != B->num_rows || A->num_rows != C->num_rows || (A->num_rows >> 31)) return PCDHIP_E_ARG;
   if (!A->row_ptr || !B->row_ptr || !C->row_ptr) return PCDHIP_E_ARG;
   BIND();
@@ -1345,10 +1393,35 @@ int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_cs
   DevCsr mats[3];
   if (A && B && C) { TRY(hipStreamSynchronize(ctx->stream)); rc = upload_three(ctx, A, B, C, fe, m, mats); if (rc) return rc; }
   else for (int k = 0; k < 3; k++) mats[k] = pk0->mats[k];
-  Dom dom_used;
-  rc = witness_map_dev(ctx, fr, mats, runs[0].z_dev, ni, &dom_used);
-  if (rc) return rc;
-  if (dom_used.n != dom.n) return PCDHIP_E_ARG;
+  const bool split3 = G >= 3 && !(A && B && C) && ctx->wm_split && pk->shards[1]->r1cs_dev && pk->shards[2]->r1cs_dev &&
+                      pk->shards[1]->rows == rows && pk->shards[2]->rows == rows;
+  if (split3) {
+    // chains b and c on devices 1 and 2 (their z is resident since prepare()), each into its own AUX_A, then device to device into
+    // device 0's AUX_B / AUX_C; chain a on device 0 meanwhile; the pointwise step and the last transform on device 0
+    const size_t vb = (size_t)dom.n * fe.words * 4;
+    TRY(ctx->aux_ws.ensure(AUX_B, vb));
+    TRY(ctx->aux_ws.ensure(AUX_C, vb));
+    for (size_t g = 1; g <= 2; g++) {
+      pcdhip_ctx* Cg = ctx->peers[g];
+      TRY(hipSetDevice(Cg->device));
+      rc = witness_chain_dev(Cg, fr, pk->shards[g]->mats[g], (int)g, runs[g].z_dev, ni, dom, AUX_A);
+      if (rc) return rc;
+      TRY(hipMemcpyPeerAsync(ctx->aux_ws.buf[g == 1 ? AUX_B : AUX_C], ctx->device, Cg->aux_ws.buf[AUX_A], Cg->device, vb, Cg->stream));
+      if (!Cg->wm_ev) TRY(hipEventCreateWithFlags(&Cg->wm_ev, hipEventDisableTiming));
+      TRY(hipEventRecord(Cg->wm_ev, Cg->stream));
+    }
+    BIND();
+    rc = witness_chain_dev(ctx, fr, mats[0], 0, runs[0].z_dev, ni, dom, AUX_A);
+    if (rc) return rc;
+    for (size_t g = 1; g <= 2; g++) TRY(hipStreamWaitEvent(ctx->stream, ctx->peers[g]->wm_ev, 0));
+    rc = witness_finish_dev(ctx, fr, dom);
+    if (rc) return rc;
+  } else {
+    Dom dom_used;
+    rc = witness_map_dev(ctx, fr, mats, runs[0].z_dev, ni, &dom_used);
+    if (rc) return rc;
+    if (dom_used.n != dom.n) return PCDHIP_E_ARG;
+  }
   TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_A], runs[0].h_can, (uint32_t)n, 2));
   TRY(hipEventRecord(ev[1], ctx->stream));
   const size_t sw = runs[0].sw, sb = runs[0].sb;
@@ -1789,7 +1862,9 @@ int prepare_inputs(pcdhip_ctx* ctx, const pcdhip_pvk* pvk, size_t k, const uint6
   if (pvk->abc_dev) {  // window tables: every proof's accumulation in one launch, no doubling chains
     const GroupEntry& ge = group_entry(cid, 1);
     const size_t jw = (size_t)ge.point_words / 2 * 3, sb = (ni - 1) * sl * 8;
-    const bool jac = acc_z && ctx->pairing_vm;
+    // Jacobian accumulations only when the wave-per-pairing kernels will take them: 3 pairings per proof, PCD_VM_MAX_PAIRS per launch
+    // (beyond, the lane-per-pairing kernels want affine points: a batch of 1366+ proofs used to fail here)
+    const bool jac = acc_z && ctx->pairing_vm && 3 * k <= PCD_VM_MAX_PAIRS;
     TRY(ctx->aux_ws.ensure(AUX_FB_JAC, k * (64 * jw * 4 + sb + l1 * 8 + l1 * 4 + 1) + 64));
     char* d = (char*)ctx->aux_ws.buf[AUX_FB_JAC];
     uint32_t* scratch = (uint32_t*)d;
@@ -1849,9 +1924,17 @@ int pcdhip_process_vk(pcdhip_ctx* ctx, int curve_id, const uint64_t* alpha_g1, c
     const size_t tab_w = ge.fb_table_words;   // one table + the Jacobians of its doubling chain
     const size_t head = (num_inputs * abi_w + num_inputs / 4 + 64 + 3) / 4 * 4;   // points, then the flag bytes, 16-byte aligned
     hipError_t e = hipMalloc((void**)&pvk->abc_dev, (head + std::max<size_t>(num_inputs - 1, 1) * tab_w) * 4);
-    if (e != hipSuccess) { pcdhip_pvk_free(ctx, pvk); return fail(ctx, e); }
+    if (e != hipSuccess) {  // no room for the window tables (up to 1.3 GB for a 753-bit key): the plain resident vector serves (MSM path)
+      (void)hipGetLastError();
+      pvk->abc_dev = nullptr;
+    }
+  }
+  if (!rc && pvk->abc_dev) {
+    const GroupEntry& ge = group_entry(curve_id, 1);
+    const size_t abi_w = (size_t)ge.point_abi_words;
+    const size_t head = (num_inputs * abi_w + num_inputs / 4 + 64 + 3) / 4 * 4;
     pvk->abc_tables_off = head;
-    e = hipMemcpyAsync(pvk->abc_dev, gamma_abc_g1, num_inputs * abi_w * 4, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipMemcpyAsync(pvk->abc_dev, gamma_abc_g1, num_inputs * abi_w * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = zero_flagged(ctx->stream, pvk->abc_dev, (uint8_t*)(pvk->abc_dev + num_inputs * abi_w), gamma_abc_inf, num_inputs, abi_w * 4);
     if (e == hipSuccess) e = ge.fb_tables(ctx->stream, pvk->abc_dev, (uint32_t)num_inputs, pvk->abc_dev + head);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

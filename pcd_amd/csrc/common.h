@@ -12,6 +12,8 @@
 #include "../../include/pcdhip.h"
 #include "msm.hip.h"
 #include "vm_tables.h"
+// batches of up to this many pairings run one WAVE per pairing (pairing_vm.hip.h); larger ones one lane per pairing (pairing.hip.h)
+#define PCD_VM_MAX_PAIRS 4096u
 
 namespace pcd {
 
@@ -108,6 +110,8 @@ struct pcdhip_ctx {
   pcd::VmCurveTables vm_tables[4] = {};
   bool pairing_vm = true;  // small batches of pairings run one wave per pairing (pcdhip_pairing_set_mode)
   hipEvent_t xstream_ev = nullptr;  // pcdhip_stream_wait: ordering against a caller-owned stream (e.g. the RCCL stream)
+  hipEvent_t wm_ev = nullptr;       // sharded prove: this device's chain of the witness map has landed in device 0's buffers
+  bool wm_split = true;             // pcdhip_groth16_set_witness_split
   std::string last_hip_error;
 };
 

@@ -18,6 +18,20 @@ typedef Fp<F753B> FT;
 #error "PCD_FIELD_IDX must be 0..3"
 #endif
 
+// The transform passes compute with the product INLINED for every field (PCD_FFT_INLINE_753=0: the 753-bit passes through the
+// non-inlined call as in round 3): a pass has five product sites, not the dozens of a point kernel, so the 1 458-multiply-add body of the
+// 27-limb product costs neither compile time nor the instruction cache here, and the scratch round trips of the call (54 words out, 27
+// back, per product, at one wave per SIMD) go away.  Same memory image; only the kernel's arithmetic type differs.
+#ifndef PCD_FFT_INLINE_753
+#define PCD_FFT_INLINE_753 1
+#endif
+#if PCD_FFT_INLINE_753
+typedef Fp<FT::Params, true> FTP;
+#else
+typedef FT FTP;
+#endif
+static_assert(sizeof(FTP) == sizeof(FT), "same image");
+
 namespace {
 
 constexpr int EW = FT::WORDS;
@@ -86,6 +100,8 @@ hipError_t run_batched(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t
   FT scale = FT::one();
   int use_scale = 0;
   const bool raw = (inverse & 2) != 0;  // inverse root, no 1/n (a row transform inside a mixed-radix domain)
+  const bool keep = (inverse & 4) != 0; // leave the result where the last pass wrote it (tmp after an odd number of passes): the caller
+                                        // chains a second transform from there -- ifft then coset_fft of the witness map: no copy at all
   inverse &= 1;
   if (inverse && !coset && !raw) {  // plain 1/n: constant multiply in the last pass
     scale = c.ninv;
@@ -103,14 +119,16 @@ hipError_t run_batched(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t
     const uint32_t* post = (last && coset && inverse) ? t.coset_inv_scaled : nullptr;
     const uint32_t blocks = 1u << (log_n - d - logT);
     const size_t lds = ((size_t)1 << (d + logT)) * EW * 4;
-    hipLaunchKernelGGL(fft_pass_kernel<FT>, dim3(blocks, batch), dim3(256), lds, st, src, dst, tw, log_n, d, logT, logs, pre, post,
-                       (last ? use_scale : 0), scale, ((size_t)EW) << log_n);
+    FTP scale_p;
+    memcpy(&scale_p, &scale, sizeof scale);
+    hipLaunchKernelGGL(fft_pass_kernel<FTP>, dim3(blocks, batch), dim3(256), lds, st, src, dst, tw, log_n, d, logT, logs, pre, post,
+                       (last ? use_scale : 0), scale_p, ((size_t)EW) << log_n);
     if (pass_ms) PCD_HIP_TRY(hipEventRecord(ev[i + 1], st));
     logs += d;
     std::swap(src, dst);
   }
   PCD_HIP_TRY(hipGetLastError());
-  if (src != x) PCD_HIP_TRY(hipMemcpyAsync(x, src, ((size_t)batch << log_n) * EW * 4, hipMemcpyDeviceToDevice, st));
+  if (src != x && !keep) PCD_HIP_TRY(hipMemcpyAsync(x, src, ((size_t)batch << log_n) * EW * 4, hipMemcpyDeviceToDevice, st));
   if (pass_ms) {
     PCD_HIP_TRY(hipStreamSynchronize(st));
     for (int i = 0; i < P && i < 8; i++) (void)hipEventElapsedTime(&pass_ms[i], ev[i], ev[i + 1]);

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(64) vm_final_exp_kernel(const uint32_t* __rest
 // Up to VM_MAX_PAIRS pairs: one wave per pairing (a Miller loop's dependent chain is ~15x shorter); beyond, one lane per pairing
 // (64 pairings per wave: the throughput form for batches that fill the chip anyway).  g1z_dev (nullable, wave form only): Z
 // coordinates of Jacobian G1 points.
-constexpr uint32_t VM_MAX_PAIRS = 4096;
+constexpr uint32_t VM_MAX_PAIRS = PCD_VM_MAX_PAIRS;  // (common.h: the host side decides by the same number whether to ask for Jacobian G1 inputs)
 hipError_t multi_pairing(hipStream_t st, const uint32_t* g1_dev, const uint32_t* g1z_dev, const uint32_t* g2_dev, uint32_t groups, uint32_t per,
                          uint32_t* scratch, uint32_t* gt_out, const VmCurveTables* vm) {
   const uint32_t n = groups * per;
@@ -173,17 +173,20 @@ static hipError_t vm_upload(hipStream_t st, void** block, VmCurveTables* out) {
       {VM_TABLE(consts), sizeof(VM_TABLE(consts))}};
   size_t off[10] = {0};
   for (int i = 0; i < 9; i++) off[i + 1] = off[i] + ((parts[i].bytes + 15) & ~(size_t)15);
-  hipError_t e = hipMalloc(block, off[9]);
+  void* blk = nullptr;
+  hipError_t e = hipMalloc(&blk, off[9]);
   if (e != hipSuccess) return e;
-  char* d = (char*)*block;
-  for (int i = 0; i < 9; i++)
-    if ((e = hipMemcpyAsync(d + off[i], parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  char* d = (char*)blk;
+  for (int i = 0; i < 9 && e == hipSuccess; i++) e = hipMemcpyAsync(d + off[i], parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { (void)hipFree(blk); return e; }  // nothing is published: the next pairing call uploads again
   auto at = [&](int i) { return (const uint32_t*)(d + off[i]); };
   out->miller = {at(0), at(1), at(2), at(8), at(3), (uint32_t)(parts[0].bytes / 12), (uint32_t)(parts[1].bytes / 12), (uint32_t)(parts[2].bytes / 4),
                  VM_TABLE(miller_script_len)};
   out->final_exp = {at(4), at(5), at(6), at(8), at(7), (uint32_t)(parts[4].bytes / 12), (uint32_t)(parts[5].bytes / 12),
                     (uint32_t)(parts[6].bytes / 4), VM_TABLE(final_exp_script_len)};
-  return hipStreamSynchronize(st);
+  *block = blk;  // block and tables become visible together, only after every copy has landed
+  return hipSuccess;
 }
 const PairingEntry* PCD_CAT(pcd_pairing_entry_, PCD_CURVE_IDX)() {
   static const PairingEntry e = {GWA, GW, multi_pairing, vm_upload};

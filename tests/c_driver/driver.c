@@ -14,8 +14,62 @@ static unsigned char* blob;
 static size_t pos;
 static const void* take(size_t bytes) { const void* p = blob + pos; pos += (bytes + 7) / 8 * 8; return p; }
 
+/* Seam S2 (rust/src/s2.rs, the hooks of the ark-ec / ark-poly forks): the call sequence a Marlin prover makes through
+ * `VariableBaseMSM::multi_scalar_mul` and `Radix2EvaluationDomain::{fft, ifft}_in_place` (/root/reference tests/mnt4_marlin.rs:72-75) --
+ * ONE upload of the committer key, MSMs over PREFIXES of it with host scalars (`powers_of_g[..deg + 1]`), transforms IN PLACE on the
+ * caller's own vector -- each result compared with the oracle's.  Blob: header {curve, n_points, n_msms, log_n, field_id, 0, 0, 0},
+ * points xy, inf, then per MSM {len (u64), scalars, expected affine xy}, then the vector, its fft and the ifft of the vector. */
+static int run_s2(long len) {
+  const uint64_t* h = (const uint64_t*)take(8 * 8);
+  const int curve = (int)h[0], field = (int)h[4];
+  const size_t n = (size_t)h[1], k = (size_t)h[2];
+  const uint32_t log_n = (uint32_t)h[3];
+  const size_t L = (size_t)pcdhip_field_limbs(pcdhip_curve_scalar_field(curve)), l1 = (size_t)pcdhip_point_limbs(curve, PCDHIP_G1);
+  const uint64_t* xy = (const uint64_t*)take(n * l1 * 8);
+  const uint8_t* inf = (const uint8_t*)take(n);
+  pcdhip_ctx* ctx = NULL;
+  int rc = pcdhip_init(0, &ctx);
+  if (rc) { fprintf(stderr, "pcdhip_init: %s\n", pcdhip_strerror(rc)); return 3; }
+  pcdhip_bases* key = NULL;
+  rc = pcdhip_bases_upload(ctx, curve, PCDHIP_G1, xy, inf, n, &key);   /* once per committer key */
+  if (rc) { fprintf(stderr, "upload: %s\n", pcdhip_strerror(rc)); return 4; }
+  int bad = 0;
+  uint64_t* xyz = (uint64_t*)calloc(l1 / 2 * 3, 8);
+  uint64_t* aff = (uint64_t*)calloc(l1, 8);
+  for (size_t i = 0; i < k; i++) {
+    const size_t m = (size_t)*(const uint64_t*)take(8);
+    const uint64_t* sc = (const uint64_t*)take(m * L * 8);
+    const uint64_t* want = (const uint64_t*)take(l1 * 8);
+    uint8_t pinf = 0;
+    rc = pcdhip_msm(ctx, key, 0, sc, m, xyz);                           /* a prefix of the resident key, host scalars */
+    if (!rc) rc = pcdhip_to_affine(ctx, curve, PCDHIP_G1, xyz, 1, aff, &pinf);
+    if (rc) { fprintf(stderr, "msm %zu: %s\n", i, pcdhip_strerror(rc)); return 5; }
+    if (memcmp(aff, want, l1 * 8) != 0 || pinf != 0) { fprintf(stderr, "prefix MSM %zu (len %zu) differs\n", i, m); bad = 1; }
+  }
+  const size_t nn = (size_t)1 << log_n, lf = (size_t)pcdhip_field_limbs(field);
+  const uint64_t* v = (const uint64_t*)take(nn * lf * 8);
+  const uint64_t* want_f = (const uint64_t*)take(nn * lf * 8);
+  const uint64_t* want_i = (const uint64_t*)take(nn * lf * 8);
+  if (pos > (size_t)len) { fprintf(stderr, "blob too short\n"); return 2; }
+  uint64_t* w = (uint64_t*)malloc(nn * lf * 8);
+  memcpy(w, v, nn * lf * 8);
+  rc = pcdhip_fft(ctx, field, w, log_n, 0, 0);                          /* fft_in_place on the vector's own storage */
+  if (rc || memcmp(w, want_f, nn * lf * 8) != 0) { fprintf(stderr, "fft differs (%s)\n", pcdhip_strerror(rc)); bad = 1; }
+  rc = pcdhip_fft(ctx, field, w, log_n, 1, 0);                          /* ifft_in_place brings the vector back */
+  if (rc || memcmp(w, v, nn * lf * 8) != 0) { fprintf(stderr, "ifft(fft(v)) differs (%s)\n", pcdhip_strerror(rc)); bad = 1; }
+  memcpy(w, v, nn * lf * 8);
+  rc = pcdhip_fft(ctx, field, w, log_n, 1, 0);
+  if (rc || memcmp(w, want_i, nn * lf * 8) != 0) { fprintf(stderr, "ifft differs (%s)\n", pcdhip_strerror(rc)); bad = 1; }
+  /* what the hook answers "not mine" for must come back as a code, never an abort: a transform beyond what the library builds */
+  { const int e = pcdhip_fft(ctx, field, w, 31, 0, 0); bad |= !(e == PCDHIP_E_SIZE_UNSUPPORTED || e == PCDHIP_E_ARG); }
+  pcdhip_bases_free(ctx, key);
+  pcdhip_destroy(ctx);
+  printf(bad ? "MISMATCH\n" : "c driver ok: S2 sequence (one upload, prefix MSMs, in-place transforms) equals the oracle\n");
+  return bad ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: driver <blob>\n"); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: driver <blob> [s2]\n"); return 2; }
   FILE* f = fopen(argv[1], "rb");
   if (!f) { perror("blob"); return 2; }
   fseek(f, 0, SEEK_END);
@@ -24,6 +78,7 @@ int main(int argc, char** argv) {
   blob = (unsigned char*)malloc((size_t)len);
   if (!blob || fread(blob, 1, (size_t)len, f) != (size_t)len) { fprintf(stderr, "short read\n"); return 2; }
   fclose(f);
+  if (argc >= 3 && strcmp(argv[2], "s2") == 0) return run_s2(len);
   const uint64_t* h = (const uint64_t*)take(12 * 8);
   const uint64_t curve = h[0], m = h[1], ni = h[2], dom = h[3], h_len = h[4], l_len = h[5], nc = h[6], nnz_a = h[7], nnz_b = h[8], nnz_c = h[9];
   const size_t L = (size_t)pcdhip_field_limbs(pcdhip_curve_scalar_field((int)curve));

@@ -51,3 +51,30 @@ def test_c_driver_proves(co, tmp_path):
     out = subprocess.run([EXE, str(blob)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "c driver ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_driver_s2_sequence(co, tmp_path):
+    """seam S2 from plain C: the calls rust/src/s2.rs makes for a Marlin prover (tests/mnt4_marlin.rs:72-75) -- one upload of the
+    committer key, MSMs over prefixes of it with host scalars, in-place transforms of host vectors -- against the oracle"""
+    _build()
+    curve, n = 0, 1 << 13
+    fr = co.CURVE_FR[curve]
+    pts = co.gen_points(curve, 1, n, seed=1301)
+    inf = np.zeros(n, dtype=np.uint8)
+    lens = [n, n // 2 + 17, 4097, n - 1]
+    parts = [np.array([curve, n, len(lens), 14, fr, 0, 0, 0], dtype=np.uint64), pts, inf]
+    for i, m in enumerate(lens):
+        sc = co.gen_scalars(fr, m, seed=1310 + i, dist=i % 2)
+        want = co.to_affine(curve, 1, co.msm(curve, 1, pts[:m], sc, nthreads=8))[0]
+        parts += [np.array([m], dtype=np.uint64), sc, want]
+    v = co.gen_field(fr, 1 << 14, seed=1320)
+    parts += [v, co.fft(fr, v, nthreads=8), co.fft(fr, v, inverse=True, nthreads=8)]
+    blob = tmp_path / "s2.blob"
+    with open(blob, "wb") as f:
+        for a in parts:
+            b = np.ascontiguousarray(a).tobytes()
+            f.write(b + b"\0" * (-len(b) % 8))
+    out = subprocess.run([EXE, str(blob), "s2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "S2 sequence" in out.stdout

@@ -87,3 +87,32 @@ def test_dag_branches_threads_x_contexts(co, gpu_ctx):
     for outs, want in zip(results, wants):
         for got in outs:
             assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("curve,nc,parts", [(0, 5000, 3), (1, 900, 3), (3, 40000, 4), (2, 3000, 8)])
+def test_witness_map_chains_on_three_devices(co, gpu_ctx, curve, nc, parts):
+    """with >= 3 devices and resident matrices the witness map's a / b / c chains run on devices 0 / 1 / 2 and the two vectors
+    travel back device to device; the proof equals the all-on-device-0 form and the oracle's (radix-2 and mixed-radix domains, repeated
+    proves with a changed assignment -- the buffers of one proof must not leak into the next)"""
+    from pcd_amd import capi
+    fr = co.CURVE_FR[curve]
+    r = co.skewed_r1cs(fr, nc, 2, seed=850 + nc)
+    keys = co.synthetic_keys(curve, r, seed=851 + nc)
+    rs = co.gen_field(fr, 2, seed=852)
+    want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=8)
+    mctx = capi.Context(devices=_devices(parts))
+    try:
+        mpk = mctx.g16_pk_upload(keys.host_struct(), curve)
+        mctx.g16_pk_set_r1cs(mpk, r)
+        for on in (1, 0, 1):
+            mctx.groth16_set_witness_split(on)
+            got, inf = mctx.groth16_prove(mpk, r, rs[0], rs[1], resident_r1cs=True)
+            assert np.array_equal(got, want) and np.array_equal(inf, winf), on
+        # another statement under the same key and matrices: scale the witness-independent part by proving with other blinding factors
+        rs2 = co.gen_field(fr, 2, seed=853)
+        want2, _ = co.groth16_prove(keys, r, rs2[0], rs2[1], nthreads=8)
+        got2, _ = mctx.groth16_prove(mpk, r, rs2[0], rs2[1], resident_r1cs=True)
+        assert np.array_equal(got2, want2)
+        mpk.free()
+    finally:
+        mctx.close()

@@ -132,6 +132,17 @@ def test_process_vk_prepared_and_rlc_batch(co, gpu_ctx, pmode, cid, nc):
         assert np.array_equal(gpu_ctx.groth16_verify_prepared(pvk, pubs, bad_pr), np.arange(k) != 1)
         assert not gpu_ctx.groth16_verify_batch_rlc(pvk, pubs, bad_pr, rho)
         assert gpu_ctx.groth16_verify_batch_rlc(pvk, pubs[:1], proofs[:1], rho[:1])
+        if cid == 0:
+            # a batch past the wave-per-pairing limit (3 x 1366 > 4096 pairings: the lane-per-pairing kernels, affine accumulations) --
+            # this size used to return an error in the default configuration
+            big = 1400
+            idx = np.arange(big) % k
+            bp, bq = pubs[idx].copy(), proofs[idx].copy()
+            bp[1001, 0, 0] ^= 1
+            bq[37, :w1] = keys.alpha_g1
+            got = gpu_ctx.groth16_verify_prepared(pvk, bp, bq)
+            want = np.ones(big, dtype=bool); want[1001] = False; want[37] = False
+            assert np.array_equal(got, want)
         with pytest.raises(Exception):
             gpu_ctx.groth16_verify_batch_rlc(pvk, pubs, proofs, np.zeros((k, 2), dtype=np.uint64))   # zero is not a challenge
     finally:
