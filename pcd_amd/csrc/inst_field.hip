@@ -94,7 +94,7 @@ hipError_t run_batched(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t
                        float* pass_ms, int* npasses, uint32_t batch) {
   std::vector<FftPass> plan = fft_plan(log_n);
   const int P = (int)plan.size();
-  const uint32_t* tw = inverse ? t.tw_inv : t.tw_fwd;
+  const uint32_t* tw = (inverse & 3) ? t.tw_inv : t.tw_fwd;   // (bit 0: inverse, bit 1: raw inverse root, bit 2: keep -- not a direction)
   DomainConsts c;
   memcpy(&c, t.consts, sizeof c);
   FT scale = FT::one();
