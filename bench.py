@@ -596,6 +596,29 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None):
                       "key_upload_precompute_s": round(up_s, 2), "input_gen_s": round(gen_s, 2)}
         total_gpu += wall
         total_cpu += cpu_ms
+        if roofline_curve is None and curve in (0, 1):
+            # the G2 accumulation of the 298-bit step (about 40 % of the main proof's work): a standalone MSM over the key's own b_g2 query,
+            # stage events on.  Executed multiply-adds per mixed addition (N = 11): MNT4-298 -- Fq2 over lane pairs, XYZZ with lazily reduced
+            # internals (ec.hip.h madd_x_lz2): 56 N^2;  MNT6-298 -- Fq3 over lane triples, XYZZ (8 products of 12 N^2 + 2 squares of 9 N^2): 114 N^2
+            n2 = min(1 << 20, int(keys.b_g2_query.shape[0]))
+            g2_mads = (56 if curve == 0 else 114) * 11 * 11
+            b = ctx.bases_upload(curve, 2, np.ascontiguousarray(keys.b_g2_query[:n2]))
+            sb = ctx.buf_upload(fr, co.gen_scalars(fr, n2, seed=SEED + 31))
+            ctx.msm_profile(True)
+            accs2, tots2 = [], []
+            for _ in range(4):
+                ctx.msm(b, sb)
+                t = ctx.msm_last_timings()
+                accs2.append(t["accumulate"]); tots2.append(t["total"])
+            ctx.msm_profile(False)
+            c2, W2, _ = ctx.bases_info(b)
+            b.free(); sb.free()
+            acc2 = float(np.median(accs2[1:]))
+            info.setdefault("roofline_int_g2", {})[name] = {
+                "kernel": "msm_accumulate_kernel (G2 over %s, lane-split)" % ("Fq2, MNT4-298" if curve == 0 else "Fq3, MNT6-298"), "n": n2,
+                "kernel_ms": round(acc2, 3), "msm_total_ms": round(float(np.median(tots2[1:])), 3), "bound": "valu_int32_mad",
+                "achieved": round(n2 * W2 * g2_mads / (acc2 * 1e-3) / 1e12, 3), "peak": round(MAD_PEAK / 1e12, 2), "unit": "T mad/s",
+                "frac": round(n2 * W2 * g2_mads / (acc2 * 1e-3) / MAD_PEAK, 4), "window_bits": c2, "windows": W2, "executed_mads_per_pair": W2 * g2_mads}
         if roofline_curve == curve:
             # the dominant kernel of the step: G1 bucket accumulation of the main proof (four of its five MSMs); measured on one
             # standalone MSM over the key's own h query with the stage events on

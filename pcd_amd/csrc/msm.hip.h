@@ -953,6 +953,15 @@ struct MsmItems {
 //  use for the 753-bit groups: with this kernel's shape -- one item, both operands finite -- the mailbox form of the Fq3-753 addition
 //  returns one wrong limb of Y (localised with tools/probe_fq3_tail.py: "ones and 257"; every other kernel and every other case is
 //  exact in both forms, also with every item slot of the wave kept active here) -- a code-generation problem this sidesteps)
+// The zeroing an MSM needs before its first kernel, in ONE launch: the histogram / cursor words the sort starts from and the four control
+// words (binning flag, error word, big-bucket and segment counters).  Round 3 spent three hipMemsetAsync per MSM on this -- 2 054 fill
+// launches in a bench run, each a dependent launch on an MSM's critical path queued behind one-wave-per-SIMD accumulate grids.
+static __global__ void __launch_bounds__(256) msm_zero_kernel(uint32_t* __restrict__ cnt, uint32_t n_cnt, uint32_t* __restrict__ ctl4) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_cnt) cnt[i] = 0;
+  if (i < 4) ctl4[i] = 0;
+}
+
 #ifndef PCD_SINGLE_ITEM_PLAIN
 #define PCD_SINGLE_ITEM_PLAIN 0  // 1: the two single-item kernels (this one, msm_horner_kernel) in the plain lane-split form as in round 3
 #endif
@@ -1469,7 +1478,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   PCD_HIP_TRY(ws.ensure(WS_SORTED, (size_t)maxM * 4));
   PCD_HIP_TRY(ws.ensure(WS_BUCKETS, (size_t)tkeys * PB));
   PCD_HIP_TRY(ws.ensure(WS_OUT, PB + 64));
-  PCD_HIP_TRY(ws.ensure(WS_ONES, (size_t)n * 4 + 16));
+  PCD_HIP_TRY(ws.ensure(WS_ONES, (size_t)n * 4 + 32));
   uint32_t* cnt = (uint32_t*)ws.buf[WS_CNT];
   uint32_t* off = (uint32_t*)ws.buf[WS_OFF];
   uint32_t* bsum = (uint32_t*)ws.buf[WS_BSUM];
@@ -1478,6 +1487,10 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   uint32_t* ones_idx = (uint32_t*)ws.buf[WS_ONES];
   uint32_t* flag = ones_idx + n;  // cap-overflow flag of the single-pass binning
   uint32_t* err = flag + 1;       // a scalar >= 2^bits was seen (msm_scalar_too_wide)
+  uint32_t* big_count = flag + 2; // [#big buckets, #segments] of the fix-up pass; flag + 4: the pair tree's chunk word
+  auto zero_start = [&](uint32_t n_cnt) {  // cnt[0 .. n_cnt) and the four control words, one launch
+    hipLaunchKernelGGL(msm_zero_kernel, dim3(std::max<uint32_t>(1u, (n_cnt + 255) / 256)), dim3(256), 0, st, cnt, n_cnt, flag);
+  };
   ws.last_err_dev = consume ? nullptr : err;
   constexpr int SBITS = G::FR::BITS;
   // Optional single-pass binning: every bucket owns `cap` slots (mean load + 6 sigma + 8), one atomic pass instead of
@@ -1503,13 +1516,13 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   if (consume) {
     // the producer's sorted list (its workspace is not touched again before every consumer has finished)
     PCD_HIP_TRY(hipStreamWaitEvent(st, share->ready, 0));
+    zero_start(0);
     src = share->src;
     off = const_cast<uint32_t*>(share->off);
     PCD_HIP_TRY(mark(1)); PCD_HIP_TRY(mark(2)); PCD_HIP_TRY(mark(3));
   } else if (use_slots) {
-    PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)tkeys * 4, st));
+    zero_start(tkeys);
     // 1. one pass: slots + exact histogram
-    PCD_HIP_TRY(hipMemsetAsync(flag, 0, 8, st));
     hipLaunchKernelGGL((msm_digits_kernel<NS, MODE_BIN>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, pl.nkeys, cnt,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, slots, cap, ones_idx, flag, 0, SBITS, err);
     PCD_HIP_TRY(mark(1));
@@ -1526,7 +1539,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     PCD_HIP_TRY(mark(3));
     src = {sorted, slots, ones_idx, flag, cap, ones_key};
   } else if (use_partition) {
-    PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)tkeys * 4, st));
+    zero_start(nbins + 1);  // (this path's histogram is per BIN)
     // 1. coarse histogram  2. bin bases  3. partition + per-bin counting sort (see "partition sort" above)
     const uint32_t tiles = (n + MSM_TILE - 1) / MSM_TILE;
     PCD_HIP_TRY(ws.ensure(WS_ENTRIES, (size_t)maxM * 8));
@@ -1535,7 +1548,6 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     uint32_t* bin_base = (uint32_t*)ws.buf[WS_CUR];
     uint32_t* cursor = bin_base + nbins + 2;
     uint32_t* ones_count = flag;  // (the binning flag word is unused on this path)
-    PCD_HIP_TRY(hipMemsetAsync(flag, 0, 8, st));
     hipLaunchKernelGGL((msm_coarse_kernel<NS, false>), dim3(tiles), dim3(256), (size_t)nbins * 4, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total,
                        bv.offset, nbins, cnt, (uint64_t*)nullptr, ones_count, ones_idx, SBITS, err);
     PCD_HIP_TRY(mark(1));
@@ -1547,8 +1559,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     PCD_HIP_TRY(mark(3));
     src = {sorted, nullptr, ones_idx, nullptr, 0u, ones_key};
   } else {
-    PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)tkeys * 4, st));
-    PCD_HIP_TRY(hipMemsetAsync(flag, 0, 8, st));
+    zero_start(tkeys);
     // 1. histogram  2. scan  3. scatter (cursor = cnt reset to zero)
     hipLaunchKernelGGL((msm_digits_kernel<NS, MODE_HIST>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, pl.nkeys, cnt,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, 0, SBITS, err);
@@ -1594,11 +1605,9 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   uint32_t* plast = (uint32_t*)ws.buf[WS_PLAST];
   uint32_t* big = (uint32_t*)ws.buf[WS_BIG];
   uint32_t* seg_list = big + 3 * big_cap;
-  uint32_t* big_count = seg_list + 3 * seg_cap;  // [#big buckets, #segments]
   uint32_t* big_partial = (uint32_t*)ws.buf[WS_BIGPART];
   // (no memset of the bucket array -- 69 MB at c = 19: every bucket is written by exactly one of msm_accumulate, msm_fixup
   //  (also the empty ones: Z = 0) and msm_big_bucket)
-  PCD_HIP_TRY(hipMemsetAsync(big_count, 0, 8, st));
   PCD_HIP_TRY(mark(8));  // the accumulate stage time is the kernel alone (mark 8 -> mark 4)
   {
     constexpr uint32_t per_wave = 64 / AccOf<G>::LANES;  // chunks per workgroup
