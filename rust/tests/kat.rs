@@ -9,14 +9,20 @@
 //! fields (`Radix2EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}`), the reduced pairing on the four curves, the witness map
 //! and the Groth16 proof for given (r, s) on MNT4-298 / MNT6-298 (`create_proof_with_reduction` over a circuit that replays the
 //! golden constraint system), and the `CanonicalSerialize` bytes of points.  Never compiled in the build container (no toolchain).
-use ark_ec::msm::VariableBaseMSM;
+//!
+//! Round 4 widens it to what the product only RECALLS of upstream (tools/kat_extra.py says why each matters):
+//! `MixedRadixEvaluationDomain` (all four transforms on 7 * 2^3, 49 * 2^2, 5 * 2^3, 25 * 2^2), the witness map over
+//! `GeneralEvaluationDomain` past the field's 2-adicity (which domain upstream PICKS, and h on it), `FixedBaseMSM` + batch
+//! normalisation on the eight groups, `generate_parameters` with the golden toxic waste (tau injected through the RNG the function
+//! samples it from), and the field / group constants themselves.
+use ark_ec::msm::{FixedBaseMSM, VariableBaseMSM};
 use ark_ec::{AffineCurve, PairingEngine, ProjectiveCurve};
-use ark_ff::{BigInteger, Field, PrimeField, Zero};
-use ark_groth16::{create_proof_with_reduction, r1cs_to_qap::LibsnarkReduction, ProvingKey, VerifyingKey};
+use ark_ff::{BigInteger, FftField, FftParameters, Field, FpParameters, PrimeField, Zero};
+use ark_groth16::{create_proof_with_reduction, generate_parameters, r1cs_to_qap::{LibsnarkReduction, R1CSToQAP}, ProvingKey, VerifyingKey};
 use ark_pcd_hip::{marshal, HipCurve};
-use ark_poly::{EvaluationDomain, Radix2EvaluationDomain};
+use ark_poly::{EvaluationDomain, GeneralEvaluationDomain, MixedRadixEvaluationDomain, Radix2EvaluationDomain};
 use ark_relations::lc;
-use ark_relations::r1cs::{ConstraintSynthesizer, ConstraintSystemRef, LinearCombination, SynthesisError, Variable};
+use ark_relations::r1cs::{ConstraintSynthesizer, ConstraintSystem, ConstraintSystemRef, LinearCombination, OptimizationGoal, SynthesisError, Variable};
 use ark_serialize::CanonicalSerialize;
 use std::collections::HashMap;
 use std::fmt::Write as _;
@@ -165,6 +171,155 @@ fn wire<E: HipCurve>(a: &Arrays, out: &mut String) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- round 4: what is only recalled
+
+/// all four transforms of `MixedRadixEvaluationDomain` on the sizes tools/kat_extra.py exported for this field
+fn mixed<F: PrimeField + FftField>(a: &Arrays, fid: usize, out: &mut String) {
+    for (name, arr) in a.iter().filter(|(k, _)| k.starts_with(&format!("x_mixed.f{}_n", fid)) && k.ends_with("_in")) {
+        let x: Vec<F> = fr_vec(arr);
+        let dom = MixedRadixEvaluationDomain::<F>::new(x.len()).expect("a 2^a q^b size within the field's adicities");
+        assert_eq!(dom.size(), x.len(), "the mixed-radix domain must have exactly the exported size");
+        let stem = &name[..name.len() - 3];
+        for (inv, coset) in [(0, 0), (0, 1), (1, 0), (1, 1)].iter() {
+            let mut v = x.clone();
+            match (inv, coset) {
+                (0, 0) => dom.fft_in_place(&mut v), (0, 1) => dom.coset_fft_in_place(&mut v),
+                (1, 0) => dom.ifft_in_place(&mut v), _ => dom.coset_ifft_in_place(&mut v),
+            }
+            emit(out, &format!("{}_i{}c{}", stem, inv, coset), "uint64", &arr.0, &fr_limbs(&v));
+        }
+    }
+}
+
+/// `LibsnarkReduction::witness_map` over `GeneralEvaluationDomain` for a circuit past the 2-adicity of E::Fr: the domain upstream
+/// picks (size) and h on it.  Same synthesis settings as `create_proof` (optimisation goal, `finalize`).
+fn wm_mixed<E: HipCurve>(a: &Arrays, out: &mut String) {
+    let pre = "x_wm.";
+    let z: Vec<E::Fr> = fr_vec(&a[&format!("{}z", pre)]);
+    let ni = a[&format!("{}num_inputs", pre)].1[0] as usize;
+    let circuit = Replay::<E::Fr> { rows: [csr(a, pre, "a"), csr(a, pre, "b"), csr(a, pre, "c")], z, num_inputs: ni };
+    let cs = ConstraintSystem::<E::Fr>::new_ref();
+    cs.set_optimization_goal(OptimizationGoal::Constraints);
+    circuit.generate_constraints(cs.clone()).unwrap();
+    assert!(cs.is_satisfied().unwrap());
+    cs.finalize();
+    let dom = GeneralEvaluationDomain::<E::Fr>::new(cs.num_constraints() + cs.num_instance_variables()).unwrap();
+    emit(out, "x_wm.domain_size", "uint64", &[1], &[dom.size() as u64]);
+    let h = LibsnarkReduction::witness_map::<E::Fr, GeneralEvaluationDomain<E::Fr>>(cs).unwrap();
+    emit(out, "x_wm.h", "uint64", &[h.len(), (E::Fr::size_in_bits() + 63) / 64], &fr_limbs(&h));
+}
+
+fn scalars_fr<E: HipCurve>(a: &Arrays, name: &str) -> Vec<E::Fr> {   // canonical limbs -> field elements
+    a[name].1.chunks(a[name].0[1]).map(|l| {
+        let mut b = <E::Fr as PrimeField>::BigInt::default();
+        b.as_mut().copy_from_slice(l);
+        E::Fr::from_repr(b).expect("reduced scalar")
+    }).collect()
+}
+/// `FixedBaseMSM` exactly as ark-groth16's generator drives it: window from `get_mul_window_size`, table, batch, normalisation
+fn fixed_base<E: HipCurve>(a: &Arrays, out: &mut String) {
+    let c = E::CURVE_ID;
+    let bits = E::Fr::size_in_bits();
+    {
+        let base = E::g1_from(&a[&format!("x_fixed.c{}_g1_base", c)].1, false);
+        let sc = scalars_fr::<E>(a, &format!("x_fixed.c{}_g1_scalars", c));
+        let w = FixedBaseMSM::get_mul_window_size(sc.len());
+        let table = FixedBaseMSM::get_window_table::<E::G1Projective>(bits, w, base.into_projective());
+        let res = FixedBaseMSM::multi_scalar_mul::<E::G1Projective>(bits, w, &table, &sc);
+        let aff = E::G1Projective::batch_normalization_into_affine(&res);
+        let (mut xy, mut inf) = (Vec::new(), Vec::new());
+        for p in &aff { let k = xy.len(); E::push_g1(p, &mut xy, &mut inf); if p.is_zero() { xy[k..].iter_mut().for_each(|w| *w = 0); } }
+        emit(out, &format!("x_fixed.c{}_g1_out_xy", c), "uint64", &[aff.len(), 2 * E::FQ_LIMBS], &xy);
+        emit(out, &format!("x_fixed.c{}_g1_out_inf", c), "uint8", &[aff.len()], &inf.iter().map(|b| *b as u64).collect::<Vec<_>>());
+    }
+    {
+        let base = E::g2_from(&a[&format!("x_fixed.c{}_g2_base", c)].1, false);
+        let sc = scalars_fr::<E>(a, &format!("x_fixed.c{}_g2_scalars", c));
+        let w = FixedBaseMSM::get_mul_window_size(sc.len());
+        let table = FixedBaseMSM::get_window_table::<E::G2Projective>(bits, w, base.into_projective());
+        let res = FixedBaseMSM::multi_scalar_mul::<E::G2Projective>(bits, w, &table, &sc);
+        let aff = E::G2Projective::batch_normalization_into_affine(&res);
+        let (mut xy, mut inf) = (Vec::new(), Vec::new());
+        for p in &aff { let k = xy.len(); E::push_g2(p, &mut xy, &mut inf); if p.is_zero() { xy[k..].iter_mut().for_each(|w| *w = 0); } }
+        emit(out, &format!("x_fixed.c{}_g2_out_xy", c), "uint64", &[aff.len(), 2 * E::G2_DEG * E::FQ_LIMBS], &xy);
+        emit(out, &format!("x_fixed.c{}_g2_out_inf", c), "uint8", &[aff.len()], &inf.iter().map(|b| *b as u64).collect::<Vec<_>>());
+    }
+}
+
+/// An RNG that replays given u64 words: `Fp::rand` fills the element's `BigInteger` limb by limb from `next_u64` (Montgomery image,
+/// then a range check), so feeding it the Montgomery limbs of tau makes `sample_element_outside_domain` return exactly tau.
+struct Replayed { words: Vec<u64>, at: usize }
+impl ark_std::rand::RngCore for Replayed {
+    fn next_u32(&mut self) -> u32 { self.next_u64() as u32 }
+    fn next_u64(&mut self) -> u64 { let w = self.words[self.at % self.words.len()]; self.at += 1; w }
+    fn fill_bytes(&mut self, dest: &mut [u8]) { for ch in dest.chunks_mut(8) { let w = self.next_u64().to_le_bytes(); ch.copy_from_slice(&w[..ch.len()]); } }
+    fn try_fill_bytes(&mut self, dest: &mut [u8]) -> Result<(), ark_std::rand::Error> { self.fill_bytes(dest); Ok(()) }
+}
+/// ark-groth16 `generate_parameters` (the body of `circuit_specific_setup`, /root/reference src/ec_cycle_pcd/mod.rs:69,78) with the
+/// golden toxic waste and the oracle's generators: every query of the key goes back out under the golden names.
+/// (Signature of the era the reference tracks: `generate_parameters(circuit, alpha, beta, gamma, delta, g1_generator, g2_generator, rng)`;
+/// tau is the first `Fr::rand(rng)` outside the domain.)
+fn setup<E: HipCurve>(a: &Arrays, out: &mut String) {
+    let pre = format!("groth16.c{}_", E::CURVE_ID);
+    let z: Vec<E::Fr> = fr_vec(&a[&format!("{}z", pre)]);
+    let ni = a[&format!("{}num_inputs", pre)].1[0] as usize;
+    let tox: Vec<E::Fr> = fr_vec(&a[&format!("{}toxic", pre)]);   // alpha, beta, gamma, delta, tau
+    let l = (E::Fr::size_in_bits() + 63) / 64;
+    let mut rng = Replayed { words: a[&format!("{}toxic", pre)].1[4 * l..5 * l].to_vec(), at: 0 };
+    let g1 = E::g1_from(&a[&format!("x_gens.c{}_g1", E::CURVE_ID)].1, false).into_projective();
+    let g2 = E::g2_from(&a[&format!("x_gens.c{}_g2", E::CURVE_ID)].1, false).into_projective();
+    let circuit = Replay::<E::Fr> { rows: [csr(a, &pre, "a"), csr(a, &pre, "b"), csr(a, &pre, "c")], z, num_inputs: ni };
+    let pk: ProvingKey<E> = generate_parameters::<E, _, _>(circuit, tox[0], tox[1], tox[2], tox[3], g1, g2, &mut rng).unwrap();
+    let mut put1 = |name: &str, pts: &[E::G1Affine], flags: bool| {
+        let (mut xy, mut inf) = (Vec::new(), Vec::new());
+        for p in pts { let k = xy.len(); E::push_g1(p, &mut xy, &mut inf); if p.is_zero() { xy[k..].iter_mut().for_each(|w| *w = 0); } }
+        let shape: Vec<usize> = if flags { vec![pts.len(), 2 * E::FQ_LIMBS] } else { vec![2 * E::FQ_LIMBS] };
+        emit(out, &format!("{}{}", pre, name), "uint64", &shape, &xy);
+        if flags { emit(out, &format!("{}{}_inf", pre, name), "uint8", &[pts.len()], &inf.iter().map(|b| *b as u64).collect::<Vec<_>>()); }
+    };
+    put1("alpha_g1", core::slice::from_ref(&pk.vk.alpha_g1), false);
+    put1("beta_g1", core::slice::from_ref(&pk.beta_g1), false);
+    put1("delta_g1", core::slice::from_ref(&pk.delta_g1), false);
+    put1("a_query", &pk.a_query, true);
+    put1("b_g1_query", &pk.b_g1_query, true);
+    put1("h_query", &pk.h_query, true);
+    put1("l_query", &pk.l_query, true);
+    put1("gamma_abc_g1", &pk.vk.gamma_abc_g1, true);
+    let mut put2 = |name: &str, pts: &[E::G2Affine], flags: bool| {
+        let (mut xy, mut inf) = (Vec::new(), Vec::new());
+        for p in pts { let k = xy.len(); E::push_g2(p, &mut xy, &mut inf); if p.is_zero() { xy[k..].iter_mut().for_each(|w| *w = 0); } }
+        let w = 2 * E::G2_DEG * E::FQ_LIMBS;
+        let shape: Vec<usize> = if flags { vec![pts.len(), w] } else { vec![w] };
+        emit(out, &format!("{}{}", pre, name), "uint64", &shape, &xy);
+        if flags { emit(out, &format!("{}{}_inf", pre, name), "uint8", &[pts.len()], &inf.iter().map(|b| *b as u64).collect::<Vec<_>>()); }
+    };
+    put2("beta_g2", core::slice::from_ref(&pk.vk.beta_g2), false);
+    put2("gamma_g2", core::slice::from_ref(&pk.vk.gamma_g2), false);
+    put2("delta_g2", core::slice::from_ref(&pk.vk.delta_g2), false);
+    put2("b_g2_query", &pk.b_g2_query, true);
+}
+
+/// the constants themselves: per field the multiplicative generator (the coset shift of every coset transform), the 2-adic root of unity,
+/// the 2-adicity and -- where upstream defines them -- the small-subgroup base and its adicity; per curve the group generators
+fn consts_field<F: PrimeField + FftField>(fid: usize, out: &mut String) {
+    emit(out, &format!("x_consts.f{}_generator", fid), "uint64", &[(F::size_in_bits() + 63) / 64], &fr_limbs(&[F::multiplicative_generator()]));
+    emit(out, &format!("x_consts.f{}_two_adic_root", fid), "uint64", &[(F::size_in_bits() + 63) / 64], &fr_limbs(&[F::two_adic_root_of_unity()]));
+    emit(out, &format!("x_consts.f{}_two_adicity", fid), "uint64", &[1], &[<F::FftParams as FftParameters>::TWO_ADICITY as u64]);
+    if let Some(b) = <F::FftParams as FftParameters>::SMALL_SUBGROUP_BASE {
+        emit(out, &format!("x_consts.f{}_small_subgroup_base", fid), "uint64", &[1], &[b as u64]);
+        emit(out, &format!("x_consts.f{}_small_subgroup_base_adicity", fid), "uint64", &[1],
+             &[<F::FftParams as FftParameters>::SMALL_SUBGROUP_BASE_ADICITY.unwrap() as u64]);
+    }
+}
+fn consts_curve<E: HipCurve>(out: &mut String) {
+    let (mut xy, mut inf) = (Vec::new(), Vec::new());
+    E::push_g1(&E::G1Affine::prime_subgroup_generator(), &mut xy, &mut inf);
+    emit(out, &format!("x_consts.c{}_g1_generator", E::CURVE_ID), "uint64", &[xy.len()], &xy);
+    let (mut xy, mut inf) = (Vec::new(), Vec::new());
+    E::push_g2(&E::G2Affine::prime_subgroup_generator(), &mut xy, &mut inf);
+    emit(out, &format!("x_consts.c{}_g2_generator", E::CURVE_ID), "uint64", &[xy.len()], &xy);
+}
+
 #[test]
 fn kat() {
     let a = load();
@@ -178,6 +333,16 @@ fn kat() {
     groth16::<ark_mnt4_298::MNT4_298>(&a, &mut out); groth16::<ark_mnt6_298::MNT6_298>(&a, &mut out);
     wire::<ark_mnt4_298::MNT4_298>(&a, &mut out); wire::<ark_mnt6_298::MNT6_298>(&a, &mut out);
     wire::<ark_mnt4_753::MNT4_753>(&a, &mut out); wire::<ark_mnt6_753::MNT6_753>(&a, &mut out);
+    // round 4
+    mixed::<ark_mnt4_298::Fq>(&a, 0, &mut out); mixed::<ark_mnt4_753::Fq>(&a, 2, &mut out);
+    wm_mixed::<ark_mnt6_753::MNT6_753>(&a, &mut out);   // Fr of MNT6-753 = field 2 (2-adicity 15)
+    fixed_base::<ark_mnt4_298::MNT4_298>(&a, &mut out); fixed_base::<ark_mnt6_298::MNT6_298>(&a, &mut out);
+    fixed_base::<ark_mnt4_753::MNT4_753>(&a, &mut out); fixed_base::<ark_mnt6_753::MNT6_753>(&a, &mut out);
+    setup::<ark_mnt4_298::MNT4_298>(&a, &mut out); setup::<ark_mnt6_298::MNT6_298>(&a, &mut out);
+    consts_field::<ark_mnt4_298::Fq>(0, &mut out); consts_field::<ark_mnt4_298::Fr>(1, &mut out);
+    consts_field::<ark_mnt4_753::Fq>(2, &mut out); consts_field::<ark_mnt4_753::Fr>(3, &mut out);
+    consts_curve::<ark_mnt4_298::MNT4_298>(&mut out); consts_curve::<ark_mnt6_298::MNT6_298>(&mut out);
+    consts_curve::<ark_mnt4_753::MNT4_753>(&mut out); consts_curve::<ark_mnt6_753::MNT6_753>(&mut out);
     std::fs::write(concat!(env!("CARGO_MANIFEST_DIR"), "/tests/kat_outputs.txt"), &out).unwrap();
     println!("wrote {} lines to rust/tests/kat_outputs.txt: now run `python tools/check_kat.py`", out.lines().count());
 }

@@ -17,6 +17,7 @@ INPUT_KEYS = {
     "msm": lambda k: k.endswith(("_bases", "_inf", "_scalars")),
     "fft": lambda k: k.endswith("_in"),
     "pairing": lambda k: k.endswith(("_p", "_q")),
+    # (the key's queries are INPUTS of the proof KAT and, since round 4, also OUTPUTS of the generate_parameters KAT: kat.rs writes them back)
     "groth16": lambda k: not k.endswith(("_h", "_proof", "_proof_inf")),
     "wire": lambda k: k.endswith(("_xy", "_inf")),
 }
@@ -35,6 +36,13 @@ def main():
         for k in g.files:
             if want(k):
                 out.append(line(f"{f}.{k}", g[k]))
+    # what the product only recalls of upstream (mixed-radix domains, the domain choice past the 2-adicity, FixedBaseMSM, constants):
+    # inputs from seeds, expected values recomputed by tools/check_kat.py (tools/kat_extra.py)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import kat_extra
+    for name, arr in kat_extra.inputs():
+        out.append(line(name, arr))
     path = os.path.join(ROOT, "rust", "tests", "kat_inputs.txt")
     with open(path, "w") as fh:
         fh.write("\n".join(out) + "\n")
