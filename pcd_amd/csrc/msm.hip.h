@@ -191,7 +191,10 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
 #endif
 constexpr int MSM_SORT_UNROLL = PCD_SORT_UNROLL;  // entries per lane in flight in the per-bin counting sort
 constexpr int MSM_BIN_SHIFT = 9;          // 512 keys per bin
-constexpr int MSM_TILE = 2048;            // scalars per workgroup in passes 0 / 1
+#ifndef PCD_MSM_TILE
+#define PCD_MSM_TILE 2048
+#endif
+constexpr int MSM_TILE = PCD_MSM_TILE;    // scalars per workgroup in passes 0 / 1
 constexpr uint32_t MSM_MAX_BINS = 8192;   // LDS histogram of a workgroup: 32 KiB
 
 template <int NS, bool WRITE>
