@@ -248,6 +248,12 @@ int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode);
  * device to device, the pointwise step and the last transform run on device 0 -- about 45 % of the map's time leaves the critical path of
  * device 0, which also carries its share of the MSMs.  0: everything on device 0.  The proof is the same either way. */
 int pcdhip_groth16_set_witness_split(pcdhip_ctx* ctx, int on);
+/* Order of the stages of pcdhip_groth16_prove.  0 (default): the four MSMs over the assignment first, the witness map concurrently with them,
+ * the h MSM behind the map.  1: the witness map first with the device to itself, then all five MSMs at once -- built in round 4 on the
+ * suspicion that the map (whose short dependent kernels wait behind the MSMs' one-wave-per-SIMD grids) serialised the h MSM at the end;
+ * measured SLOWER on every configuration (the proof is bound by the sum of its MSMs' throughput), kept as an A/B knob.
+ * The proof is the same either way. */
+int pcdhip_groth16_set_schedule(pcdhip_ctx* ctx, int mode);
 
 /* ---- the caller side of the path -- key generation -------------------------------------
  * Replaces ark-ec `FixedBaseMSM::{get_window_table, multi_scalar_mul}` + `batch_normalization_into_affine`:

@@ -502,6 +502,12 @@ int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode) {
   ctx->g16_assembly = mode;
   return PCDHIP_OK;
 }
+int pcdhip_groth16_set_schedule(pcdhip_ctx* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 1) return PCDHIP_E_ARG;
+  ctx->g16_schedule = mode;
+  for (pcdhip_ctx* p : ctx->peers) if (p != ctx) p->g16_schedule = mode;
+  return PCDHIP_OK;
+}
 int pcdhip_groth16_set_witness_split(pcdhip_ctx* ctx, int on) {
   if (!ctx) return PCDHIP_E_ARG;
   ctx->wm_split = on != 0;
@@ -1293,7 +1299,7 @@ struct G16Run {
   // others reuse its list.  The two variable-base products of the assembly, s*A and r*B_1, are either one-lane products queued right
   // behind the A / B_1 MSMs on their high-priority streams (whole-key runs only), or two more MSMs over the same bases with every
   // scalar scaled by s / r (`folded`; the form that also adds up across devices).
-  int launch_assignment(size_t lo, size_t cnt, bool folded) {
+  int launch_assignment(size_t lo, size_t cnt, bool folded, hipEvent_t after = nullptr) {
     const GroupEntry& g1 = group_entry(cid, 1);
     const GroupEntry& g2 = group_entry(cid, 2);
     const int PRODUCE = MSM_SHARE_PRODUCE, CONSUME = MSM_SHARE_CONSUME, NONE = MSM_SHARE_NONE;
@@ -1311,7 +1317,7 @@ struct G16Run {
       jobs[nj++] = {&g2, pk->b_g2_query->view(0), zc, n, msm_g2, 5, nullptr, nullptr, CONSUME};             // B
       jobs[nj++] = {&g1, pk->l_query->view(0), zc, n, slot(1), 2, nullptr, nullptr, CONSUME};               // l'
     }
-    for (int k = 0; k < nj; k++) { int rc = launch(k, ctx->g16_ready); if (rc) return rc; }
+    for (int k = 0; k < nj; k++) { int rc = launch(k, after ? after : ctx->g16_ready); if (rc) return rc; }
     return PCDHIP_OK;
   }
   // the h MSM over the entries [hlo, hlo + cnt) of h (entries [0, cnt) of this device's h query), once `after` has fired
@@ -1378,6 +1384,12 @@ int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_cs
   EventSet<3> ev;
   TRY(ev.create());
   TRY(hipEventRecord(ev[0], ctx->stream));
+  const bool split3 = G >= 3 && !(A && B && C) && ctx->wm_split && pk->shards[1]->r1cs_dev && pk->shards[2]->r1cs_dev &&
+                      pk->shards[1]->rows == rows && pk->shards[2]->rows == rows;
+  // (pcdhip_groth16_set_schedule 1, off by default: measured slower) a device that carries a chain of the witness map starts its MSMs only
+  // when that chain is through
+  const bool map_first = ctx->g16_schedule == 1;
+  auto carries_chain = [&](size_t g) { return g == 0 || (split3 && g <= 2); };
   std::vector<G16Run> runs(G);
   for (size_t g = 0; g < G; g++) {
     runs[g].ctx = ctx->peers[g];
@@ -1385,6 +1397,7 @@ int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_cs
     ctx->peers[g]->msm_sort = ctx->msm_sort;
     rc = runs[g].prepare(z, r_mont, s_mont, n);
     if (rc) return rc;
+    if (map_first && carries_chain(g)) continue;
     rc = runs[g].launch_assignment(pk->lo[g], pk->lo[g + 1] - pk->lo[g], true);
     if (rc) return rc;
   }
@@ -1393,8 +1406,6 @@ int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_cs
   DevCsr mats[3];
   if (A && B && C) { TRY(hipStreamSynchronize(ctx->stream)); rc = upload_three(ctx, A, B, C, fe, m, mats); if (rc) return rc; }
   else for (int k = 0; k < 3; k++) mats[k] = pk0->mats[k];
-  const bool split3 = G >= 3 && !(A && B && C) && ctx->wm_split && pk->shards[1]->r1cs_dev && pk->shards[2]->r1cs_dev &&
-                      pk->shards[1]->rows == rows && pk->shards[2]->rows == rows;
   if (split3) {
     // chains b and c on devices 1 and 2 (their z is resident since prepare()), each into its own AUX_A, then device to device into
     // device 0's AUX_B / AUX_C; chain a on device 0 meanwhile; the pointwise step and the last transform on device 0
@@ -1409,6 +1420,7 @@ int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_cs
       TRY(hipMemcpyPeerAsync(ctx->aux_ws.buf[g == 1 ? AUX_B : AUX_C], ctx->device, Cg->aux_ws.buf[AUX_A], Cg->device, vb, Cg->stream));
       if (!Cg->wm_ev) TRY(hipEventCreateWithFlags(&Cg->wm_ev, hipEventDisableTiming));
       TRY(hipEventRecord(Cg->wm_ev, Cg->stream));
+      if (map_first) { rc = runs[g].launch_assignment(pk->lo[g], pk->lo[g + 1] - pk->lo[g], true, Cg->wm_ev); if (rc) return rc; }
     }
     BIND();
     rc = witness_chain_dev(ctx, fr, mats[0], 0, runs[0].z_dev, ni, dom, AUX_A);
@@ -1424,6 +1436,7 @@ int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_cs
   }
   TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_A], runs[0].h_can, (uint32_t)n, 2));
   TRY(hipEventRecord(ev[1], ctx->stream));
+  if (map_first) { rc = runs[0].launch_assignment(pk->lo[0], pk->lo[1] - pk->lo[0], true, ev[1]); if (rc) return rc; BIND(); }
   const size_t sw = runs[0].sw, sb = runs[0].sb;
   for (size_t g = 0; g < G; g++) {
     const size_t hlo = std::min(pk->hlo[g], hl), hhi = std::min(pk->hlo[g + 1], hl);
@@ -1513,9 +1526,15 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   // 580 vs 536 ms (753-bit, 2^20), 99 vs 120 ms (753-bit, 5 * 2^14).
   const size_t fold_below = fe.abi_words > 12 ? (1u << 18) : (1u << 17);
   const bool folded = ctx->g16_assembly == 1 || (ctx->g16_assembly == 0 && m + 4 <= fold_below);
-  rc = run.launch_assignment(0, m + 4, folded);
-  if (rc) return rc;
-  // ---- K1: h, on the context's stream, while the MSMs above run
+  // Schedule (pcdhip_groth16_set_schedule).  Default 0: the four assignment MSMs are launched BEFORE the witness map and run concurrently
+  // with it; the h MSM follows the map.  Inside a proof the map's ~30 short dependent kernels wait behind the MSMs' accumulate grids (the 8 ms
+  // map of a 753-bit proof ends at 160 ms) and the h MSM runs last -- which LOOKS like a serialised tail, so round 4 built mode 1: the map
+  // first with the device to itself, then all five MSMs at once.  Measured on one box (tools/ab_step.py, profiles/r04_ab_prove_schedule.txt):
+  // mode 1 is SLOWER -- 23.4 against 20.3 ms (MNT4-298, 2^20), 5.9 against 4.9 ms (MNT6-298, 2^16), 202 against 196.5 ms (MNT4-753, 2^20): the
+  // proof is bound by the sum of its MSMs' throughput either way, and mode 1 adds the map's time in front while mode 0 hides it.
+  const bool map_first = ctx->g16_schedule == 1;
+  if (!map_first) { rc = run.launch_assignment(0, m + 4, folded); if (rc) return rc; }
+  // ---- K1: h, on the context's stream
   DevCsr mats[3];
   if (A && B && C) { TRY(hipStreamSynchronize(st)); rc = upload_three(ctx, A, B, C, fe, m, mats); if (rc) return rc; }  // (staging slot AUX_SCAL is reused)
   else for (int k = 0; k < 3; k++) mats[k] = pk->mats[k];
@@ -1525,6 +1544,7 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   if (dom_used.n != dom.n) return PCDHIP_E_ARG;
   TRY(fe.convert(st, (const uint32_t*)ctx->aux_ws.buf[AUX_A], run.h_can, (uint32_t)n, 2));
   TRY(hipEventRecord(ev[1], st));
+  if (map_first) { rc = run.launch_assignment(0, m + 4, folded, ev[1]); if (rc) return rc; }
   rc = run.launch_h(0, std::min<size_t>(pk->h_query->n, n), ev[1]);
   if (rc) return rc;
   rc = run.join();

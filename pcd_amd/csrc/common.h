@@ -112,6 +112,7 @@ struct pcdhip_ctx {
   hipEvent_t xstream_ev = nullptr;  // pcdhip_stream_wait: ordering against a caller-owned stream (e.g. the RCCL stream)
   hipEvent_t wm_ev = nullptr;       // sharded prove: this device's chain of the witness map has landed in device 0's buffers
   bool wm_split = true;             // pcdhip_groth16_set_witness_split
+  int g16_schedule = 0;             // pcdhip_groth16_set_schedule: 0 assignment MSMs first, the witness map under them; 1 the map first (slower)
   std::string last_hip_error;
 };
 

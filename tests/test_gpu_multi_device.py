@@ -51,8 +51,11 @@ def test_sharded_groth16_prove(co, gpu_ctx, curve, nc, parts):
     want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=8)
     pk = gpu_ctx.g16_pk_upload(keys.host_struct(), curve)
     single, _ = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
+    gpu_ctx.groth16_set_schedule(1)               # the witness map first, then all five MSMs: same proof
+    single1, _ = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
+    gpu_ctx.groth16_set_schedule(0)
     pk.free()
-    assert np.array_equal(single, want)
+    assert np.array_equal(single, want) and np.array_equal(single1, want)
     mctx = capi.Context(devices=_devices(parts))
     try:
         mpk = mctx.g16_pk_upload(keys.host_struct(), curve)
@@ -104,10 +107,11 @@ def test_witness_map_chains_on_three_devices(co, gpu_ctx, curve, nc, parts):
     try:
         mpk = mctx.g16_pk_upload(keys.host_struct(), curve)
         mctx.g16_pk_set_r1cs(mpk, r)
-        for on in (1, 0, 1):
+        for on, sched in ((1, 0), (0, 0), (1, 1), (0, 1), (1, 0)):
             mctx.groth16_set_witness_split(on)
+            mctx.groth16_set_schedule(sched)      # 1: every device's MSMs behind its chain of the witness map
             got, inf = mctx.groth16_prove(mpk, r, rs[0], rs[1], resident_r1cs=True)
-            assert np.array_equal(got, want) and np.array_equal(inf, winf), on
+            assert np.array_equal(got, want) and np.array_equal(inf, winf), (on, sched)
         # another statement under the same key and matrices: scale the witness-independent part by proving with other blinding factors
         rs2 = co.gen_field(fr, 2, seed=853)
         want2, _ = co.groth16_prove(keys, r, rs2[0], rs2[1], nthreads=8)

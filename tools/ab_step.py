@@ -18,9 +18,15 @@ rs = co.gen_field(fr, 2, seed=79)
 pk = ctx.g16_pk_upload(keys.host_struct(), curve)
 ctx.g16_pk_set_r1cs(pk, r)
 r.z = capi.pinned_like(r.z)
-for _ in range(3):
-    ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
-walls = []
-for _ in range(7):
-    t0 = time.perf_counter(); ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True); walls.append((time.perf_counter() - t0) * 1e3)
-print(f"lib={os.environ.get('PCDHIP_LIB', 'in-tree')} curve={curve} prove wall ms median {np.median(walls):.3f} min {min(walls):.3f}; device {ctx.groth16_last_timings()}", flush=True)
+first = None
+for sched in [int(x) for x in os.environ.get("AB_SCHEDULES", "0,1,0,1").split(",")]:   # 0: assignment MSMs first (default); 1: witness map first
+    ctx.groth16_set_schedule(sched)
+    for _ in range(3):
+        proof, _ = ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
+    first = proof if first is None else first
+    assert np.array_equal(proof, first)
+    walls = []
+    for _ in range(7):
+        t0 = time.perf_counter(); ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True); walls.append((time.perf_counter() - t0) * 1e3)
+    tm = {k: round(float(v), 2) for k, v in ctx.groth16_last_timings().items()}
+    print(f"lib={os.environ.get('PCDHIP_LIB', 'in-tree')} curve={curve} schedule={sched} prove wall ms median {np.median(walls):.3f} min {min(walls):.3f}; device {tm}", flush=True)
