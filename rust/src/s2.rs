@@ -12,7 +12,6 @@
 //! Source only (no Rust toolchain in the build container); the C-ABI call sequence made here -- ONE upload of a base vector, MSMs
 //! over prefixes of it, in-place transforms of host vectors -- is what tests/c_driver/driver.c runs from plain C against the oracle.
 use crate::ffi;
-use crate::marshal;
 use crate::prover::{with_device, Device};
 use crate::HipCurve;
 use ark_ec::AffineCurve;
@@ -145,9 +144,8 @@ fn field_of(t: TypeId) -> Option<(c_int, usize)> {
 /// The registered `ark_poly::domain::hook::FftHook`: in place on the vector's own storage (an `Fp320` / `Fp768` is its Montgomery
 /// `BigInteger` limbs in memory, the C-ABI's encoding -- `marshal::limbs_of` asserts the size).
 unsafe fn fft_hook(field: TypeId, data: *mut u8, len: usize, log_n: u32, inverse: bool) -> bool {
-    let (field_id, limbs) = match field_of(field) { Some(f) => f, None => return false };
+    let (field_id, _limbs) = match field_of(field) { Some(f) => f, None => return false };
     if log_n < MIN_LOG_N || len != 1usize << log_n || (data as usize) % core::mem::align_of::<u64>() != 0 { return false; }
-    let _ = limbs;
     with_device(|dev| ffi::check(ffi::pcdhip_fft(dev.ctx, field_id, data as *mut u64, log_n, inverse as c_int, 0))).is_ok()
 }
 
@@ -155,7 +153,5 @@ unsafe fn fft_hook(field: TypeId, data: *mut u8, len: usize, log_n: u32, inverse
 pub fn install() -> bool {
     let a = ark_ec::msm::hook::set_msm_hook(msm_hook);
     let b = ark_poly::domain::hook::set_fft_hook(fft_hook);
-    // (mention marshal so that a build without the Groth16 seam still type-checks the shared helpers)
-    let _ = marshal::limbs_of::<ark_mnt4_298::Fr>;
     a && b
 }
