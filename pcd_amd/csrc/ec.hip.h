@@ -444,6 +444,59 @@ struct EC {
     return o;
   }
 
+  // The same addition with the accumulator held OUTSIDE the register file (ST: four slots of N words per lane -- msm.hip.h keeps them in LDS):
+  // every coordinate is fetched when a product needs it and written back as soon as its new value exists, so at most one of the four is in
+  // registers at a time.  The point of it: the 298-bit G1 accumulation needs 206 registers with the accumulator resident -- two waves per
+  // SIMD; without it the working set is P, R, PP, RR, PPP, Q, one operand and the product's temporaries (experiment PCD_ACC_LDS).
+  // ST: ld(slot) -> F (as stored), st(slot, F), bool& inf().  Slot 0 holds X's unreduced limbs (as uint32 images of the signed limbs).
+  template <class ST>
+  PCD_HD static void madd_lz_st(ST& st, const A& q) {
+    typedef typename F::Lz L;
+    if (q.is_inf()) return;
+    if (st.inf()) { st.st(0, q.x); st.st(1, q.y); st.st(2, F::one()); st.st(3, F::one()); st.inf() = false; return; }
+    auto as_lz = [](const F& f) { L l;
+#pragma unroll
+      for (int i = 0; i < F::N; i++) l.v[i] = (int32_t)f.v[i];
+      return l; };
+    auto as_f = [](const L& l) { F f;
+#pragma unroll
+      for (int i = 0; i < F::N; i++) f.v[i] = (uint32_t)l.v[i];
+      return f; };
+    const F U2 = F::lz_mul(q.x.lz(), st.ld(2).lz());
+    const F S2 = F::lz_mul(q.y.lz(), st.ld(3).lz());
+    const L P = F::lz_carry(F::template lz_sub<2>(U2.lz(), as_lz(st.ld(0))));
+    const L R = F::lz_carry(F::template lz_sub<0>(S2.lz(), st.ld(1).lz()));
+    const F PP = F::lz_sqr(P);
+    const F RR = F::lz_sqr(R);
+    if (PP.is_zero()) {  // same x: the same point (double it the ordinary way) or opposite points -- through the ordinary record
+      AccLz p;
+      p.X = as_lz(st.ld(0)); p.Y = st.ld(1); p.ZZ = st.ld(2); p.ZZZ = st.ld(3); p.inf = false;
+      AccLz o = RR.is_zero() ? lz_from(dbl(lz_to_jac(p))) : lz_infinity();
+      st.st(0, as_f(o.X)); st.st(1, o.Y); st.st(2, o.ZZ); st.st(3, o.ZZZ); st.inf() = o.inf;
+      return;
+    }
+    const L pp = PP.lz();
+    const F PPP = F::lz_mul(P, pp);
+    const F Q = F::lz_mul(as_lz(st.ld(0)), pp);
+    L x3;
+    {  // X3 = R^2 - PPP - 2Q + 8p
+      L t;
+#pragma unroll
+      for (int i = 0; i < F::N; i++)
+        t.v[i] = (int32_t)RR.v[i] - (int32_t)PPP.v[i] - (int32_t)(Q.v[i] << 1) + (int32_t)(F::Params::mod4(i) << 1);
+      x3 = F::lz_carry(t);
+    }
+    const L t2 = F::template lz_sub<2>(Q.lz(), x3);
+    st.st(0, as_f(x3));
+    const L ppp = PPP.lz();
+    {
+      const L y1n = F::template lz_sub<0>(F::zero().lz(), st.ld(1).lz());
+      st.st(1, F::lz_dot2(R, t2, y1n, ppp));
+    }
+    st.st(2, F::lz_mul(st.ld(2).lz(), pp));
+    st.st(3, F::lz_mul(st.ld(3).lz(), ppp));
+  }
+
   // the same product with a fixed 4-bit window (one lane: 14 group operations for the table, then 4 doublings and at
   // most one addition per nibble, leading zero nibbles skipped); `table` = 15 caller-provided Jacobian slots
   PCD_HD static J mul_w4(const J& p, const uint32_t* k, int nwords, J* table) {

@@ -505,6 +505,61 @@ struct MsmRunLazy {
     a = EC<G>::lz_infinity();
   }
 };
+// EXPERIMENT (PCD_ACC_LDS=1, with PCD_ACC_WAVES_G1=3): the same running sum with the four coordinates in per-lane LDS slots
+// ([coordinate][16-byte piece][lane]: a wave's access is conflict-free ds_read_b128 / ds_write_b128), EC::madd_lz_st -- so that the
+// register allocation can aim at three waves per SIMD.  One wave per workgroup: 4 x 3 x 64 x 16 B = 12 KB, 144 KB for the 12 waves of a CU.
+#ifndef PCD_ACC_LDS
+#define PCD_ACC_LDS 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+template <class G>
+struct MsmRunLazyLds {
+  typedef typename G::F F;
+  typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) V4* LdsV4;
+  static constexpr int CH = (F::N + 3) / 4;
+  struct Store {
+    LdsV4 box;
+    bool is_inf;
+    PCD_DEV bool& inf() { return is_inf; }
+    PCD_DEV F ld(int slot) const {
+      F r;
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        const V4 w = box[(slot * CH + k) * 64 + threadIdx.x];
+        r.v[4 * k] = w.x;
+        if (4 * k + 1 < F::N) r.v[4 * k + 1] = w.y;
+        if (4 * k + 2 < F::N) r.v[4 * k + 2] = w.z;
+        if (4 * k + 3 < F::N) r.v[4 * k + 3] = w.w;
+      }
+      return r;
+    }
+    PCD_DEV void st(int slot, const F& a) {
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        V4 w;
+        w.x = a.v[4 * k];
+        w.y = 4 * k + 1 < F::N ? a.v[4 * k + 1] : 0u;
+        w.z = 4 * k + 2 < F::N ? a.v[4 * k + 2] : 0u;
+        w.w = 4 * k + 3 < F::N ? a.v[4 * k + 3] : 0u;
+        box[(slot * CH + k) * 64 + threadIdx.x] = w;
+      }
+    }
+  };
+  Store s;
+  PCD_DEV MsmRunLazyLds() {
+    __shared__ V4 accbox[4 * CH * 64];
+    s.box = (LdsV4)accbox;
+    s.is_inf = true;
+  }
+  PCD_DEV void add(const Aff<F>& q) { EC<G>::madd_lz_st(s, q); }
+  PCD_DEV void flush(uint32_t* dst) {
+    if (s.is_inf) { F::zero().store(dst + 2 * F::WORDS); return; }
+    s.ld(0).store(dst); s.ld(1).store(dst + F::WORDS); s.ld(2).store(dst + 2 * F::WORDS); s.ld(3).store(dst + 3 * F::WORDS);
+    s.is_inf = true;
+  }
+};
+#endif
 // a point written by msm_accumulate's flush, as a reduced Jacobian point; WORDS = u32 words of one flushed record
 template <class G, bool XYZZ = MsmUseXyzz<G>::value>
 struct MsmStoredPlain {  // XYZZ record
@@ -590,7 +645,11 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
   cur.seek(off, nkeys, start);
   bool open_start = cur.key_start < start;  // current run began in an earlier chunk
   // the running sum: Jacobian, or (G1 of the 298-bit curves) the lazily reduced accumulator of EC::madd_lz
+#if PCD_ACC_LDS
+  typename std::conditional<LazyCapable<F>::value, MsmRunLazyLds<GA>, MsmRunPlain<GA>>::type acc;
+#else
   typename std::conditional<LazyCapable<F>::value, MsmRunLazy<GA>, MsmRunPlain<GA>>::type acc;
+#endif
   // The next point is prefetched while the current addition runs -- except for the 753-bit fields, whose products are
   // function calls: the 54 .. 162 registers of a prefetched point are live across eleven calls per addition and get spilled
   // around every one of them (same-box A/B on MI355X: G1-753 31.4 -> 27.5 ms at 2^19, split Fq2-753 37.6 -> 33.3 ms at 2^17,
