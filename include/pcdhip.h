@@ -113,7 +113,7 @@ int pcdhip_msm_collect(pcdhip_ctx* ctx, int ticket, uint64_t* out_xyz_mont);
  * collective is enqueued on) wait for that MSM -- no host wait -- and frees the ticket.  Before a slot is written again its reader
  * must have been ordered in front of the context's stream (pcdhip_stream_wait direction 0), which every submission follows.
  * Several shard MSMs then overlap each other and the exchange of earlier ones, like pcdhip_msm_submit / collect on one GPU.
- * An unreduced scalar is not reported on this path. */
+ * An unreduced scalar (PCDHIP_E_ARG from pcdhip_msm_dev) is reported on this path by the NEXT submission that reuses the ticket's slot. */
 int pcdhip_msm_submit_partial(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset,
                               size_t n, uint64_t* out_xyz_device_slots, size_t slot_stride_bytes, int* ticket);
 int pcdhip_msm_ticket_wait(pcdhip_ctx* ctx, int ticket, void* other_stream);

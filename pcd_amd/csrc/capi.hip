@@ -579,6 +579,14 @@ static int msm_submit_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t 
   ctx->pipe_next = (slot + 1) % pcdhip_ctx::PIPE_SLOTS;
   if (!ctx->pipe_host) TRY(hipHostMalloc((void**)&ctx->pipe_host, pcdhip_ctx::PIPE_SLOTS * pcdhip_ctx::PIPE_HOST_WORDS * 8, hipHostMallocDefault));
   if (!ctx->pipe_done[slot]) TRY(hipEventCreateWithFlags(&ctx->pipe_done[slot], hipEventDisableTiming));
+  if (ctx->pipe_partial[slot]) {
+    // the slot's previous ticket was handed to another stream (pcdhip_msm_ticket_wait), so nobody has looked at its error word and its
+    // device-to-host copy may still be in flight: wait for that MSM (long finished in a pipelined loop: it was submitted PIPE_SLOTS
+    // submissions ago and its gather has been consumed) before the word is reset, and report an unreduced scalar HERE
+    TRY(hipEventSynchronize(ctx->pipe_done[slot]));
+    ctx->pipe_partial[slot] = false;
+    if ((uint32_t)ctx->pipe_host[(size_t)slot * pcdhip_ctx::PIPE_HOST_WORDS + pcdhip_ctx::PIPE_HOST_WORDS - 1]) return PCDHIP_E_ARG;
+  }
   const GroupEntry& ge = group_entry(bases->curve_id, bases->group_id);
   const size_t jac_b = (size_t)ge.point_words / 2 * 3 * 4, jac_abi_b = (size_t)ge.point_abi_words / 2 * 3 * 4;
   MsmWorkspace& ws = ctx->g16_ws[2 + slot];
@@ -618,6 +626,7 @@ int pcdhip_msm_ticket_wait(pcdhip_ctx* ctx, int ticket, void* other_stream) {
   BIND();
   TRY(hipStreamWaitEvent((hipStream_t)other_stream, ctx->pipe_done[ticket], 0));
   ctx->pipe_busy[ticket] = false;  // only once the other stream IS ordered behind the MSM: a failed wait keeps the ticket
+  ctx->pipe_partial[ticket] = true;
   return PCDHIP_OK;
 }
 int pcdhip_msm_collect(pcdhip_ctx* ctx, int ticket, uint64_t* out_xyz) {

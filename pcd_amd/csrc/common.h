@@ -100,6 +100,7 @@ struct pcdhip_ctx {
   // with that stream's workspace); results land in page-locked host memory
   static constexpr int PIPE_SLOTS = 4;
   bool pipe_busy[PIPE_SLOTS] = {false, false, false, false};
+  bool pipe_partial[PIPE_SLOTS] = {};   // the slot's last ticket was released by pcdhip_msm_ticket_wait: its error word is checked at the next submit
   hipEvent_t pipe_done[PIPE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t* pipe_host = nullptr;  // PIPE_SLOTS x PIPE_HOST_WORDS u64
   static constexpr size_t PIPE_HOST_WORDS = 256;  // >= one Jacobian point in the C-ABI image (216 u64 for Fq3-753) + the error word

@@ -352,6 +352,24 @@ def test_submit_partial_tickets(co, gpu_ctx):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     with pytest.raises(Exception):
         ctx.msm_ticket_wait(0, ts)                    # not outstanding any more
+    # an unreduced scalar on this path is reported by the next submission that reuses the ticket's slot (nobody collects a partial ticket)
+    bad = sc[:9000].copy()
+    bad[17] = 0xFFFFFFFFFFFFFFFF
+    badbuf = ctx.buf_upload(fr, bad)
+    t_bad = ctx.msm_submit_partial(b, badbuf, slots.data_ptr(), 8 * limbs, offset=0, n=9000)
+    ctx.msm_ticket_wait(t_bad, ts)
+    outcomes = []
+    for q in range(4):                                # round robin: one of the next four submissions lands on that slot
+        try:
+            t = ctx.msm_submit_partial(b, parts[q], slots.data_ptr(), 8 * limbs, offset=q * 9000, n=9000)
+            ctx.msm_ticket_wait(t, ts)
+            outcomes.append(t)
+        except Exception:
+            outcomes.append("error")
+    assert outcomes.count("error") == 1, outcomes
+    torch.cuda.synchronize()
+    ctx.sync()
+    badbuf.free()
     b.free()
     for p in parts:
         p.free()
