@@ -363,8 +363,8 @@ struct EC {
         s0[i] = (int64_t)RR.c0.v[i] - (int64_t)PPP.c0.v[i] - 2 * (int64_t)Q.c0.v[i];
         s1[i] = (int64_t)RR.c1.v[i] - (int64_t)PPP.c1.v[i] - 2 * (int64_t)Q.c1.v[i];
       }
-      o.X.c0 = B_::from_signed_sum(s0, 6);
-      o.X.c1 = B_::from_signed_sum(s1, 6);
+      o.X.c0 = B_::from_signed_sum(s0);
+      o.X.c1 = B_::from_signed_sum(s1);
     }
     const L t0 = B_::lz_carry(B_::template lz_sub<0>(Q.c0.lz(), o.X.c0.lz())), t1 = B_::lz_carry(B_::template lz_sub<0>(Q.c1.lz(), o.X.c1.lz()));
     const L y0n = B_::template lz_sub<0>(B_::zero().lz(), p.Y.c0.lz()), y1n = B_::template lz_sub<0>(B_::zero().lz(), p.Y.c1.lz());

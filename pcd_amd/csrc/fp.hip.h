@@ -36,7 +36,7 @@ namespace pcd {
     static constexpr uint32_t INV = PFX28##_INV;                                                              \
     static constexpr int EST_SHIFT = PFX28##_EST_SHIFT;                                                       \
     static constexpr uint32_t EST_RECIP = PFX28##_EST_RECIP;                                                  \
-    static constexpr double RECIP_D = PFX28##_RECIP_D;                                                        \
+    static constexpr double RECIP3_D = PFX28##_RECIP3_D;                                                      \
     PCD_HD static uint32_t mod(int i) { constexpr uint32_t m[N] = PFX28##_MOD; return m[i]; }                 \
     PCD_HD static uint32_t mod2(int i) { constexpr uint32_t m[N] = PFX28##_MOD2; return m[i]; }               \
     PCD_HD static uint32_t mod4(int i) { constexpr uint32_t m[N] = PFX28##_MOD4; return m[i]; }               \
@@ -599,33 +599,27 @@ struct Fp {
     return norm_reduce<false>(r);
   }
   // The value of a signed limb-wise sum of small multiples of field elements: s[i] = sum_t c_t a_t[i] with every a_t in [0, 2p) and
-  // sum |c_t| <= 2000; K = 2 sum |negative c_t| (K p is added so that the integer V is non-negative; V < 2^12 p).  One carry chain, a
-  // quotient estimate in double precision from the two top limbs (d = V / 2^(28 (N - 2)) up to a relative 2^-52, times a reciprocal of
-  // p biased down by 2^-30: never above floor(V / p), at most 1 short) and one conditional subtraction bring it to [0, 2p).  The LIN
-  // instruction of the pairing VM and the small-coefficient entries of the mat-vec use it.
-  PCD_HD static Fp from_signed_sum(const int64_t* s, int64_t K) {
-    uint32_t t28[N];
-    int64_t cy = 0;
-#pragma unroll
-    for (int i = 0; i < N - 1; i++) {
-      cy += s[i] + K * (int64_t)P::mod(i);
-      t28[i] = (uint32_t)cy & MASK;
-      cy >>= 28;
-    }
-    cy += s[N - 1] + K * (int64_t)P::mod(N - 1);  // top limb, kept whole (>= 0, below 2^40)
-    const double d = (double)cy * 268435456.0 + (double)t28[N - 2];
-    const int64_t q = (int64_t)(d * P::RECIP_D);
-    int32_t r[N];
+  // sum |c_t| <= 2000, so V = sum s[i] 2^(28 i) has |V| < 2^12 p and every |s[i]| < 2^40.  ONE pass: the quotient is estimated BEFORE
+  // any carry runs, in double precision from the three top columns -- d = s[N-1] 2^56 + s[N-2] 2^28 + s[N-3] is V / 2^(28 (N - 3)) up to
+  // 2^-15 from the columns below and 2^43 from rounding, against p / 2^(28 (N - 3)) > 2^72: x = d * RECIP3_D is V / p to within 2^-28 --
+  // and q = floor(x - 1/2) puts V - q p in (0.49 p, 1.51 p): inside [0, 2p) with no correction step, for negative V as well (no offset
+  // K p).  Then one signed carry chain over s[i] - q p_i.  (Before: a chain with K p added, the estimate, a second chain, and the two
+  // chains of norm_reduce: 134 instructions at 11 limbs against 75 now.)  The LIN instruction of the pairing VM, the small-coefficient
+  // entries of the mat-vec and the Fq2 accumulator use it.
+  PCD_HD static Fp from_signed_sum(const int64_t* s) {
+    const double d = ((double)s[N - 1] * 268435456.0 + (double)s[N - 2]) * 268435456.0 + (double)s[N - 3];
+    const int32_t q = (int32_t)__builtin_floor(d * P::RECIP3_D - 0.5);
+    Fp o;
     int64_t cc = 0;
 #pragma unroll
     for (int i = 0; i < N - 1; i++) {
-      cc += (int64_t)t28[i] - q * (int64_t)P::mod(i);
-      r[i] = (int32_t)((uint32_t)cc & MASK);
+      cc += s[i] - (int64_t)q * (int64_t)(int32_t)P::mod(i);   // (int32 factors: one v_mad_i64_i32)
+      o.v[i] = (uint32_t)cc & MASK;
       cc >>= 28;
     }
-    cc += cy - q * (int64_t)P::mod(N - 1);
-    r[N - 1] = (int32_t)cc;
-    return norm_reduce<false>(r);
+    cc += s[N - 1] - (int64_t)q * (int64_t)(int32_t)P::mod(N - 1);
+    o.v[N - 1] = (uint32_t)cc;   // the top limb of a value in (0, 2p): non-negative and small
+    return o;
   }
   // the inverse (zero maps to zero): divsteps -- 25x (753 bits) / 7x (298 bits) fewer instructions than a^(p-2), which matters wherever
   // ONE lane inverts on the critical path: the affine images of a proof's three points, batch normalisations, the pairing's inverses

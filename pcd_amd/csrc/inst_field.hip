@@ -255,24 +255,22 @@ hipError_t convert(hipStream_t st, const uint32_t* in, uint32_t* out, uint32_t n
 constexpr int SPMV_FLUSH = 48;  // light entries per reduction: 48 x 32 <= 2000
 struct SpmvLight {
   int64_t s[FT::N];
-  int64_t K = 0;
   int cnt = 0;
   PCD_DEV SpmvLight() {
 #pragma unroll
     for (int i = 0; i < FT::N; i++) s[i] = 0;
   }
   PCD_DEV void add(int c, const FT& v, FT& acc) {
-    if (c < 0) K -= 2 * c;
 #pragma unroll
-    for (int i = 0; i < FT::N; i++) s[i] += (int64_t)c * (int64_t)v.v[i];
+    for (int i = 0; i < FT::N; i++) s[i] += (int64_t)c * (int64_t)(int32_t)v.v[i];   // (limbs below 2^29: one v_mad_i64_i32)
     if (++cnt == SPMV_FLUSH) flush(acc);
   }
   PCD_DEV void flush(FT& acc) {
     if (!cnt) return;
-    acc = acc + FT::from_signed_sum(s, K);
+    acc = acc + FT::from_signed_sum(s);
 #pragma unroll
     for (int i = 0; i < FT::N; i++) s[i] = 0;
-    K = 0; cnt = 0;
+    cnt = 0;
   }
 };
 // one lane per row (rows of up to SPMV_LONG_ROW entries; longer ones are left to spmv_long_kernel), the tail of the vector too

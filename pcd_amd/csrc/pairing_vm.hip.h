@@ -34,18 +34,19 @@ struct VmArith {
   static constexpr int STRIDE = (N + 3) & ~3;  // words per register record
   static constexpr uint32_t MASK = F::MASK;
 
-  // operand -> register: space 0 a plain register, 1 / 2 a state slot in its current / other bank (bank bits in the low half of `bank`),
-  // 3 an entry of a table: base + sel * stride + offset with the selector in bits 16.. of `bank`; TB = {base0, stride0, base1, stride1}
+  // operand -> register.  `bank`: low half the bank bit of every state slot, high half the table selector.
   template <class G>
   PCD_HD static uint32_t reg_of_g(uint32_t op, uint64_t bank) {
-    const uint32_t sp = op >> 14, idx = op & 0x3FFFu;
-    if (sp == 0) return idx;
-    if (sp == 3) {
-      const uint32_t sel = (uint32_t)(bank >> 32);
-      return (idx >> 8) ? (uint32_t)G::TAB1_BASE + sel * (uint32_t)G::TAB1_STRIDE + (idx & 0xFFu) : (uint32_t)G::TAB0_BASE + sel * (uint32_t)G::TAB0_STRIDE + (idx & 0xFFu);
-    }
-    return 2 * idx + ((uint32_t)((bank >> idx) & 1u) ^ (sp == 2 ? 1u : 0u));
+    // operand (16 bits) = A | B << 8 | f << 14 (tools/gen_pairing_vm.py enc_operand): register A + bit B of {bank, ~bank} + sel * stride of
+    // table 0 (f & 1) / table 1 (f & 2).  Everything derived from `bank` is wave-uniform (scalar registers, once per program); what a
+    // lane does per operand is four instructions -- the decode by operand space this replaces was twenty, in front of every term.
+    const uint32_t lo = (uint32_t)bank, sel = (uint32_t)(bank >> 32);
+    const uint64_t bankx = (uint64_t)lo | ((uint64_t)~lo << 32);
+    const uint32_t s0 = sel * (uint32_t)G::TAB0_STRIDE, s1 = sel * (uint32_t)G::TAB1_STRIDE;
+    const uint32_t m0 = (uint32_t)((int32_t)(op << 17) >> 31), m1 = (uint32_t)((int32_t)(op << 16) >> 31);   // (masks: a 32-bit multiply is quarter rate)
+    return (op & 0xFFu) + ((uint32_t)(bankx >> ((op >> 8) & 63u)) & 1u) + (m0 & s0) + (m1 & s1);
   }
+  PCD_HD static uint32_t state_op(uint32_t slot) { return 2u * slot | (slot << 8); }   // the operand of state slot `slot` in its current bank
   template <class PTR>
   PCD_HD static F ld(PTR regs, uint32_t r) {
     F v;
@@ -139,30 +140,74 @@ struct VmArith {
     return reduce_columns(col);
   }
 
-  // dst = sum c_t a_t mod p (up to 16 terms, sum of |c_t| <= VM_LIN_WEIGHT), operands and result in [0, 2p).  Negative terms are covered
-  // by adding K p, K = 2 sum |negative c_t| (every operand is below 2p): Fp::from_signed_sum.  Terms 8 .. 15 sit in the continuation slot w2.
+  // dst = sum c_t a_t mod p (up to 16 terms, sum of |c_t| <= VM_LIN_WEIGHT), operands and result in [0, 2p): the signed limb-wise sum, then
+  // Fp::from_signed_sum.  Terms 8 .. 15 sit in the continuation slot w2.
   template <class G, class PTR>
   PCD_HD static F lin(const uint32_t* w, const uint32_t* w2, PTR regs, uint64_t bank) {
     const int T = (int)((w[0] >> 8) & 0xFFu);
     int64_t s[N];
 #pragma unroll
     for (int i = 0; i < N; i++) s[i] = 0;
-    int64_t K = 0;
 #pragma unroll
     for (int t = 0; t < vmgen::VM_LIN_TERMS; t++) {
       if (t < T) {
         const uint32_t* ww = t < 8 ? w : w2;
         const int tt = t & 7;
         const uint32_t op = (ww[1 + tt / 2] >> (16 * (tt & 1))) & 0xFFFFu;
-        const int64_t c = (int64_t)(int16_t)((ww[5 + tt / 2] >> (16 * (tt & 1))) & 0xFFFFu);
+        const int32_t c = (int32_t)(int16_t)((ww[5 + tt / 2] >> (16 * (tt & 1))) & 0xFFFFu);
         const F a = ld(regs, reg_of_g<G>(op, bank));
-        if (c < 0) K -= 2 * c;
+        // (both factors as int32 -- limbs are below 2^29, |c| <= VM_LIN_WEIGHT -- so that a term costs ONE v_mad_i64_i32 per limb; as
+        //  int64 x uint32 the same line was two multiply-adds and two moves per limb: 45 instructions per term instead of 11)
 #pragma unroll
-        for (int i = 0; i < N; i++) s[i] += c * (int64_t)a.v[i];
+        for (int i = 0; i < N; i++) s[i] += (int64_t)c * (int64_t)(int32_t)a.v[i];
       }
     }
-    return F::from_signed_sum(s, K);
+    return F::from_signed_sum(s);
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // The same on the device, WAVE-UNIFORM: every lane runs the step's largest term count (the step table carries it; a lane with fewer
+  // terms has zero coefficients on register 0 in the unused places, which add nothing), so the terms are straight-line code -- all
+  // operand reads of a part in flight together, one LDS latency per part instead of one per term, and no exec-mask bookkeeping between
+  // terms.  (Per-lane `if (t < T)` blocks cost ~375 cycles a term, two thirds of it the exposed ds_read and the divergence scaffolding.)
+  template <class G, int TT>
+  PCD_DEV static void lin_terms(const uint32_t* ww, LdsPtr regs, uint64_t bank, int64_t* s) {
+    F a[TT];
+    int32_t c[TT];
+#pragma unroll
+    for (int t = 0; t < TT; t++) {
+      const uint32_t op = (ww[1 + t / 2] >> (16 * (t & 1))) & 0xFFFFu;
+      c[t] = (int32_t)(int16_t)((ww[5 + t / 2] >> (16 * (t & 1))) & 0xFFFFu);
+      a[t] = ld(regs, reg_of_g<G>(op, bank));
+    }
+#pragma unroll
+    for (int t = 0; t < TT; t++) {
+#pragma unroll
+      for (int i = 0; i < N; i++) s[i] += (int64_t)c[t] * (int64_t)(int32_t)a[t].v[i];
+    }
+  }
+  template <class G>
+  PCD_DEV static void lin_part(const uint32_t* ww, LdsPtr regs, uint64_t bank, uint32_t cnt /* wave-uniform, 1 .. 8 */, int64_t* s) {
+    switch (cnt) {
+      case 1: lin_terms<G, 1>(ww, regs, bank, s); break;
+      case 2: lin_terms<G, 2>(ww, regs, bank, s); break;
+      case 3: lin_terms<G, 3>(ww, regs, bank, s); break;
+      case 4: lin_terms<G, 4>(ww, regs, bank, s); break;
+      case 5: lin_terms<G, 5>(ww, regs, bank, s); break;
+      case 6: lin_terms<G, 6>(ww, regs, bank, s); break;
+      case 7: lin_terms<G, 7>(ww, regs, bank, s); break;
+      default: lin_terms<G, 8>(ww, regs, bank, s); break;
+    }
+  }
+  template <class G>
+  PCD_DEV static F lin_uniform(const uint32_t* w, const uint32_t* w2, LdsPtr regs, uint64_t bank, uint32_t tmax) {
+    int64_t s[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) s[i] = 0;
+    lin_part<G>(w, regs, bank, tmax < 8u ? tmax : 8u, s);
+    if (tmax > 8u) lin_part<G>(w2, regs, bank, tmax - 8u, s);
+    return F::from_signed_sum(s);
+  }
+#endif
 };
 
 #if defined(__HIPCC__)
@@ -195,8 +240,8 @@ struct VmWave {
       A::st(regs, G::CONST_BASE + c, v);
     }
   }
-  PCD_DEV F get_state(int slot) const { return A::ld(regs, A::template reg_of_g<G>((1u << 14) | (uint32_t)slot, bank)); }
-  PCD_DEV void set_state(int slot, const F& v) { A::st(regs, A::template reg_of_g<G>((1u << 14) | (uint32_t)slot, bank), v); }
+  PCD_DEV F get_state(int slot) const { return A::ld(regs, A::template reg_of_g<G>(A::state_op((uint32_t)slot), bank)); }
+  PCD_DEV void set_state(int slot, const F& v) { A::st(regs, A::template reg_of_g<G>(A::state_op((uint32_t)slot), bank), v); }
   PCD_DEV F get_reg(int r) const { return A::ld(regs, (uint32_t)r); }
   PCD_DEV void set_reg(int r, const F& v) { A::st(regs, (uint32_t)r, v); }
 
@@ -206,7 +251,10 @@ struct VmWave {
     const uint32_t first = progs[3 * pid], cnt = progs[3 * pid + 1];
     const uint32_t lane = threadIdx.x;
     for (uint32_t s = first; s < first + cnt; s++) {
-      const uint32_t kind = steps[3 * s], off = steps[3 * s + 1], n = steps[3 * s + 2];
+      // (the step's words are the same for every lane: taken through readfirstlane so that the dispatch below is scalar branches)
+      const uint32_t kw = __builtin_amdgcn_readfirstlane(steps[3 * s]), off = __builtin_amdgcn_readfirstlane(steps[3 * s + 1]),
+                     n = __builtin_amdgcn_readfirstlane(steps[3 * s + 2]);
+      const uint32_t kind = kw & 0xFFu, tmax = kw >> 8;   // tmax: the largest term count among the step's LIN instructions
       if (lane < n) {
         uint32_t w[12], w2[12];
 #pragma unroll
@@ -219,7 +267,12 @@ struct VmWave {
             const bool wide = ((w[0] >> 8) & 0xFFu) > 8;
 #pragma unroll
             for (int i = 0; i < 12; i++) w2[i] = wide ? code[(off + lane + 1) * 12 + i] : 0u;
-            o = A::template lin<G>(w, w2, regs, bank);
+#if defined(__HIP_DEVICE_COMPILE__)
+            o = A::template lin_uniform<G>(w, w2, regs, bank, tmax);
+#else
+            o = A::template lin<G>(w, w2, regs, bank);   // (host pass of the compiler: never run)
+            (void)tmax;
+#endif
           }
           A::st(regs, A::template reg_of_g<G>(w[0] >> 16, bank), o);   // (every lane has read its operands before any lane stores: lockstep)
         }

@@ -40,14 +40,14 @@ struct HostVm {
   HostVm(const VmTables& t) : regs((size_t)VG::NREGS * A::STRIDE, 0u), tb(t) {
     for (int c = 0; c < VG::NCONST; c++) { Fq v; for (int i = 0; i < Fq::N; i++) v.v[i] = tb.consts[c * Fq::N + i]; A::st(regs.data(), VG::CONST_BASE + c, v); }
   }
-  Fq get_state(int s) { return A::ld(regs.data(), A::template reg_of_g<VG>((1u << 14) | (uint32_t)s, bank)); }
-  void set_state(int s, const Fq& v) { A::st(regs.data(), A::template reg_of_g<VG>((1u << 14) | (uint32_t)s, bank), v); }
+  Fq get_state(int s) { return A::ld(regs.data(), A::template reg_of_g<VG>(A::state_op((uint32_t)s), bank)); }
+  void set_state(int s, const Fq& v) { A::st(regs.data(), A::template reg_of_g<VG>(A::state_op((uint32_t)s), bank), v); }
   void set_reg(int r, const Fq& v) { A::st(regs.data(), (uint32_t)r, v); }
   void run(int pid) {
     const uint32_t first = tb.progs[3 * pid], cnt = tb.progs[3 * pid + 1];
     static const uint32_t zero12[12] = {0};
     for (uint32_t s = first; s < first + cnt; s++) {
-      const uint32_t kind = tb.steps[3 * s], off = tb.steps[3 * s + 1], n = tb.steps[3 * s + 2];
+      const uint32_t kind = tb.steps[3 * s] & 0xFFu /* bits 8 up: the step's largest LIN term count, for the device */, off = tb.steps[3 * s + 1], n = tb.steps[3 * s + 2];
       std::vector<Fq> res(n);
       for (uint32_t l = 0; l < n; l++) {
         const uint32_t* w = tb.code + (size_t)(off + l) * 12;
@@ -109,18 +109,25 @@ extern "C" int hc_vm_pairing(int curve, const uint32_t* g1, const uint32_t* g1z,
   }
   return 0;
 }
-// Fp::from_signed_sum on the host: out = sum c_t a_t (a: T elements in the C-ABI image; c: T coefficients, sum |c| <= 2000)
+// Fp::from_signed_sum on the host: out = sum c_t a_t (a: T elements in the C-ABI image, below p; c: T coefficients, sum |c| <= 4000 -- the weight 2000 on operands below 2p)
 template <class FQ>
 static void signed_sum_host(const uint32_t* a_abi, const int32_t* c, int T, uint32_t* out) {
   typedef Fp<FQ, false> F;
   int64_t s[F::N] = {0};
-  int64_t K = 0;
   for (int t = 0; t < T; t++) {
     const F a = F::from_abi(a_abi + (size_t)t * F::ABI_WORDS);
-    if (c[t] < 0) K -= 2 * (int64_t)c[t];
     for (int i = 0; i < F::N; i++) s[i] += (int64_t)c[t] * (int64_t)a.v[i];
   }
-  F::from_signed_sum(s, K).to_abi(out);
+  const F o = F::from_signed_sum(s);
+  // the contract: limbs normalised and the value below 2p (everything downstream assumes it)
+  bool ok = true, below = false;
+  for (int i = 0; i < F::N - 1; i++) ok = ok && o.v[i] <= F::MASK;
+  for (int i = F::N - 1; i >= 0 && !below; i--) {
+    if (o.v[i] < FQ::mod2(i)) below = true;
+    else if (o.v[i] > FQ::mod2(i)) break;
+  }
+  if (!ok || !below) { for (int i = 0; i < F::ABI_WORDS; i++) out[i] = 0xFFFFFFFFu; return; }
+  o.to_abi(out);
 }
 extern "C" int hc_signed_sum(int field, const uint32_t* a_abi, const int32_t* c, int T, uint32_t* out) {
   switch (field) {

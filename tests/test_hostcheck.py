@@ -174,7 +174,7 @@ def test_vm_pairing(hc, golden, co, cid):
 @pytest.mark.parametrize("fid", [0, 1, 2, 3])
 def test_signed_sum_reduction(hc, fid):
     """Fp::from_signed_sum (the LIN instruction of the pairing VM, the small-coefficient entries of the mat-vec): sums of up to 16
-    terms with coefficient weight up to 2000 -- all positive, all negative, alternating, on operands 0, 1, p - 1 and random ones --
+    terms with coefficient weight up to 4000 (= 2000 on operands below 2p) -- all positive, all negative, alternating, on operands 0, 1, p - 1 and random ones --
     against Python integers"""
     from oracle import pyoracle as O
     f = O.FIELDS[fid]
@@ -184,7 +184,7 @@ def test_signed_sum_reduction(hc, fid):
         for mode in ("pos", "neg", "alt", "rand"):
             for vals in ("max", "rand", "small"):
                 a = [f.p - 1 if vals == "max" else rnd.randrange(f.p) if vals == "rand" else rnd.randrange(3) for _ in range(T)]
-                w = 2000 // T
+                w = 4000 // T   # (canonical operands here: twice the weight stands in for operands up to 2p)
                 c = [w if mode == "pos" else -w if mode == "neg" else (w if i % 2 else -w) if mode == "alt" else rnd.randrange(-w, w + 1) for i in range(T)]
                 cases.append((a, c))
     for a, c in cases:

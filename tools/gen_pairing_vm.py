@@ -743,10 +743,25 @@ def limbs28(x, n):
     return [(x >> (B28 * i)) & ((1 << B28) - 1) for i in range(n)]
 
 
+ZERO_BIT = 31   # a bit of the bank word that is never set (fewer than 32 state slots): what plain registers "select" with
+
+
 def enc_operand(env, op):
+    """16 bits: A (8, base register) | B (6, a bit of {bank, ~bank}: added to A) | f (2: add sel * stride of table 0 / table 1).
+    register = A + bit B + sel * stride -- four instructions on the device where a decode by operand space was twenty"""
     space, idx = reg_index(env, op)
-    assert idx < (1 << 14)
-    return (space << 14) | idx
+    named = 2 * len(env.slots) + len(env.const_values)
+    if space == SP_REG:
+        A, B, f = idx, ZERO_BIT, 0
+    elif space == SP_IN:
+        A, B, f = 2 * idx, idx, 0
+    elif space == SP_OUT:
+        A, B, f = 2 * idx, 32 + idx, 0
+    else:
+        table, off = idx >> 8, idx & 0xFF
+        A, B, f = named + env.regs[("ft1_0", "pb1_0")[table]] + off, ZERO_BIT, 1 << table
+    assert A < 256 and len(env.slots) <= ZERO_BIT
+    return A | (B << 8) | (f << 14)
 
 
 def emit(envs):
@@ -755,7 +770,8 @@ def emit(envs):
          f"constexpr int VM_TMAX = {TMAX}, VM_LIN_TERMS = {LIN_TERMS}, VM_LIN_WEIGHT = {LIN_WEIGHT};",
          "// instruction = 12 words: w0 = kind | terms << 8 | dst << 16;  MUL / SQR: w[1 + t] = a_t | b_t << 16;  LIN: w[1 + t / 2] holds operand t in its",
          "// low / high half, w[5 + t / 2] the signed 16-bit coefficient; a LIN of more than 8 terms continues in the next slot (w0 = 0xFF, whose lane",
-         "// idles).  Operand = space << 14 | index (space 0: register, 1: state slot in its current bank, 2: state slot in the other bank).",
+         "// idles).  Operand (16 bits) = A | B << 8 | f << 14: register A + bit B of {bank, ~bank} + sel * (f & 1 ? TAB0_STRIDE : f & 2 ? TAB1_STRIDE : 0) --",
+         "// plain register r: A = r, B = 31 (never set); state slot j: A = 2 j, B = j (current bank) or 32 + j (the other bank); table t entry: A = TABt_BASE + offset.",
          "// kind: 0 LIN, 1 MUL, 2 SQR (a step of squarings only).  Scripts: the program ids a kernel runs, in order.", ""]
     for env in envs:
         N = env.N
@@ -802,7 +818,9 @@ def emit(envs):
                             words += w2
                     nslots = (len(words) - first_word) // 12
                     assert nslots <= LANES
-                    steps.append((kind, first_word // 12, nslots))
+                    # (LIN steps carry their largest term count in bits 8 up: the kernel runs the terms wave-uniformly)
+                    tmax = max(len(terms) for _, terms, _ in instrs) if kind == K_LIN else 0
+                    steps.append((kind | (tmax << 8), first_word // 12, nslots))
                 mask = 0
                 for sl in c["written"]:
                     mask |= 1 << sl
@@ -824,9 +842,9 @@ def emit(envs):
             L.append("};")
             L.append(f"static const uint32_t {T}_progs[{len(progs)}][3] = {{  // first step, steps, mask of the state slots written")
             L.append("  " + ", ".join(f"{{{first}, {cnt}, 0x{mask:08x}u}}" for _, first, cnt, mask in progs) + "};")
-            L.append(f"static const uint32_t {T}_steps[{len(steps)}][3] = {{  // kind, first instruction slot, slots")
+            L.append(f"static const uint32_t {T}_steps[{len(steps)}][3] = {{  // kind | largest LIN term count << 8, first instruction slot, slots")
             for q in range(0, len(steps), 8):
-                L.append("  " + ", ".join(f"{{{k_}, {o}, {n_}}}" for k_, o, n_ in steps[q:q + 8]) + ",")
+                L.append("  " + ", ".join(f"{{0x{k_:x}, {o}, {n_}}}" for k_, o, n_ in steps[q:q + 8]) + ",")
             L.append("};")
             L.append(f"static const uint32_t {T}_code[{len(words)}] = {{")
             for q in range(0, len(words), 12):
