@@ -246,40 +246,63 @@ struct VmWave {
   PCD_DEV void set_reg(int r, const F& v) { A::st(regs, (uint32_t)r, v); }
 
   // one program: steps in order, a barrier (one wave: a fence) after each; lanes beyond a step's slot count, and the lanes of
-  // continuation slots, idle
+  // continuation slots, idle.  The fetch is software-pipelined: while step s computes, the instruction words of step s + 1 and the
+  // header of step s + 2 are already on their way from LDS (the fetch chain header -> words -> operands was three exposed LDS round
+  // trips in front of every step).  Everything the loop needs of *this is held in locals: the object lives in private memory, and
+  // members read through `this` are reloaded from there after every barrier -- two flat loads per step on the critical path.
   __device__ __noinline__ void run(int pid) {
-    const uint32_t first = progs[3 * pid], cnt = progs[3 * pid + 1];
+    const Lds regs_ = regs, code_ = code, steps_ = steps;
+    const uint64_t bank_ = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(bank >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)bank);
+    const uint32_t first = __builtin_amdgcn_readfirstlane(progs[3 * pid]), cnt = __builtin_amdgcn_readfirstlane(progs[3 * pid + 1]);
+    const uint32_t flip = progs[3 * pid + 2];
     const uint32_t lane = threadIdx.x;
-    for (uint32_t s = first; s < first + cnt; s++) {
+    const uint32_t last = first + cnt - 1;   // (headers past the end are read from the last step: harmless, never used)
+    auto header = [&](uint32_t s, uint32_t& kw, uint32_t& off, uint32_t& n) {
+      s = s < last ? s : last;
+      kw = steps_[3 * s]; off = steps_[3 * s + 1]; n = steps_[3 * s + 2];
+    };
+    auto fetch = [&](uint32_t off, uint32_t n, uint32_t* w) {   // (lanes beyond the step's slots re-read its last slot: in bounds, unused)
+      const uint32_t slot = off + (lane < n ? lane : n - 1);
+#pragma unroll
+      for (int i = 0; i < 12; i++) w[i] = code_[slot * 12 + i];
+    };
+    uint32_t kw0, off0, n0, kw1, off1, n1;
+    header(first, kw0, off0, n0);
+    header(first + 1, kw1, off1, n1);
+    uint32_t w[12];
+    fetch(__builtin_amdgcn_readfirstlane(off0), __builtin_amdgcn_readfirstlane(n0), w);
+    for (uint32_t s = first; s <= last; s++) {
       // (the step's words are the same for every lane: taken through readfirstlane so that the dispatch below is scalar branches)
-      const uint32_t kw = __builtin_amdgcn_readfirstlane(steps[3 * s]), off = __builtin_amdgcn_readfirstlane(steps[3 * s + 1]),
-                     n = __builtin_amdgcn_readfirstlane(steps[3 * s + 2]);
+      const uint32_t kw = __builtin_amdgcn_readfirstlane(kw0), off = __builtin_amdgcn_readfirstlane(off0), n = __builtin_amdgcn_readfirstlane(n0);
+      const uint32_t off_next = __builtin_amdgcn_readfirstlane(off1), n_next = __builtin_amdgcn_readfirstlane(n1);
       const uint32_t kind = kw & 0xFFu, tmax = kw >> 8;   // tmax: the largest term count among the step's LIN instructions
-      if (lane < n) {
-        uint32_t w[12], w2[12];
+      uint32_t wn[12];
+      fetch(off_next, n_next, wn);               // step s + 1's words
+      kw0 = kw1; off0 = off1; n0 = n1;
+      header(s + 2, kw1, off1, n1);              // step s + 2's header
+      if (lane < n && (w[0] & 0xFFu) != 0xFFu) {
+        F o;
+        if (kind == 1) o = A::template mul<G>(w, regs_, bank_);
+        else if (kind == 2) o = A::template sqr<G>(w, regs_, bank_);
+        else {
+          uint32_t w2[12];
+          const bool wide = tmax > 8u && ((w[0] >> 8) & 0xFFu) > 8;   // (tmax is scalar: steps without a wide instruction skip the reads)
 #pragma unroll
-        for (int i = 0; i < 12; i++) w[i] = code[(off + lane) * 12 + i];
-        if ((w[0] & 0xFFu) != 0xFFu) {
-          F o;
-          if (kind == 1) o = A::template mul<G>(w, regs, bank);
-          else if (kind == 2) o = A::template sqr<G>(w, regs, bank);
-          else {
-            const bool wide = ((w[0] >> 8) & 0xFFu) > 8;
-#pragma unroll
-            for (int i = 0; i < 12; i++) w2[i] = wide ? code[(off + lane + 1) * 12 + i] : 0u;
+          for (int i = 0; i < 12; i++) w2[i] = wide ? code_[(off + lane + 1) * 12 + i] : 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
-            o = A::template lin_uniform<G>(w, w2, regs, bank, tmax);
+          o = A::template lin_uniform<G>(w, w2, regs_, bank_, tmax);
 #else
-            o = A::template lin<G>(w, w2, regs, bank);   // (host pass of the compiler: never run)
-            (void)tmax;
+          o = A::template lin<G>(w, w2, regs_, bank_);   // (host pass of the compiler: never run)
+          (void)tmax;
 #endif
-          }
-          A::st(regs, A::template reg_of_g<G>(w[0] >> 16, bank), o);   // (every lane has read its operands before any lane stores: lockstep)
         }
+        A::st(regs_, A::template reg_of_g<G>(w[0] >> 16, bank_), o);   // (every lane has read its operands before any lane stores: lockstep)
       }
       __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 12; i++) w[i] = wn[i];
     }
-    bank ^= (uint64_t)progs[3 * pid + 2];
+    bank ^= (uint64_t)flip;
   }
   // the kernel's script: program ids in order; entries from 0xF0 up select a table entry for the programs that follow, 0xEF inverts
   PCD_DEV void run_script() {

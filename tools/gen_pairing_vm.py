@@ -312,7 +312,12 @@ def build(cid):
     # state: r = (x, y, z, t) <- (qx, qy, 1, 1), f <- 1
     env.put(P, "rx", qx, EV); env.put(P, "ry", qy, EV)
     env.put(P, "rz", one(P), EV); env.put(P, "rt", one(P), EV)
+    # f travels as a PAIR: the state slots f (call it s) and ln (the line of the step before, not multiplied in yet); the Miller value is
+    # s * ln.  A doubling then is  s <- (s ln)^2, ln <- its own line: the product s ln and the squaring sit on the first two product levels,
+    # beside the point arithmetic whose line is only complete after the third -- the program is three product levels deep where
+    # f <- f^2 * line behind the line made it four (7 steps instead of 9, on two thirds of the loop).  `flush` multiplies the last line in.
     env.put(P, "f", one(P), ALL)
+    env.put(P, "ln", one(P), ALL)
 
     def line_regs(P):
         pxt = X(P, [None, None, P.reg("pxz0")] + [None] * (k - 3))   # px pz * twist
@@ -321,7 +326,7 @@ def build(cid):
 
     P = env.prog("dbl")
     x, y, z, t = (env.st(P, n, EV) for n in ("rx", "ry", "rz", "rt"))
-    f = env.st(P, "f", ALL)
+    f, ln = env.st(P, "f", ALL), env.st(P, "ln", ALL)
     pxt, pyt = line_regs(P)
     a, b, c = t.sqr(), x.sqr(), y.sqr()
     d = c.sqr()
@@ -338,14 +343,14 @@ def build(cid):
     pz3 = P.reg("pz30")
     c_l4 = c_l - c.times(4)
     g_rr = (X(P, [None if a_ is None else P.mul([(a_, pz3)]) for a_ in c_l4.c]) - c_j * pxt) + (c_h * pyt).shift(1)
-    fn = f.sqr() * g_rr
     for n, v in (("rx", ox), ("ry", oy), ("rz", oz), ("rt", ot)):
         env.put(P, n, v, EV)
-    env.put(P, "f", fn, ALL)
+    env.put(P, "f", (f * ln).sqr(), ALL)
+    env.put(P, "ln", g_rr, ALL)
 
     P = env.prog("add")
     x, y, z, t = (env.st(P, n, EV) for n in ("rx", "ry", "rz", "rt"))
-    f = env.st(P, "f", ALL)
+    f, ln = env.st(P, "f", ALL), env.st(P, "ln", ALL)
     pxt, pyt = line_regs(P)
     qx, qy, qy2 = env.rg(P, "qx", EV), env.rg(P, "qy", EV), env.rg(P, "qy2", EV)
     qyo, l1c = env.rg(P, "qyo", EV), env.rg(P, "l1c", EV)
@@ -362,10 +367,13 @@ def build(cid):
     oz = (z + h).sqr() - t - i
     ot = oz.sqr()
     line = (oz * pyt) + (qyo * oz + l1c * l1).neg().shift(1)
-    fn = f * line
     for n, vv in (("rx", ox), ("ry", oy), ("rz", oz), ("rt", ot)):
         env.put(P, n, vv, EV)
-    env.put(P, "f", fn, ALL)
+    env.put(P, "f", f * ln, ALL)
+    env.put(P, "ln", line, ALL)
+
+    P = env.prog("flush")       # the Miller value itself: the pending line multiplied in
+    env.put(P, "f", env.st(P, "f", ALL) * env.st(P, "ln", ALL), ALL)
 
     # loop count < 0: upstream multiplies by the line through R and -R and inverts.  That line is (0, 4 l1c r.y) exactly (the mixed
     # addition of R and its own affine negation has h = 0, so o.z = 0 and l1 = -4 r.y: no inversion of r.z is needed to know it),
@@ -459,13 +467,14 @@ def build(cid):
         mil.append("dbl")
         if bch == "1":
             mil.append("add")
+    mil.append("flush")
     if env.ate_neg:
         mil.append("negfix")
     env.scripts["miller"] = mil
     env.scripts["final_exp"] = (["fe_norm", ("inv", 0), ("sel", 0), "fq_init", "fe_easy", "pow_tab"]
                                 + window_schedule(env.w0, WIN_POW, "pow_init", "pow_sqr", "pow_mul") + ["fe_last"])
     # which kernel needs which programs (each kernel stages only its own in LDS)
-    env.sets = {"miller": ["setup", "dbl", "add", "negfix"],
+    env.sets = {"miller": ["setup", "dbl", "add", "flush", "negfix"],
                 "final_exp": ["fe_mul"] + [n for n in env.progs if n.startswith(("fe_n", "fq_", "fe_e", "pow_", "fe_l"))]}
     # the table registers are consecutive: entry (j - 1) / 2 of table 0 is ft<j>_0, of table 1 is pb<j>_0 .. pb<j>_(k-1)
     return env
