@@ -63,8 +63,8 @@ def test_programs_compute_the_pairing(gen, envs, cid):
 
 def test_bounds_the_interpreter_relies_on(gen, envs):
     for env in envs:
-        nregs = 2 * len(env.slots) + len(env.const_values) + len(env.regs) + env.ntemp
-        assert len(env.slots) <= 31 and nregs <= 256   # (operand = 8-bit base register | 6-bit bank bit | 2 table flags; bank bit 31 stays clear)
+        nregs = 2 * env.nslots + len(env.const_values) + len(env.regs) + env.ntemp
+        assert env.nslots <= 31 and nregs <= 256   # (operand = 8-bit base register | 6-bit bank bit | 2 table flags; bank bit 31 stays clear)
         stride = (env.N + 3) // 4 * 4
         for setname, names in env.sets.items():            # what one kernel stages in LDS: registers + its own programs + script
             slots = steps = 0

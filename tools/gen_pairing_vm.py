@@ -21,6 +21,7 @@ textbook pairing of the test oracle -- and writes pcd_amd/csrc/pairing_vm_gen.h.
 """
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -228,13 +229,21 @@ class Env:
         w = pow(self.nr, (self.p - 1) // self.k, self.p)
         self.frob_w = [pow(w, i, self.p) for i in range(self.k)]
         self.slots, self.regs, self.consts = {}, {}, {}
+        self.nslots = 0
         self.scripts = {}
         self.const_values = []   # plain registers 0 .. : constants first, then named registers
         self.progs = {}
 
     def slot(self, name):
+        # (the final exponentiation's slots reuse the numbers of the Miller loop's: two kernels, two register files -- and the bank word
+        #  holds 31 slots)
         if name not in self.slots:
-            self.slots[name] = len(self.slots)
+            m = re.fullmatch(r"(acc|pw)(\d+)", name)
+            if m:
+                self.slots[name] = self.slot(("f" if m.group(1) == "acc" else "ln") + m.group(2))
+            else:
+                self.slots[name] = self.nslots
+                self.nslots += 1
         return self.slots[name]
 
     def const(self, value):
@@ -286,7 +295,7 @@ def build(cid):
 
     # ---------------- Miller loop (one wave per pair) ----------------
     # plain registers: px0, py0 (G1 point), qx*, qy* (G2 point, even positions), derived once by `setup`:
-    #   qyo* = qy / twist, l1c* = px - qx / twist, qy2* = qy^2      (twist = u = v^2;  1 / u = u^(d-1) / nr)
+    #   qyo* = qy / twist, l1c* = px - qx / twist      (twist = u = v^2;  1 / u = u^(d-1) / nr)
     # The G1 point arrives in JACOBIAN form (px, py, pz): x = px / pz^2, y = py / pz^3 (pz = 1 for an affine point).  Every line is
     # evaluated times pz^3 -- an element of Fq*, which the final exponentiation kills -- so no inversion is ever needed for P:
     #   doubling line  (c_l - 4c) pz^3 - c_j (px pz) u,   c_h py u          addition line  oz py u,  -(qyo pz^3 oz + (px pz - qxo pz^3) l1)
@@ -306,12 +315,11 @@ def build(cid):
     l1c = X(P, [pxz] + [None] * (k - 1)) - scale(qxo, pz3)
     env.put_reg(P, "qyo", scale(qyo, pz3), EV)
     env.put_reg(P, "l1c", l1c, EV)
-    env.put_reg(P, "qy2", qy.sqr(), EV)
     P.out_reg("pxz0", pxz)
     P.out_reg("pz30", pz3)
-    # state: r = (x, y, z, t) <- (qx, qy, 1, 1), f <- 1
+    # state: r = (x, y, z, t = z^2, c = z^3) <- (qx, qy, 1, 1, 1), f <- 1
     env.put(P, "rx", qx, EV); env.put(P, "ry", qy, EV)
-    env.put(P, "rz", one(P), EV); env.put(P, "rt", one(P), EV)
+    env.put(P, "rz", one(P), EV); env.put(P, "rt", one(P), EV); env.put(P, "rc", one(P), EV)
     # f travels as a PAIR: the state slots f (call it s) and ln (the line of the step before, not multiplied in yet); the Miller value is
     # s * ln.  A doubling then is  s <- (s ln)^2, ln <- its own line: the product s ln and the squaring sit on the first two product levels,
     # beside the point arithmetic whose line is only complete after the third -- the program is three product levels deep where
@@ -328,46 +336,53 @@ def build(cid):
     x, y, z, t = (env.st(P, n, EV) for n in ("rx", "ry", "rz", "rt"))
     f, ln = env.st(P, "f", ALL), env.st(P, "ln", ALL)
     pxt, pyt = line_regs(P)
+    # (upstream's doubling -- ark-ec mnt4 / mnt6 `doubling_step_for_flipped_miller_loop` -- takes its mixed terms from squares, e.g.
+    #  2 y z = (y + z)^2 - y^2 - z^2: one product saved in a lane.  Here products on sibling lanes are free and every term of a LIN
+    #  costs time, so the mixed terms are products: the values are the same, the sum in front of the first level disappears (6 steps
+    #  instead of 7) and the widest LIN has 5 terms instead of 8.)
     a, b, c = t.sqr(), x.sqr(), y.sqr()
     d = c.sqr()
-    e = (x + c).sqr() - b - d
+    e = (x * c).dbl()
     fq = b.times(3) + mul_by_a(a)
     g = fq.sqr()
     ox = g - e.times(4)
     oy = fq * (e.dbl() - ox) - d.times(8)
-    oz = (y + z).sqr() - c - z.sqr()
+    oz = (y * z).dbl()
     ot = oz.sqr()
-    c_h = (oz + t).sqr() - ot - a
-    c_j = (fq + t).sqr() - g - a
-    c_l = (fq + x).sqr() - g - b
+    c_h = (oz * t).dbl()
+    c_j = (fq * t).dbl()
+    c_l = (fq * x).dbl()
     pz3 = P.reg("pz30")
     c_l4 = c_l - c.times(4)
     g_rr = (X(P, [None if a_ is None else P.mul([(a_, pz3)]) for a_ in c_l4.c]) - c_j * pxt) + (c_h * pyt).shift(1)
-    for n, v in (("rx", ox), ("ry", oy), ("rz", oz), ("rt", ot)):
+    for n, v in (("rx", ox), ("ry", oy), ("rz", oz), ("rt", ot), ("rc", oz * ot)):
         env.put(P, n, v, EV)
     env.put(P, "f", (f * ln).sqr(), ALL)
     env.put(P, "ln", g_rr, ALL)
 
+    # mixed addition (madd-2007-bl on the extended coordinates), THREE product levels deep like the doubling.  Upstream's order
+    # (ark-ec mnt4 / mnt6 `mixed_addition_step_for_flipped_miller_loop`) is four: d = ((z + qy)^2 - qy^2 - t) t and
+    # y3 = l1 (v - x3) - 2 y j both wait for a product of the level before.  Here d = 2 qy z^3 comes straight from the cached cube
+    # (state rc; (z + qy)^2 - qy^2 - z^2 = 2 z qy), so l1 = d - 2y is known after the first level, and y3 is expanded in products of
+    # second-level values:  y3 = l1 (3v + j - l1^2) - 2 y j = (12 l1 x + 4 l1 h - 8 y h) i - l1^2 l1   (i = h^2, v = 4 x i, j = 4 h i).
+    # The same values as upstream's, coefficient by coefficient (tests/test_pairing_vm.py: the pairing against the textbook one).
     P = env.prog("add")
-    x, y, z, t = (env.st(P, n, EV) for n in ("rx", "ry", "rz", "rt"))
+    x, y, z, t, zc = (env.st(P, n, EV) for n in ("rx", "ry", "rz", "rt", "rc"))
     f, ln = env.st(P, "f", ALL), env.st(P, "ln", ALL)
     pxt, pyt = line_regs(P)
-    qx, qy, qy2 = env.rg(P, "qx", EV), env.rg(P, "qy", EV), env.rg(P, "qy2", EV)
+    qx, qy = env.rg(P, "qx", EV), env.rg(P, "qy", EV)
     qyo, l1c = env.rg(P, "qyo", EV), env.rg(P, "l1c", EV)
-    bb = t * qx
-    dd = ((z + qy).sqr() - qy2 - t) * t
-    h = bb - x
+    h = t * qx - x
+    l1 = (zc * qy).dbl() - y.dbl()
     i = h.sqr()
-    e = i.times(4)
-    j = h * e
-    v = x * e
-    l1 = dd - y.dbl()
-    ox = l1.sqr() - j - v.dbl()
-    oy = l1 * (v - ox) - j * y.dbl()
-    oz = (z + h).sqr() - t - i
+    l1sq = l1.sqr()
+    ox = l1sq - (h.times(4) + x.times(8)) * i      # l1^2 - j - 2v
+    oy = ((l1 * x).times(12) + (l1 * h).times(4) - (y * h).times(8)) * i - l1sq * l1   # (sums before the product with i: fewer products on the level)
+    oz = (z * h).dbl()
     ot = oz.sqr()
+    oc = ((zc * h) * i).times(8)                   # oz = 2 z h, so oz^3 = 8 z^3 h^3
     line = (oz * pyt) + (qyo * oz + l1c * l1).neg().shift(1)
-    for n, vv in (("rx", ox), ("ry", oy), ("rz", oz), ("rt", ot)):
+    for n, vv in (("rx", ox), ("ry", oy), ("rz", oz), ("rt", ot), ("rc", oc)):
         env.put(P, n, vv, EV)
     env.put(P, "f", f * ln, ALL)
     env.put(P, "ln", line, ALL)
@@ -539,19 +554,46 @@ def compile_prog(env, P, nconst_regs):
                 continue
             extra.append((dest, node))
         wanted[node] = [dests[first]] if first is not None else []
-    slot_of = {}
     order = [n for n in range(len(nodes)) if n in live]
+    preds_of = {n: [x for t in nodes[n][1] for x in (t if nodes[n][0] == "mul" else (t[1],))] for n in order if nodes[n][0] != "leaf"}
+    par_of = lambda n: 1 if nodes[n][0] == "mul" else 0
+
+    def fit(lo, par):
+        return lo if lo % 2 == par else lo + 1
+    # as soon as possible (unbounded lanes): the length of the critical path
+    asap = {}
     for n in order:
-        kind, pay = nodes[n]
-        if kind == "leaf":
-            slot_of[n] = -1
+        asap[n] = -1 if nodes[n][0] == "leaf" else fit(max(asap[x] for x in preds_of[n]) + 1, par_of(n))
+    depth = max([v for v in asap.values()] + [0])
+    # as late as possible within that length: the slack of a node is alap - asap
+    alap = {}
+    for n in reversed(order):
+        if nodes[n][0] == "leaf":
             continue
-        preds = [x for t in pay for x in (t if kind == "mul" else (t[1],))]
-        lo = max(slot_of[x] for x in preds) + 1
-        par = 1 if kind == "mul" else 0
-        if lo % 2 != par:
-            lo += 1
-        slot_of[n] = lo
+        hi = alap.get(n, depth)
+        if hi % 2 != par_of(n):
+            hi -= 1
+        alap[n] = hi
+        for x in preds_of[n]:
+            if nodes[x][0] != "leaf":
+                alap[x] = min(alap.get(x, depth), hi - 1)
+    # list scheduling, a step = at most LANES instruction slots: when a level holds more (the first level of an MNT6 doubling: 66
+    # products), the nodes with slack wait for a later step of their kind instead of the level running as two steps
+    slot_of = {n: -1 for n in order if nodes[n][0] == "leaf"}
+    todo = [n for n in order if nodes[n][0] != "leaf"]
+    sl = 0
+    while todo:
+        par = sl % 2
+        ready = sorted((n for n in todo if par_of(n) == par and all(slot_of.get(x, 1 << 30) < sl for x in preds_of[n])), key=lambda n: (alap[n], n))
+        used = 0
+        for n in ready:
+            need = 2 if (par == 0 and len(nodes[n][1]) > 8) else 1
+            if used + need > LANES:
+                continue
+            used += need
+            slot_of[n] = sl
+        todo = [n for n in todo if n not in slot_of]
+        sl += 1
     copies = []   # (slot time, dest, src node)
     for dest, node in extra:
         lo = slot_of[node] + 1
@@ -648,7 +690,7 @@ def reg_index(env, op):
     if space == SP_TAB:
         return space, (idx[0] << 8) | idx[1]
     tag, i = idx
-    base = 2 * len(env.slots)
+    base = 2 * env.nslots
     if tag == "c":
         return SP_REG, base + i
     if tag == "r":
@@ -662,10 +704,10 @@ class Machine:
 
     def __init__(self, env):
         self.env = env
-        self.nregs = 2 * len(env.slots) + len(env.const_values) + len(env.regs) + env.ntemp
+        self.nregs = 2 * env.nslots + len(env.const_values) + len(env.regs) + env.ntemp
         self.r = [0] * self.nregs
         self.bank = 0
-        base = 2 * len(env.slots)
+        base = 2 * env.nslots
         for i, v in enumerate(env.const_values):
             self.r[base + i] = v
         self.steps_run = 0
@@ -759,7 +801,7 @@ def enc_operand(env, op):
     """16 bits: A (8, base register) | B (6, a bit of {bank, ~bank}: added to A) | f (2: add sel * stride of table 0 / table 1).
     register = A + bit B + sel * stride -- four instructions on the device where a decode by operand space was twenty"""
     space, idx = reg_index(env, op)
-    named = 2 * len(env.slots) + len(env.const_values)
+    named = 2 * env.nslots + len(env.const_values)
     if space == SP_REG:
         A, B, f = idx, ZERO_BIT, 0
     elif space == SP_IN:
@@ -769,7 +811,7 @@ def enc_operand(env, op):
     else:
         table, off = idx >> 8, idx & 0xFF
         A, B, f = named + env.regs[("ft1_0", "pb1_0")[table]] + off, ZERO_BIT, 1 << table
-    assert A < 256 and len(env.slots) <= ZERO_BIT
+    assert A < 256 and env.nslots <= ZERO_BIT
     return A | (B << 8) | (f << 14)
 
 
@@ -786,13 +828,13 @@ def emit(envs):
         N = env.N
         Rp = 1 << (B28 * N)
         nm = env.name
-        assert len(env.slots) <= 32
-        nregs = 2 * len(env.slots) + len(env.const_values) + len(env.regs) + env.ntemp
-        named = 2 * len(env.slots) + len(env.const_values)
-        L.append(f"// ---- {nm}: {len(env.slots)} state slots, {len(env.const_values)} constants, {len(env.regs)} named registers, {env.ntemp} temporaries")
+        assert env.nslots <= 32
+        nregs = 2 * env.nslots + len(env.const_values) + len(env.regs) + env.ntemp
+        named = 2 * env.nslots + len(env.const_values)
+        L.append(f"// ---- {nm}: {env.nslots} state slots, {len(env.const_values)} constants, {len(env.regs)} named registers, {env.ntemp} temporaries")
         L.append(f"struct {nm} {{")
-        L.append(f"  static constexpr int NSLOTS = {len(env.slots)}, NCONST = {len(env.const_values)}, NNAMED = {len(env.regs)}, NTEMP = {env.ntemp}, NREGS = {nregs};")
-        L.append(f"  static constexpr int CONST_BASE = {2 * len(env.slots)}, NAMED_BASE = {named};")
+        L.append(f"  static constexpr int NSLOTS = {env.nslots}, NCONST = {len(env.const_values)}, NNAMED = {len(env.regs)}, NTEMP = {env.ntemp}, NREGS = {nregs};")
+        L.append(f"  static constexpr int CONST_BASE = {2 * env.nslots}, NAMED_BASE = {named};")
         L.append(f"  // operand space 3: register = TAB_BASE[table] + sel * TAB_STRIDE[table] + offset (the script sets sel)")
         L.append(f"  static constexpr int TAB0_BASE = {named + env.regs['ft1_0']}, TAB0_STRIDE = 1, TAB1_BASE = {named + env.regs['pb1_0']}, TAB1_STRIDE = {env.k};")
         for sname, si in env.slots.items():
@@ -881,7 +923,7 @@ def main():
         for fam in ("f", "acc"):
             assert all(env.slots[f"{fam}{j}"] == env.slots[f"{fam}0"] + j for j in range(env.k)), fam
         tot = {n: (len(c["steps"]), sum(len(i) for _, i in c["steps"])) for n, c in env.compiled.items()}
-        print(env.name, "slots", len(env.slots), "consts", len(env.const_values), "named", len(env.regs), "temps", env.ntemp, tot)
+        print(env.name, "slots", env.nslots, "consts", len(env.const_values), "named", len(env.regs), "temps", env.ntemp, tot)
     path = os.path.join(ROOT, "pcd_amd", "csrc", "pairing_vm_gen.h")
     with open(path, "w") as fh:
         fh.write(emit(envs))
