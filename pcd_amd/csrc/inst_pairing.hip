@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(64) vm_miller_kernel(const uint32_t* __restric
     if (lane < (uint32_t)KK) (lane == 0 ? Fq::one() : Fq::zero()).store(out + (size_t)pair * GW + tower_word((int)lane, Fq::WORDS));
     return;
   }
-  vm.run_script();
+  vm.run_flat(tb.flat, 0, tb.nflat);
   if (lane < (uint32_t)KK) vm.get_state(VG::S_F0 + (int)lane).store(out + (size_t)pair * GW + tower_word((int)lane, Fq::WORDS));
 }
 // one wave per group of `per` consecutive Miller values: their product, then the final exponentiation
@@ -111,9 +111,9 @@ __global__ void __launch_bounds__(64) vm_final_exp_kernel(const uint32_t* __rest
   for (uint32_t i = 1; i < per; i++) {
     if (lane < (uint32_t)KK) vm.set_reg(VG::R_G0 + (int)lane, Fq::load(fs + ((size_t)g * per + i) * GW + tower_word((int)lane, Fq::WORDS)));
     __syncthreads();
-    vm.run(VM_TABLE(final_exp_P_FE_MUL));
+    vm.run_flat(tb.flat, tb.alone_off, tb.alone_len);   // fe_mul
   }
-  vm.run_script();  // norm, the one field inversion (sliding window over p - 2), easy part, w0 power (sliding window), last product
+  vm.run_flat(tb.flat, 0, tb.nflat);  // norm, the one field inversion (sliding window over p - 2), easy part, w0 power (sliding window), last product
   if (lane < (uint32_t)KK) vm.get_state(VG::S_ACC0 + (int)lane).to_abi(out + (size_t)g * GWA + tower_word((int)lane, Fq::ABI_WORDS));
 }
 
@@ -166,25 +166,24 @@ hipError_t g1_scale(hipStream_t st, const uint32_t* g1_dev, const uint32_t* k_de
 static hipError_t vm_upload(hipStream_t st, void** block, VmCurveTables* out) {
   struct Part { const void* src; size_t bytes; };
   const Part parts[] = {
-      {VM_TABLE(miller_progs), sizeof(VM_TABLE(miller_progs))}, {VM_TABLE(miller_steps), sizeof(VM_TABLE(miller_steps))},
-      {VM_TABLE(miller_code), sizeof(VM_TABLE(miller_code))}, {VM_TABLE(miller_script), sizeof(VM_TABLE(miller_script))},
-      {VM_TABLE(final_exp_progs), sizeof(VM_TABLE(final_exp_progs))}, {VM_TABLE(final_exp_steps), sizeof(VM_TABLE(final_exp_steps))},
-      {VM_TABLE(final_exp_code), sizeof(VM_TABLE(final_exp_code))}, {VM_TABLE(final_exp_script), sizeof(VM_TABLE(final_exp_script))},
+      {VM_TABLE(miller_code), sizeof(VM_TABLE(miller_code))}, {VM_TABLE(miller_flat), sizeof(VM_TABLE(miller_flat))},
+      {VM_TABLE(final_exp_code), sizeof(VM_TABLE(final_exp_code))}, {VM_TABLE(final_exp_flat), sizeof(VM_TABLE(final_exp_flat))},
       {VM_TABLE(consts), sizeof(VM_TABLE(consts))}};
-  size_t off[10] = {0};
-  for (int i = 0; i < 9; i++) off[i + 1] = off[i] + ((parts[i].bytes + 15) & ~(size_t)15);
+  constexpr int NP = 5;
+  size_t off[NP + 1] = {0};
+  for (int i = 0; i < NP; i++) off[i + 1] = off[i] + ((parts[i].bytes + 15) & ~(size_t)15);
   void* blk = nullptr;
-  hipError_t e = hipMalloc(&blk, off[9]);
+  hipError_t e = hipMalloc(&blk, off[NP]);
   if (e != hipSuccess) return e;
   char* d = (char*)blk;
-  for (int i = 0; i < 9 && e == hipSuccess; i++) e = hipMemcpyAsync(d + off[i], parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, st);
+  for (int i = 0; i < NP && e == hipSuccess; i++) e = hipMemcpyAsync(d + off[i], parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) { (void)hipFree(blk); return e; }  // nothing is published: the next pairing call uploads again
   auto at = [&](int i) { return (const uint32_t*)(d + off[i]); };
-  out->miller = {at(0), at(1), at(2), at(8), at(3), (uint32_t)(parts[0].bytes / 12), (uint32_t)(parts[1].bytes / 12), (uint32_t)(parts[2].bytes / 4),
-                 VM_TABLE(miller_script_len)};
-  out->final_exp = {at(4), at(5), at(6), at(8), at(7), (uint32_t)(parts[4].bytes / 12), (uint32_t)(parts[5].bytes / 12),
-                    (uint32_t)(parts[6].bytes / 4), VM_TABLE(final_exp_script_len)};
+  // (progs / steps / script stay on the host: the device walks the flat records)
+  out->miller = {nullptr, nullptr, at(0), at(4), nullptr, 0, 0, (uint32_t)(parts[0].bytes / 4), 0, at(1), VM_TABLE(miller_flat_script_len), 0, 0};
+  out->final_exp = {nullptr, nullptr, at(2), at(4), nullptr, 0, 0, (uint32_t)(parts[2].bytes / 4), 0, at(3), VM_TABLE(final_exp_flat_script_len),
+                    VM_TABLE(final_exp_flat_FE_MUL_off), VM_TABLE(final_exp_flat_FE_MUL_len)};
   *block = blk;  // block and tables become visible together, only after every copy has landed
   return hipSuccess;
 }

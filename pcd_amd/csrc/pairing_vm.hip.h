@@ -217,22 +217,18 @@ struct VmWave {
   typedef VmArith<F> A;
   typedef __attribute__((address_space(3))) uint32_t* Lds;
   Lds regs;
-  Lds code, steps, progs, script;  // this kernel's tables, copied into LDS once: an instruction fetch is a ~100-cycle LDS read, not a
+  Lds code;                        // this kernel's instruction words, copied into LDS once: an instruction fetch is a ~100-cycle LDS read, not a
                                    // dependent trip to L2 in front of every one of the thousands of steps of a pairing
   uint64_t bank;                   // low half: the bank of every state slot; high half: the table selector
-  uint32_t script_len;
 
-  // LDS words: the register file, then the tables
+  // LDS words: the register file, then the instruction words
   static constexpr uint32_t REG_WORDS = (uint32_t)G::NREGS * A::STRIDE;
-  __host__ __device__ static uint32_t lds_words(const VmTables& t) { return REG_WORDS + t.ncode + 3 * t.nsteps + 3 * t.nprogs + (t.script_len + 3) / 4; }
+  __host__ __device__ static uint32_t lds_words(const VmTables& t) { return REG_WORDS + t.ncode; }
 
   PCD_DEV void init(Lds r, const VmTables& t) {
-    regs = r; bank = 0; script_len = t.script_len;
-    code = r + REG_WORDS; steps = code + t.ncode; progs = steps + 3 * t.nsteps; script = progs + 3 * t.nprogs;
+    regs = r; bank = 0;
+    code = r + REG_WORDS;
     for (uint32_t i = threadIdx.x; i < t.ncode; i += 64) code[i] = t.code[i];
-    for (uint32_t i = threadIdx.x; i < 3 * t.nsteps; i += 64) steps[i] = t.steps[i];
-    for (uint32_t i = threadIdx.x; i < 3 * t.nprogs; i += 64) progs[i] = t.progs[i];
-    for (uint32_t i = threadIdx.x; i < (t.script_len + 3) / 4; i += 64) script[i] = t.script[i];
     for (uint32_t c = threadIdx.x; c < (uint32_t)G::NCONST; c += 64) {
       F v;
 #pragma unroll
@@ -245,41 +241,47 @@ struct VmWave {
   PCD_DEV F get_reg(int r) const { return A::ld(regs, (uint32_t)r); }
   PCD_DEV void set_reg(int r, const F& v) { A::st(regs, (uint32_t)r, v); }
 
-  // one program: steps in order, a barrier (one wave: a fence) after each; lanes beyond a step's slot count, and the lanes of
-  // continuation slots, idle.  The fetch is software-pipelined: while step s computes, the instruction words of step s + 1 and the
-  // header of step s + 2 are already on their way from LDS (the fetch chain header -> words -> operands was three exposed LDS round
-  // trips in front of every step).  Everything the loop needs of *this is held in locals: the object lives in private memory, and
-  // members read through `this` are reloaded from there after every barrier -- two flat loads per step on the critical path.
-  __device__ __noinline__ void run(int pid) {
-    const Lds regs_ = regs, code_ = code, steps_ = steps;
-    const uint64_t bank_ = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(bank >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)bank);
-    const uint32_t first = __builtin_amdgcn_readfirstlane(progs[3 * pid]), cnt = __builtin_amdgcn_readfirstlane(progs[3 * pid + 1]);
-    const uint32_t flip = progs[3 * pid + 2];
+  // Steps first .. first + cnt - 1 of the kernel's flat list (vm_tables.h: the script with its programs expanded), a barrier (one wave:
+  // a fence) after each; lanes beyond a step's slot count, and the lanes of continuation slots, idle.  The records are wave-uniform
+  // (every lane loads the same 16 bytes from global memory); the fetch is software-pipelined ACROSS program
+  // boundaries: while step i computes, the instruction words of step i + 1 are on their way from LDS and the record of step i + 2 from
+  // memory (the fetch chain record -> words -> operands was three exposed round trips in front of every step, and every program began
+  // with an empty pipeline: 400 of them in a verification).  Everything the loop needs of *this is held in locals: the object lives in
+  // private memory, and members read through `this` are reloaded from there after every barrier.
+  __device__ __noinline__ void run_flat(const uint32_t* __restrict__ flat, uint32_t first, uint32_t cnt) {
+    if (cnt == 0) return;
+    const Lds regs_ = regs, code_ = code;
+    uint32_t bank_lo = __builtin_amdgcn_readfirstlane((uint32_t)bank), sel = __builtin_amdgcn_readfirstlane((uint32_t)(bank >> 32));
+    first = __builtin_amdgcn_readfirstlane(first); cnt = __builtin_amdgcn_readfirstlane(cnt);
+    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+    // (a GLOBAL pointer, not a generic one: a flat load counts on the LDS counter as well, and every wait for an operand would wait for it)
+    typedef const __attribute__((address_space(1))) U4* RecPtr;
+    const RecPtr recs = (RecPtr)(uintptr_t)flat;
     const uint32_t lane = threadIdx.x;
-    const uint32_t last = first + cnt - 1;   // (headers past the end are read from the last step: harmless, never used)
-    auto header = [&](uint32_t s, uint32_t& kw, uint32_t& off, uint32_t& n) {
-      s = s < last ? s : last;
-      kw = steps_[3 * s]; off = steps_[3 * s + 1]; n = steps_[3 * s + 2];
-    };
+    const uint32_t last = first + cnt - 1;   // (records past the end are read from the last step: harmless, never used)
     auto fetch = [&](uint32_t off, uint32_t n, uint32_t* w) {   // (lanes beyond the step's slots re-read its last slot: in bounds, unused)
       const uint32_t slot = off + (lane < n ? lane : n - 1);
 #pragma unroll
       for (int i = 0; i < 12; i++) w[i] = code_[slot * 12 + i];
     };
-    uint32_t kw0, off0, n0, kw1, off1, n1;
-    header(first, kw0, off0, n0);
-    header(first + 1, kw1, off1, n1);
+    U4 r0 = recs[first], r1 = recs[first < last ? first + 1 : last];
     uint32_t w[12];
-    fetch(__builtin_amdgcn_readfirstlane(off0), __builtin_amdgcn_readfirstlane(n0), w);
+    fetch(__builtin_amdgcn_readfirstlane(r0.y), __builtin_amdgcn_readfirstlane(r0.z), w);
     for (uint32_t s = first; s <= last; s++) {
-      // (the step's words are the same for every lane: taken through readfirstlane so that the dispatch below is scalar branches)
-      const uint32_t kw = __builtin_amdgcn_readfirstlane(kw0), off = __builtin_amdgcn_readfirstlane(off0), n = __builtin_amdgcn_readfirstlane(n0);
-      const uint32_t off_next = __builtin_amdgcn_readfirstlane(off1), n_next = __builtin_amdgcn_readfirstlane(n1);
-      const uint32_t kind = kw & 0xFFu, tmax = kw >> 8;   // tmax: the largest term count among the step's LIN instructions
+      // (every lane loaded the same record: through readfirstlane the dispatch below is scalar branches)
+      const uint32_t kw = __builtin_amdgcn_readfirstlane(r0.x), off = __builtin_amdgcn_readfirstlane(r0.y), n = __builtin_amdgcn_readfirstlane(r0.z),
+                     flip = __builtin_amdgcn_readfirstlane(r0.w);
+      const uint32_t kind = kw & 0xFFu, tmax = (kw >> 8) & 0xFFu, flags = kw >> 16;   // tmax: the largest term count among the step's LIN instructions
       uint32_t wn[12];
-      fetch(off_next, n_next, wn);               // step s + 1's words
-      kw0 = kw1; off0 = off1; n0 = n1;
-      header(s + 2, kw1, off1, n1);              // step s + 2's header
+      fetch(__builtin_amdgcn_readfirstlane(r1.y), __builtin_amdgcn_readfirstlane(r1.z), wn);   // step s + 1's words
+      r0 = r1;
+      r1 = recs[s + 2 < last ? s + 2 : last];    // step s + 2's record
+      if (flags & 2u) sel = (flags >> 4) & 0xFu;
+      if (flags & 4u) {   // SCRIPT_INV: the one field inversion of a final exponentiation, by divsteps on one lane
+        if (lane == 0) A::st(regs_, (uint32_t)G::R_FT1_0, A::ld(regs_, (uint32_t)G::R_NRM0).inv());
+        __syncthreads();
+      }
+      const uint64_t bank_ = ((uint64_t)sel << 32) | bank_lo;
       if (lane < n && (w[0] & 0xFFu) != 0xFFu) {
         F o;
         if (kind == 1) o = A::template mul<G>(w, regs_, bank_);
@@ -293,27 +295,16 @@ struct VmWave {
           o = A::template lin_uniform<G>(w, w2, regs_, bank_, tmax);
 #else
           o = A::template lin<G>(w, w2, regs_, bank_);   // (host pass of the compiler: never run)
-          (void)tmax;
 #endif
         }
         A::st(regs_, A::template reg_of_g<G>(w[0] >> 16, bank_), o);   // (every lane has read its operands before any lane stores: lockstep)
       }
       __syncthreads();
+      if (flags & 1u) bank_lo ^= flip;           // a program ends: the slots it wrote change banks
 #pragma unroll
       for (int i = 0; i < 12; i++) w[i] = wn[i];
     }
-    bank ^= (uint64_t)flip;
-  }
-  // the kernel's script: program ids in order; entries from 0xF0 up select a table entry for the programs that follow, 0xEF inverts
-  PCD_DEV void run_script() {
-    for (uint32_t i = 0; i < script_len; i++) {
-      const uint32_t e = (script[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-      if (e >= 0xF0u) bank = (bank & 0xFFFFFFFFull) | ((uint64_t)(e - 0xF0u) << 32);
-      else if (e == 0xEFu) {  // SCRIPT_INV: the one field inversion of a final exponentiation, by divsteps on one lane
-        if (threadIdx.x == 0) set_reg(G::R_FT1_0, get_reg(G::R_NRM0).inv());
-        __syncthreads();
-      } else run((int)e);
-    }
+    bank = ((uint64_t)sel << 32) | bank_lo;
   }
 };
 #endif

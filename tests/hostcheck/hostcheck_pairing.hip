@@ -96,7 +96,7 @@ static void vm_pairing_host(const VmCurveTables& tb, int p_fe_mul, const uint32_
   for (int j = 0; j < K; j++) vm.get_state(VG::S_ACC0 + j).to_abi(out + ((j & 1) * D + (j >> 1)) * Fq::ABI_WORDS);
 }
 #define HC_VM_SET(C, S) VmTables{&vmgen::C##_##S##_progs[0][0], &vmgen::C##_##S##_steps[0][0], vmgen::C##_##S##_code, &vmgen::C##_consts[0][0], \
-                                 vmgen::C##_##S##_script, 0, 0, 0, vmgen::C##_##S##_script_len}
+                                 vmgen::C##_##S##_script, 0, 0, 0, vmgen::C##_##S##_script_len, nullptr, 0, 0, 0}
 #define HC_VM_TABLES(C) VmCurveTables{HC_VM_SET(C, miller), HC_VM_SET(C, final_exp)}, vmgen::C##_final_exp_P_FE_MUL
 // g1z: nullable (affine points) or one Fq element per pair (Jacobian points)
 extern "C" int hc_vm_pairing(int curve, const uint32_t* g1, const uint32_t* g1z, const uint32_t* g2, int n, uint32_t* out) {

@@ -489,6 +489,7 @@ def build(cid):
     env.scripts["final_exp"] = (["fe_norm", ("inv", 0), ("sel", 0), "fq_init", "fe_easy", "pow_tab"]
                                 + window_schedule(env.w0, WIN_POW, "pow_init", "pow_sqr", "pow_mul") + ["fe_last"])
     # which kernel needs which programs (each kernel stages only its own in LDS)
+    env.standalone = {"final_exp": ["fe_mul"]}     # programs a kernel also runs outside its script
     env.sets = {"miller": ["setup", "dbl", "add", "flush", "negfix"],
                 "final_exp": ["fe_mul"] + [n for n in env.progs if n.startswith(("fe_n", "fq_", "fe_e", "pow_", "fe_l"))]}
     # the table registers are consecutive: entry (j - 1) / 2 of table 0 is ft<j>_0, of table 1 is pb<j>_0 .. pb<j>_(k-1)
@@ -876,6 +877,37 @@ def emit(envs):
                 for sl in c["written"]:
                     mask |= 1 << sl
                 progs.append((pname, first, len(steps) - first, mask))
+            # the kernel's whole run as ONE list of step records {kind | tmax << 8 | flags << 16, first slot, slots, bank flip}: the
+            # script with its programs expanded.  flags: 1 = last step of a program (flip the banks of the slots it wrote, word 3),
+            # 2 = select table entry (flags >> 4) before the step, 4 = the field inversion (SCRIPT_INV) before the step.  The device
+            # interpreter walks this list with scalar loads, prefetching across program boundaries; programs a kernel runs on their
+            # own (fe_mul) follow the script's records.
+            by_name = {pname: (first, cnt, mask) for pname, first, cnt, mask in progs}
+
+            def records(pname, pending=0):
+                first, cnt, mask = by_name[pname]
+                out = []
+                for q in range(cnt):
+                    k_, o, n_ = steps[first + q]
+                    fl = (pending if q == 0 else 0) | (1 if q == cnt - 1 else 0)
+                    out.append((k_ | (fl << 16), o, n_, mask if q == cnt - 1 else 0))
+                return out
+            flat, pending = [], 0
+            for e in env.scripts[setname]:
+                if isinstance(e, tuple) and e[0] == "inv":
+                    pending |= 4
+                elif isinstance(e, tuple):
+                    assert e[1] < 16
+                    pending = (pending & ~0xF2) | 2 | (e[1] << 4)
+                else:
+                    flat += records(e, pending)
+                    pending = 0
+            assert pending == 0
+            nflat_script = len(flat)
+            alone = {}
+            for pname in env.standalone.get(setname, []):
+                alone[pname] = (len(flat), by_name[pname][1])
+                flat += records(pname)
             pid = {pname: i for i, (pname, _, _, _) in enumerate(progs)}
             assert len(progs) < SCRIPT_INV
             ids = [SCRIPT_INV if isinstance(e, tuple) and e[0] == "inv" else (SET_SEL + e[1]) if isinstance(e, tuple) else pid[e]
@@ -896,6 +928,13 @@ def emit(envs):
             L.append(f"static const uint32_t {T}_steps[{len(steps)}][3] = {{  // kind | largest LIN term count << 8, first instruction slot, slots")
             for q in range(0, len(steps), 8):
                 L.append("  " + ", ".join(f"{{0x{k_:x}, {o}, {n_}}}" for k_, o, n_ in steps[q:q + 8]) + ",")
+            L.append("};")
+            L.append(f"static const uint32_t {T}_flat_script_len = {nflat_script};")
+            for pname, (o, c_) in alone.items():
+                L.append(f"static const uint32_t {T}_flat_{pname.upper()}_off = {o}, {T}_flat_{pname.upper()}_len = {c_};")
+            L.append(f"static const uint32_t {T}_flat[{len(flat)}][4] = {{  // the run as step records: kind | tmax << 8 | flags << 16, first slot, slots, bank flip")
+            for q in range(0, len(flat), 6):
+                L.append("  " + ", ".join(f"{{0x{a:x}, {b}, {c_}, 0x{d:x}}}" for a, b, c_, d in flat[q:q + 6]) + ",")
             L.append("};")
             L.append(f"static const uint32_t {T}_code[{len(words)}] = {{")
             for q in range(0, len(words), 12):
