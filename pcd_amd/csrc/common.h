@@ -148,10 +148,10 @@ struct GroupEntry {
                            uint32_t* jac_scratch, uint32_t* out_abi, uint8_t* out_inf);
   // prepared public inputs (fixed_base.hip.h): window tables of the bases 1 .. ni - 1 (fb_table_words each, consecutive), then
   // acc_i = base_0 + sum_j x_ij base_j for k proofs in one launch (scratch: k x 64 Jacobians), C-ABI affine out -- or, with out_z_abi,
-  // the Jacobian (X, Y) in out_abi and Z in out_z_abi (no inversion)
+  // the Jacobian (X, Y) in out_abi and Z in out_z_abi (no inversion); proof i's result lands out_stride points after proof i - 1's
   hipError_t (*fb_tables)(hipStream_t, const uint32_t* bases_abi, uint32_t ni, uint32_t* tables);
   hipError_t (*fb_inputs)(hipStream_t, const uint32_t* tables, const uint32_t* base0_abi, uint32_t ni, const uint32_t* scalars, uint32_t k,
-                          uint32_t* scratch, uint32_t* out_abi, uint8_t* out_inf, uint32_t* out_z_abi);
+                          uint32_t* scratch, uint32_t* out_abi, uint8_t* out_inf, uint32_t* out_z_abi, uint32_t out_stride);
 };
 const GroupEntry& group_entry(int curve_id, int group_id);  // group_id 1 / 2
 

@@ -109,7 +109,8 @@ template <class G>
 __global__ void __launch_bounds__(64) fb_inputs_kernel(const uint32_t* __restrict__ tables, size_t tab_words, const uint32_t* __restrict__ abc0_abi, uint32_t ni,
                                                        const uint32_t* __restrict__ scalars /* k x (ni - 1) canonical */, int nwin, int w,
                                                        uint32_t* __restrict__ scratch /* k x 64 Jacobians */, uint32_t* __restrict__ out_abi,
-                                                       uint8_t* __restrict__ out_inf, uint32_t* __restrict__ out_z_abi /* nullable */) {
+                                                       uint8_t* __restrict__ out_inf, uint32_t* __restrict__ out_z_abi /* nullable */,
+                                                       uint32_t out_stride /* points between two proofs' results in out_abi / out_z_abi */) {
   typedef typename G::F F;
   constexpr int SW = G::FR::N32, JW = Jac<F>::WORDS;
   const uint32_t proof = blockIdx.x, lane = threadIdx.x;
@@ -140,10 +141,10 @@ __global__ void __launch_bounds__(64) fb_inputs_kernel(const uint32_t* __restric
     if (out_z_abi) {  // Jacobian result (X, Y | Z): the pairing VM takes it as it is -- no inversion (pairing_vm.hip.h)
       if (acc.is_inf()) acc = Jac<F>::infinity();
       const Aff<F> xy = {acc.X, acc.Y};
-      xy.to_abi(out_abi + (size_t)proof * Aff<F>::ABI_WORDS);
-      acc.Z.to_abi(out_z_abi + (size_t)proof * F::ABI_WORDS);
+      xy.to_abi(out_abi + (size_t)proof * out_stride * Aff<F>::ABI_WORDS);
+      acc.Z.to_abi(out_z_abi + (size_t)proof * out_stride * F::ABI_WORDS);
     } else {
-      EC<G>::to_affine(acc).to_abi(out_abi + (size_t)proof * Aff<F>::ABI_WORDS);
+      EC<G>::to_affine(acc).to_abi(out_abi + (size_t)proof * out_stride * Aff<F>::ABI_WORDS);
     }
   }
 }
@@ -162,9 +163,9 @@ hipError_t fb_tables_build(hipStream_t st, const uint32_t* bases_abi, uint32_t n
 }
 template <class G>
 hipError_t fb_inputs_run(hipStream_t st, const uint32_t* tables, size_t tab_words, const uint32_t* abc0_abi, uint32_t ni, const uint32_t* scalars,
-                         uint32_t k, uint32_t* scratch, uint32_t* out_abi, uint8_t* out_inf, uint32_t* out_z_abi) {
+                         uint32_t k, uint32_t* scratch, uint32_t* out_abi, uint8_t* out_inf, uint32_t* out_z_abi, uint32_t out_stride) {
   constexpr int w = FB_WINDOW, nwin = (G::FR::BITS + w - 1) / w;
-  if (k) hipLaunchKernelGGL((fb_inputs_kernel<G>), dim3(k), dim3(64), 0, st, tables, tab_words, abc0_abi, ni, scalars, nwin, w, scratch, out_abi, out_inf, out_z_abi);
+  if (k) hipLaunchKernelGGL((fb_inputs_kernel<G>), dim3(k), dim3(64), 0, st, tables, tab_words, abc0_abi, ni, scalars, nwin, w, scratch, out_abi, out_inf, out_z_abi, out_stride);
   return hipGetLastError();
 }
 

@@ -120,8 +120,8 @@ hipError_t fb_tables_entry(hipStream_t st, const uint32_t* bases_abi, uint32_t n
   return fb_tables_build<GT>(st, bases_abi, ni, FB_TABLE_WORDS, tables);
 }
 hipError_t fb_inputs_entry(hipStream_t st, const uint32_t* tables, const uint32_t* abc0_abi, uint32_t ni, const uint32_t* scalars, uint32_t k,
-                           uint32_t* scratch, uint32_t* out_abi, uint8_t* out_inf, uint32_t* out_z_abi) {
-  return fb_inputs_run<GT>(st, tables, FB_TABLE_WORDS, abc0_abi, ni, scalars, k, scratch, out_abi, out_inf, out_z_abi);
+                           uint32_t* scratch, uint32_t* out_abi, uint8_t* out_inf, uint32_t* out_z_abi, uint32_t out_stride) {
+  return fb_inputs_run<GT>(st, tables, FB_TABLE_WORDS, abc0_abi, ni, scalars, k, scratch, out_abi, out_inf, out_z_abi, out_stride);
 }
 
 }  // namespace
