@@ -16,11 +16,15 @@ namespace pcd {
 
 constexpr int FB_WINDOW = 8;
 
-// B_j = 2^(w j) B, one lane (a chain of doublings)
+// B_j = 2^(w j) B, one lane (a chain of doublings).  One workgroup per base: base b is the b-th C-ABI point behind base_abi, its chain
+// goes to bj + b * slot_stride -- the chains of several bases (the public-input bases of a verifying key) run side by side instead
+// of one launch after the other.
 template <class G>
-__global__ void __launch_bounds__(64) fb_powers_kernel(const uint32_t* __restrict__ base_abi, uint32_t* __restrict__ bj, int nwin, int w) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__global__ void __launch_bounds__(64) fb_powers_kernel(const uint32_t* __restrict__ base_abi, uint32_t* __restrict__ bj, int nwin, int w, size_t slot_stride) {
+  if (threadIdx.x != 0) return;
   typedef typename G::F F;
+  base_abi += (size_t)blockIdx.x * Aff<F>::ABI_WORDS;
+  bj += (size_t)blockIdx.x * slot_stride;
   Aff<F> b = Aff<F>::from_abi(base_abi);
   Jac<F> p = b.is_inf() ? Jac<F>::infinity() : Jac<F>{b.x, b.y, F::one()};
   for (int j = 0; j < nwin; j++) {
@@ -29,10 +33,12 @@ __global__ void __launch_bounds__(64) fb_powers_kernel(const uint32_t* __restric
   }
 }
 
-// T[j][d] = d * B_j (w-bit double-and-add), affine
+// T[j][d] = d * B_j (w-bit double-and-add), affine; blockIdx.y = the base (chains and tables slot_stride words apart)
 template <class G>
-__global__ void __launch_bounds__(64) fb_table_kernel(const uint32_t* __restrict__ bj, uint32_t* __restrict__ table, int nwin, int w) {
+__global__ void __launch_bounds__(64) fb_table_kernel(const uint32_t* __restrict__ bj, uint32_t* __restrict__ table, int nwin, int w, size_t slot_stride) {
   typedef typename G::F F;
+  bj += (size_t)blockIdx.y * slot_stride;
+  table += (size_t)blockIdx.y * slot_stride;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t j = t >> w, d = t & ((1u << w) - 1);
   if (j >= (uint32_t)nwin || d == 0) return;
@@ -154,10 +160,9 @@ template <class G>
 hipError_t fb_tables_build(hipStream_t st, const uint32_t* bases_abi, uint32_t ni, size_t tab_words, uint32_t* tables) {
   constexpr int w = FB_WINDOW, nwin = (G::FR::BITS + w - 1) / w;
   const size_t pure = ((size_t)nwin << w) * Aff<typename G::F>::WORDS;
-  for (uint32_t j = 1; j < ni; j++) {
-    uint32_t* slot = tables + (size_t)(j - 1) * tab_words;
-    hipLaunchKernelGGL((fb_powers_kernel<G>), dim3(1), dim3(64), 0, st, bases_abi + (size_t)j * Aff<typename G::F>::ABI_WORDS, slot + pure, nwin, w);
-    hipLaunchKernelGGL((fb_table_kernel<G>), dim3(((nwin << w) + 63) / 64), dim3(64), 0, st, slot + pure, slot, nwin, w);
+  if (ni > 1) {  // every base's doubling chain at once, then every table (was: ni - 1 pairs of launches, the chains one after the other)
+    hipLaunchKernelGGL((fb_powers_kernel<G>), dim3(ni - 1), dim3(64), 0, st, bases_abi + Aff<typename G::F>::ABI_WORDS, tables + pure, nwin, w, tab_words);
+    hipLaunchKernelGGL((fb_table_kernel<G>), dim3(((nwin << w) + 63) / 64, ni - 1), dim3(64), 0, st, tables + pure, tables, nwin, w, tab_words);
   }
   return hipGetLastError();
 }
@@ -174,8 +179,8 @@ template <class G>
 hipError_t fixed_base_run(hipStream_t st, const uint32_t* base_abi, const uint32_t* scalars, uint32_t n, uint32_t* bj, uint32_t* table,
                           uint32_t* jac_tmp, uint32_t* out_abi, uint8_t* out_inf) {
   constexpr int w = FB_WINDOW, nwin = (G::FR::BITS + w - 1) / w;
-  hipLaunchKernelGGL((fb_powers_kernel<G>), dim3(1), dim3(64), 0, st, base_abi, bj, nwin, w);
-  hipLaunchKernelGGL((fb_table_kernel<G>), dim3(((nwin << w) + 63) / 64), dim3(64), 0, st, bj, table, nwin, w);
+  hipLaunchKernelGGL((fb_powers_kernel<G>), dim3(1), dim3(64), 0, st, base_abi, bj, nwin, w, (size_t)0);
+  hipLaunchKernelGGL((fb_table_kernel<G>), dim3(((nwin << w) + 63) / 64), dim3(64), 0, st, bj, table, nwin, w, (size_t)0);
   if (n) {
     hipLaunchKernelGGL((fb_mul_kernel<G>), dim3((n + 63) / 64), dim3(64), 0, st, table, scalars, n, nwin, w, jac_tmp);
     const uint32_t lanes = (n + FB_BATCH - 1) / FB_BATCH;
