@@ -132,6 +132,10 @@ def test_process_vk_prepared_and_rlc_batch(co, gpu_ctx, pmode, cid, nc):
         assert np.array_equal(gpu_ctx.groth16_verify_prepared(pvk, pubs, bad_pr), np.arange(k) != 1)
         assert not gpu_ctx.groth16_verify_batch_rlc(pvk, pubs, bad_pr, rho)
         assert gpu_ctx.groth16_verify_batch_rlc(pvk, pubs[:1], proofs[:1], rho[:1])
+        # flagged infinities (A of proof 2, C of proof 4; whatever the flagged coordinates hold is ignored): e(O, .) = 1, so those two fail,
+        # in the single-trip form of the wave-per-pairing kernels and in the lane-per-pairing form alike
+        pinf = np.zeros((k, 3), dtype=np.uint8); pinf[2, 0] = 1; pinf[4, 2] = 1
+        assert np.array_equal(gpu_ctx.groth16_verify_prepared(pvk, pubs, proofs, proofs_inf=pinf), ~np.isin(np.arange(k), (2, 4)))
         if cid == 0:
             # a batch past the wave-per-pairing limit (3 x 1366 > 4096 pairings: the lane-per-pairing kernels, affine accumulations) --
             # this size used to return an error in the default configuration
