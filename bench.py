@@ -555,7 +555,8 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None):
     info = {"unit": "ms", "timing": "median of 5 proves per assembly form",
             "what": "witness map + the proof's MSMs (h, l, A, B1 on G1; B on G2) + assembly (s*A, r*B1 chained behind their MSMs or folded "
                     "into two more MSMs, chosen by size), per proof; the MSMs over the assignment overlap the witness map; R1CS synthesis "
-                    "(Rust host) excluded"}
+                    "(Rust host) excluded.  Keys: seeded points, the a / b queries of variables absent from A / B are the point at infinity "
+                    "as a real setup makes them (`query_infinity_frac`; the CPU port times the same key)"}
     total_gpu, total_cpu = 0.0, 0.0
     for name, curve, nc in proofs:
         fr = co.CURVE_FR[curve]
@@ -563,7 +564,9 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None):
         # the constraint matrices have the shape `cs.finalize()` leaves of a verifier circuit: power-law row lengths (a few rows above 4096
         # entries), >= 80 % unit coefficients (coracle.skewed_r1cs); the assignment stays uniformly random field elements
         r = co.skewed_r1cs(fr, nc, 2, seed=SEED + curve)
-        keys = co.synthetic_keys(curve, r, seed=SEED + 10 + curve)
+        # the key: seeded points, with the points at infinity a real setup leaves in the a / b queries (variables that no row of A / B
+        # mentions: a_i(tau) G = O); PCD_BENCH_DENSE_KEYS=1 makes every entry finite instead (rounds 1-3 measured that: the densest key)
+        keys = co.synthetic_keys(curve, r, seed=SEED + 10 + curve, consistent=os.environ.get("PCD_BENCH_DENSE_KEYS") != "1")
         rs = co.gen_field(fr, 2, seed=SEED + 20)
         gen_s = time.time() - t0
         t0 = time.time()
@@ -593,6 +596,8 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None):
                       "gpu_device_ms": {k: round(float(v), 3) for k, v in tm.items()},
                       "witness_map_alone_ms": wm,   # standalone: inside a prove it shares the device with four MSMs (gpu_device_ms.witness_map)
                       "r1cs_entries": [int(len(r.col_a)), int(len(r.col_b)), int(len(r.col_c))],
+                      # fraction of the a / b query entries that are the point at infinity (as a setup over this R1CS makes them)
+                      "query_infinity_frac": {"a": round(float(np.mean(keys.a_inf)), 4), "b": round(float(np.mean(keys.b_g2_inf)), 4)},
                       "cpu_port_ms": round(cpu_ms, 1), "cpu_threads": threads, "domain": int(keys.domain_size),
                       "key_upload_precompute_s": round(up_s, 2), "input_gen_s": round(gen_s, 2)}
         total_gpu += wall
@@ -672,8 +677,11 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None):
             # the whole main proof against the same peak: executed multiply-adds of its five accumulations (h: n - 1 pairs; l', A, B1 on G1 and
             # B on G2: m + 4 pairs each, W windows of the 2^20 plan) + the 7 transforms (3 passes each, ~5 products per element and pass),
             # over the proof's wall time -- fix-up, bucket reduction, sorts and the assembly count as zero work
+            # (pairs whose base is the point at infinity are not executed: l' has none, A is in the chained form's shared list whole,
+            #  B1 and B leave theirs out)
             m4 = int(keys.a_query.shape[0]) + 4
-            work = ((n - 1) + 3 * m4) * W * madd_mads(curve) + m4 * W * g2_mads + 7 * 3 * n * 5 * 2 * 27 * 27
+            fin_b = 1.0 - float(np.mean(keys.b_g2_inf))
+            work = int(((n - 1) + (2 + fin_b) * m4) * W * madd_mads(curve) + fin_b * m4 * W * g2_mads + 7 * 3 * n * 5 * 2 * 27 * 27)
             info["whole_step_int_frac"] = {"main_mnt4_753": round(work / (info[name]["gpu_wall_ms"] * 1e-3) / MAD_PEAK, 4),
                                            "executed_mads": work, "note": "accumulations + transforms only; everything else counted as zero work"}
         if pk is not None:

@@ -298,11 +298,14 @@ class Keys:
         return s
 
 
-def synthetic_keys(curve, r, seed, mt=False):
+def synthetic_keys(curve, r, seed, mt=False, consistent=True):
     """Groth16 key made of seeded on-curve points, sized for the domain `GeneralEvaluationDomain::new` picks (radix-2 or
     mixed radix).  A real trusted setup at 2^20 takes minutes on the CPU and the prover arithmetic does not depend on the
     key being consistent; proofs made with such a key are compared bit for bit with this oracle's, not verified.
-    mt: the points come from gen_points_mt (other points than with mt=False; for the 2^20+ keys of the 753-bit curves)."""
+    mt: the points come from gen_points_mt (other points than with mt=False; for the 2^20+ keys of the 753-bit curves).
+    consistent: the queries carry the points at infinity a real setup puts there -- a_query[i] = a_i(tau) G is the identity when no
+    row of A mentions variable i (a_i is the zero polynomial), likewise b_g1 / b_g2 for B (ark-groth16 `generate_parameters`; what
+    groth16_setup above produces).  False: every entry finite, the densest key there can be."""
     m, ni = r.num_vars, r.num_inputs
     n = domain_size(r.field, r.num_constraints + ni)
     gen = gen_points_mt if mt else gen_points
@@ -320,6 +323,14 @@ def synthetic_keys(curve, r, seed, mt=False):
     A.update(b_g2_query=np.ascontiguousarray(g2[:m]), beta_g2=np.ascontiguousarray(g2[m]), delta_g2=np.ascontiguousarray(g2[m + 1]),
              gamma_g2=np.ascontiguousarray(g2[m + 1]), gamma_abc_g1=np.ascontiguousarray(g1[:ni]), gamma_abc_inf=z8(ni),
              a_inf=z8(m), b_g1_inf=z8(m), b_g2_inf=z8(m), h_inf=z8(n - 1), l_inf=z8(m - ni))
+    if consistent:
+        for mat, names in ((r.col_a, ("a_inf",)), (r.col_b, ("b_g1_inf", "b_g2_inf"))):
+            absent = np.ones(m, dtype=np.uint8)
+            absent[np.asarray(mat, dtype=np.int64)] = 0
+            if names[0] == "a_inf":
+                absent[:ni] = 0   # (the input-consistency rows of the QAP put every public input into A)
+            for nm in names:
+                A[nm] = absent.copy()
     keys = Keys(curve, r, A)
     keys.domain_size = n
     return keys

@@ -35,7 +35,8 @@ struct pcdhip_bases {
   uint32_t* dptr;  // groups * n affine points, (0,0) = infinity; group g holds 2^(c * Wg * g) P_i
   int c;           // window bits fixed at upload when groups > 1 (0 otherwise)
   int groups;      // 1 = plain bases
-  pcd::MsmBasesView view(size_t offset) const { return {dptr, (uint32_t)n, (uint32_t)offset, c, groups}; }
+  uint32_t* inf_bits = nullptr;  // device bitmap of the points at infinity (bit i: point i), null when the vector holds none
+  pcd::MsmBasesView view(size_t offset) const { return {dptr, (uint32_t)n, (uint32_t)offset, c, groups, inf_bits}; }
   // uploaded through a multi-device context: the vector is cut into contiguous point ranges, shard g (points
   // [shard_lo[g], shard_lo[g + 1])) resident on the context's device g as an ordinary handle; dptr is null then
   std::vector<pcdhip_bases*> shards;
@@ -67,6 +68,10 @@ struct pcdhip_g16_pk {
   std::vector<pcdhip_g16_pk*> shards;
   std::vector<size_t> lo, hlo;
   uint64_t h_len = 0;
+  // points at infinity among this device's entries of the a / b queries (a variable that no row of A / B mentions), and whether b_g1 and
+  // b_g2 flag the same entries (they do in any key a setup made): decides which MSMs of a proof share a sort (G16Run::launch_assignment)
+  size_t a_inf_count = 0, b_inf_count = 0;
+  bool b_inf_same = false;
 };
 struct pcdhip_ctx {
   // multi-device context (pcdhip_init_devices with more than one id): peers[0] == this, peers[g] = the sub-context of device g;
@@ -83,6 +88,7 @@ struct pcdhip_ctx {
   pcd::MsmWorkspace g16_ws[6];
   hipEvent_t g16_ready = nullptr, g16_begin[6] = {nullptr}, g16_end[6] = {nullptr};
   pcd::MsmSharedSort g16_share;  // the sort of the assignment's digits, made once per proof and used by four MSMs
+  pcd::MsmSharedSort g16_share_b;  // ... and a second one without the entries of the B queries' points at infinity (b_g1 / b_g2 only)
   std::map<uint64_t, pcd::FftTables> fft_tables;
   int msm_c = 0;
   uint32_t msm_chunk = 0;

@@ -99,6 +99,11 @@ PCD_DEV bool msm_scalar_too_wide(const uint32_t* s, int bits) {
   }
   return o != 0;
 }
+// Bases that are the point at infinity contribute nothing whatever their scalar: with a bitmap of them (one bit per base of the resident
+// vector; null when it holds none) their entries never enter the bucket lists.  The queries of a Groth16 key are full of them -- a
+// variable that no constraint's A (B) row mentions has a_query (b_query) = O: 28 % / 41 % of the variables of the bench's R1CS -- and a
+// lane that meets one in its chunk idles for a whole mixed addition while its wave works.
+PCD_DEV bool msm_base_is_inf(const uint32_t* __restrict__ inf_bits, uint32_t idx) { return inf_bits && ((inf_bits[idx >> 5] >> (idx & 31u)) & 1u); }
 template <int NS>
 PCD_DEV uint32_t msm_digit(const uint32_t* s, int w, int c) {
   int bit = w * c;
@@ -127,10 +132,10 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
                                                          uint32_t* __restrict__ sorted_idx, uint32_t* __restrict__ slots, uint32_t cap,
                                                          uint32_t* __restrict__ ones_idx, uint32_t* __restrict__ flag, int skip_ones,
-                                                         int scalar_bits, uint32_t* __restrict__ err) {
+                                                         int scalar_bits, uint32_t* __restrict__ err, const uint32_t* __restrict__ inf_bits) {
   if (MODE == MODE_SCATTER && flag && *flag == 0) return;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool live = i < n;
+  bool live = i < n && !msm_base_is_inf(inf_bits, base_offset + i);
   uint32_t s[NS];
   bool is_one = false;
   if (live) {
@@ -202,7 +207,8 @@ __global__ void __launch_bounds__(256) msm_coarse_kernel(const uint32_t* __restr
                                                          uint32_t n_total, uint32_t base_offset, uint32_t nbins,
                                                          uint32_t* __restrict__ gbin /* WRITE: cursors (start at the bin bases) */,
                                                          uint64_t* __restrict__ entries, uint32_t* __restrict__ ones_count,
-                                                         uint32_t* __restrict__ ones_idx, int scalar_bits, uint32_t* __restrict__ err) {
+                                                         uint32_t* __restrict__ ones_idx, int scalar_bits, uint32_t* __restrict__ err,
+                                                         const uint32_t* __restrict__ inf_bits) {
   extern __shared__ uint32_t lbin[];  // nbins counters, then (WRITE) reused as cursors
   __shared__ uint32_t s_ones[WRITE ? 1 : MSM_TILE];  // pass 0: base indices of this tile's scalars equal to one
   __shared__ uint32_t s_nones, s_ones_base;
@@ -213,7 +219,7 @@ __global__ void __launch_bounds__(256) msm_coarse_kernel(const uint32_t* __restr
   // sweep A: histogram of this tile
   for (uint32_t k = threadIdx.x; k < MSM_TILE; k += blockDim.x) {
     uint32_t i = tile0 + k;
-    bool live = i < n;
+    bool live = i < n && !msm_base_is_inf(inf_bits, base_offset + i);
     uint32_t s[NS];
     bool is_one = false;
     if (live) {
@@ -263,7 +269,7 @@ __global__ void __launch_bounds__(256) msm_coarse_kernel(const uint32_t* __restr
   // sweep B: write the entries
   for (uint32_t k = threadIdx.x; k < MSM_TILE; k += blockDim.x) {
     uint32_t i = tile0 + k;
-    if (i >= n) continue;
+    if (i >= n || msm_base_is_inf(inf_bits, base_offset + i)) continue;
     uint32_t s[NS];
     uint32_t hi = 0;
 #pragma unroll
@@ -1451,6 +1457,7 @@ struct MsmBasesView {
   uint32_t offset;       // first point of this MSM
   int c;                 // window bits the groups were built for (0: no precomputation, free choice)
   int groups;            // 1: no precomputation
+  const uint32_t* inf_bits = nullptr;  // bit i set: point i (of n_total) is the point at infinity; null: none is (msm_base_is_inf)
 };
 
 // Several MSMs over the SAME scalar vector and identically laid-out base arrays (the a, b_g1, b_g2 and l queries of one
@@ -1586,7 +1593,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     zero_start(tkeys);
     // 1. one pass: slots + exact histogram
     hipLaunchKernelGGL((msm_digits_kernel<NS, MODE_BIN>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, pl.nkeys, cnt,
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr, slots, cap, ones_idx, flag, 0, SBITS, err);
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, slots, cap, ones_idx, flag, 0, SBITS, err, bv.inf_bits);
     PCD_HIP_TRY(mark(1));
     // 2. scan
     hipLaunchKernelGGL(scan_block_sums, dim3(scan_blocks), dim3(1024), 0, st, cnt, tkeys, scan_per_block, bsum);
@@ -1597,7 +1604,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     uint32_t* cur = (uint32_t*)ws.buf[WS_CUR];
     PCD_HIP_TRY(hipMemsetAsync(cur, 0, (size_t)tkeys * 4, st));
     hipLaunchKernelGGL((msm_digits_kernel<NS, MODE_SCATTER>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, pl.nkeys, cur,
-                       off, sorted, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, flag, 1, SBITS, err);
+                       off, sorted, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, flag, 1, SBITS, err, bv.inf_bits);
     PCD_HIP_TRY(mark(3));
     src = {sorted, slots, ones_idx, flag, cap, ones_key};
   } else if (use_partition) {
@@ -1611,12 +1618,12 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     uint32_t* cursor = bin_base + nbins + 2;
     uint32_t* ones_count = flag;  // (the binning flag word is unused on this path)
     hipLaunchKernelGGL((msm_coarse_kernel<NS, false>), dim3(tiles), dim3(256), (size_t)nbins * 4, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total,
-                       bv.offset, nbins, cnt, (uint64_t*)nullptr, ones_count, ones_idx, SBITS, err);
+                       bv.offset, nbins, cnt, (uint64_t*)nullptr, ones_count, ones_idx, SBITS, err, bv.inf_bits);
     PCD_HIP_TRY(mark(1));
     hipLaunchKernelGGL(msm_bin_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, nbins, bin_base, cursor, ones_count, off, pl.nkeys);
     PCD_HIP_TRY(mark(2));
     hipLaunchKernelGGL((msm_coarse_kernel<NS, true>), dim3(tiles), dim3(256), (size_t)nbins * 4, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total,
-                       bv.offset, nbins, cursor, entries, ones_count, ones_idx, SBITS, err);
+                       bv.offset, nbins, cursor, entries, ones_count, ones_idx, SBITS, err, bv.inf_bits);
     hipLaunchKernelGGL(msm_bin_sort_kernel, dim3(nbins), dim3(256), 0, st, entries, bin_base, sorted, off);
     PCD_HIP_TRY(mark(3));
     src = {sorted, nullptr, ones_idx, nullptr, 0u, ones_key};
@@ -1624,14 +1631,14 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     zero_start(tkeys);
     // 1. histogram  2. scan  3. scatter (cursor = cnt reset to zero)
     hipLaunchKernelGGL((msm_digits_kernel<NS, MODE_HIST>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, pl.nkeys, cnt,
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, 0, SBITS, err);
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, 0, SBITS, err, bv.inf_bits);
     PCD_HIP_TRY(mark(1));
     hipLaunchKernelGGL(scan_block_sums, dim3(scan_blocks), dim3(1024), 0, st, cnt, tkeys, scan_per_block, bsum);
     hipLaunchKernelGGL(scan_apply, dim3(scan_blocks), dim3(1024), 0, st, cnt, tkeys, scan_per_block, bsum, scan_blocks, off);
     PCD_HIP_TRY(mark(2));
     PCD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)tkeys * 4, st));
     hipLaunchKernelGGL((msm_digits_kernel<NS, MODE_SCATTER>), gd, bd, 0, st, scalars_dev, n, pl.c, pl.W, Wg, bv.n_total, bv.offset, pl.nkeys, cnt,
-                       off, sorted, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, 0, SBITS, err);
+                       off, sorted, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, 0, SBITS, err, bv.inf_bits);
     PCD_HIP_TRY(mark(3));
     src = {sorted, nullptr, nullptr, nullptr, 0u, ones_key};
   }

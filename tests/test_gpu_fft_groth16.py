@@ -127,6 +127,50 @@ def test_witness_map_skewed_matrix(co, gpu_ctx, cid, nc):
         pk.free()
 
 
+@pytest.mark.parametrize("cid,nc", [(0, 30000), (3, 6000)])
+def test_prove_keys_with_points_at_infinity(co, gpu_ctx, cid, nc):
+    """The a / b queries of a real key hold the point at infinity for every variable that no row of A / B mentions (a third of them in
+    this R1CS).  Their entries are left out of the MSMs' bucket lists, and which MSMs of a proof share a sort depends on them
+    (capi.hip G16Run::launch_assignment): the key as a setup makes it, the key with every entry finite, and a key whose b_g1 / b_g2 flags
+    differ, each through both assembly forms -- the proof equal to the oracle's every time.  (Whatever coordinates a flagged entry holds
+    are ignored: the synthetic key keeps its seeded points there.)"""
+    fr = co.CURVE_FR[cid]
+    r = co.skewed_r1cs(fr, nc, 2, seed=330 + cid)
+    rs = co.gen_field(fr, 2, seed=331)
+    variants = []
+    sparse = co.synthetic_keys(cid, r, seed=332)
+    assert 0.1 < sparse.a_inf.mean() < 0.6 and 0.2 < sparse.b_g2_inf.mean() < 0.7 and not sparse.a_inf[:r.num_inputs].any()
+    variants.append(sparse)
+    variants.append(co.synthetic_keys(cid, r, seed=332, consistent=False))
+    odd = co.synthetic_keys(cid, r, seed=332)
+    i = int(np.flatnonzero(odd.b_g1_inf)[3])
+    odd.b_g1_inf[i] = 0                      # b_g1 finite where b_g2 is infinite: the two B MSMs may not share a list
+    variants.append(odd)
+    for keys in variants:
+        want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=16)
+        pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
+        try:
+            for mode in (1, 2, 0):
+                gpu_ctx.groth16_set_assembly(mode)
+                got, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
+                assert np.array_equal(got, want) and np.array_equal(inf, winf), (mode, float(keys.b_g2_inf.mean()))
+        finally:
+            gpu_ctx.groth16_set_assembly(0)
+            pk.free()
+    # a plain MSM over a vector with flagged entries, scalars of every kind on them (random, zero, one)
+    n = 5000
+    pts = co.gen_points(cid, 1, n, seed=333)
+    inf = (np.arange(n) % 3 == 0).astype(np.uint8)
+    sc = co.gen_scalars(fr, n, seed=334, dist=1)
+    b = gpu_ctx.bases_upload(cid, 1, pts, inf=inf)
+    sb = gpu_ctx.buf_upload(fr, sc)
+    try:
+        got = gpu_ctx.msm(b, sb)
+    finally:
+        b.free(); sb.free()
+    assert np.array_equal(co.to_affine(cid, 1, got)[0], co.to_affine(cid, 1, co.msm(cid, 1, pts, sc, inf=inf, nthreads=8))[0])
+
+
 @pytest.mark.parametrize("cid", [0, 1])
 def test_groth16_golden_proof(co, golden, gpu_ctx, cid):
     """Keys and expected proof come from the pure-Python oracle (tests/golden/groth16.npz)."""
