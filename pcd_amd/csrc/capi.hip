@@ -1363,11 +1363,11 @@ struct G16Run {
       } else if (sparse_b) {
         jobs[nj++] = {&g1, vb1, zc, n, slot(5), 4, t1, slot(4), NONE};
         jobs[nj++] = {&g2, vb2, zc, n, msm_g2, 5, nullptr, nullptr, NONE};
-      } else {
-        jobs[nj++] = {&g1, plain(vb1), zc, n, slot(5), 4, t1, slot(4), CONSUME};
+      } else {   // (the full list: made by A, or by B_1 when A sorts for itself)
+        jobs[nj++] = {&g1, plain(vb1), zc, n, slot(5), 4, t1, slot(4), sparse_a ? PRODUCE : CONSUME};
         jobs[nj++] = {&g2, plain(vb2), zc, n, msm_g2, 5, nullptr, nullptr, CONSUME};
       }
-      jobs[nj++] = {&g1, plain(vl), zc, n, slot(1), 2, nullptr, nullptr, CONSUME};                           // l'
+      jobs[nj++] = {&g1, plain(vl), zc, n, slot(1), 2, nullptr, nullptr, (sparse_a && sparse_b) ? NONE : CONSUME};   // l'
     }
     for (int k = 0; k < nj; k++) { int rc = launch(k, after ? after : ctx->g16_ready); if (rc) return rc; }
     return PCDHIP_OK;

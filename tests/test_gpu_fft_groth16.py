@@ -146,6 +146,9 @@ def test_prove_keys_with_points_at_infinity(co, gpu_ctx, cid, nc):
     i = int(np.flatnonzero(odd.b_g1_inf)[3])
     odd.b_g1_inf[i] = 0                      # b_g1 finite where b_g2 is infinite: the two B MSMs may not share a list
     variants.append(odd)
+    only_a = co.synthetic_keys(cid, r, seed=332); only_a.b_g1_inf[:] = 0; only_a.b_g2_inf[:] = 0    # (each combination shares sorts differently)
+    only_b = co.synthetic_keys(cid, r, seed=332); only_b.a_inf[:] = 0
+    variants += [only_a, only_b]
     for keys in variants:
         want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=16)
         pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
