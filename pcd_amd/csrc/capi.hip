@@ -1341,16 +1341,21 @@ struct G16Run {
     const MsmBasesView va = pk->a_query->view(0), vb1 = pk->b_g1_query->view(0), vb2 = pk->b_g2_query->view(0), vl = pk->l_query->view(0);
     const bool sparse_b = pk->b_inf_count * 16 > cnt;
     if (folded) {
+      // (A leaves the shared list for a sort of its own when enough of its entries are infinite AND the MSM is large: at 2^16 the sort costs
+      //  what the shorter accumulation saves)
+      const bool a_alone = pk->a_inf_count * 16 > cnt && cnt >= ((size_t)1 << 17);   // (measured, folded form: 298-bit 2^20 neutral, 753-bit 2^20 185 -> 180 ms)
       if (sparse_b) {
         jobs[nj++] = {&g2, vb2, zc, n, msm_g2, 5, nullptr, nullptr, NONE};                                   // B (heaviest: high priority), its own sort
-        jobs[nj++] = {&g1, plain(va), zc, n, slot(2), 3, nullptr, nullptr, PRODUCE};                         // A
+        if (a_alone) jobs[nj++] = {&g1, va, zc, n, slot(2), 3, nullptr, nullptr, NONE};                      // A
+        else jobs[nj++] = {&g1, plain(va), zc, n, slot(2), 3, nullptr, nullptr, PRODUCE};
       } else {
         jobs[nj++] = {&g2, plain(vb2), zc, n, msm_g2, 5, nullptr, nullptr, PRODUCE};                         // B
-        jobs[nj++] = {&g1, plain(va), zc, n, slot(2), 3, nullptr, nullptr, CONSUME};                         // A
+        if (a_alone) jobs[nj++] = {&g1, va, zc, n, slot(2), 3, nullptr, nullptr, NONE};                      // A
+        else jobs[nj++] = {&g1, plain(va), zc, n, slot(2), 3, nullptr, nullptr, CONSUME};
       }
       jobs[nj++] = {&g1, va, szc, n, slot(3), 3, nullptr, nullptr, NONE};                                    // s * A
       jobs[nj++] = {&g1, vb1, rzc, n, slot(4), 4, nullptr, nullptr, NONE};                                   // r * B_1
-      jobs[nj++] = {&g1, plain(vl), zc, n, slot(1), 2, nullptr, nullptr, CONSUME};                           // l' (with -rs delta)
+      jobs[nj++] = {&g1, plain(vl), zc, n, slot(1), 2, nullptr, nullptr, (sparse_b && a_alone) ? NONE : CONSUME};   // l' (with -rs delta)
     } else {
       // (A sorts for itself when enough of its entries are infinite -- l' then does too: a sort is HBM and atomics and overlaps the other
       //  MSMs' multiply-adds, the accumulation it shortens does not; measured on the bench's 298-bit main proof: 17.2 -> 17.0 ms)
