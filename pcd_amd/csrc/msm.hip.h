@@ -620,11 +620,8 @@ struct MsmAccWaves {
 #ifndef PCD_ACC_WAVES_MB298
 #define PCD_ACC_WAVES_MB298 2
 #endif
-#ifndef PCD_ACC_WAVES_FQ2U
-#define PCD_ACC_WAVES_FQ2U 1   // (the unsplit Fq2-298 accumulation needs 359 registers: at two waves it spills ~120 words a lane)
-#endif
   static constexpr int value = !FA::Base::INLINE_ARITH ? (FA::Base::N <= 11 ? PCD_ACC_WAVES_MB298 : 1)
-                             : FA::DEG == 1 ? PCD_ACC_WAVES_G1 : AccOf<G>::LANES > 1 ? PCD_ACC_WAVES_SPLIT : PCD_ACC_WAVES_FQ2U;
+                             : FA::DEG == 1 ? PCD_ACC_WAVES_G1 : AccOf<G>::LANES > 1 ? PCD_ACC_WAVES_SPLIT : 1;
 };
 
 // COMPACT: the entries form one list (`sorted_idx`, the scalars equal to one possibly in their own list `ones_idx` behind it), so
