@@ -412,7 +412,7 @@ static int bases_upload_single(pcdhip_ctx* ctx, int curve_id, int group_id, cons
   // holds 2^(c Wg g) P_i.  Full precomputation (Wg = 1) needs W copies of the query vector.
   if (ctx->precompute != 0 && n >= 64) {
     const bool full = ctx->precompute < 0;
-    const int c = ctx->msm_c ? ctx->msm_c : msm_pick_window(n, ge.scalar_bits, full ? 1 : 0);
+    const int c = ctx->msm_c ? ctx->msm_c : std::max(6, msm_pick_window(n, ge.scalar_bits, full ? 1 : 0) + ctx->msm_c_bias);
     const int W = msm_num_windows(ge.scalar_bits, c);
     b->c = c;
     b->groups = full ? W : std::min(W, ctx->precompute);
@@ -1169,6 +1169,12 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
       return bases_upload_single(C, cid, q.group, q.pts.data() + lo * pl, q.inf.data() + lo, hi - lo, dst);
     };
     for (size_t i = lo; i < hi && i < m; i++) { pk->a_inf_count += qa.inf[i] != 0; pk->b_inf_count += qb2.inf[i] != 0; }
+    // Window bits of a key's queries: one less than the lone MSM's choice for large queries.  A proof runs six MSMs at once and is bound by
+    // the sum of their kernels' work; the bucket reductions and fix-ups (proportional to 2^c, a third of that sum at the lone optimum) count
+    // in full there, while the lone MSM hides part of them behind its own latency.  Same box, tools/ab_window_step.py: MNT4-298 main proof
+    // 17.5 -> 16.8 ms (c = 20 -> 19; 18: 18.2), MNT4-753 160.3 -> 153.0 ms (21 -> 20; 19: 155.8); flat at the help proofs' 2^16 (left alone).
+    struct BiasGuard { pcdhip_ctx* c; ~BiasGuard() { c->msm_c_bias = 0; } } bias_guard{C};
+    C->msm_c_bias = (hi - lo >= ((size_t)1 << 18)) ? -1 : 0;
     pk->b_inf_same = memcmp(qb1.inf.data() + lo, qb2.inf.data() + lo, hi - lo) == 0;
     int rc = up(qa, &pk->a_query);
     rc = rc ? rc : up(qb1, &pk->b_g1_query);

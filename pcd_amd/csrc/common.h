@@ -87,6 +87,9 @@ struct pcdhip_ctx {
   hipStream_t g16_streams[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   pcd::MsmWorkspace g16_ws[6];
   hipEvent_t g16_ready = nullptr, g16_begin[6] = {nullptr}, g16_end[6] = {nullptr};
+  // added to the window bits msm_pick_window chooses for vectors uploaded next (0 outside pcdhip_g16_pk_upload): the lone MSM's best
+  // window is one bit too wide inside a proof, whose time is the SUM of its kernels' work -- bucket reductions and fix-ups included
+  int msm_c_bias = 0;
   pcd::MsmSharedSort g16_share;  // the sort of the assignment's digits, made once per proof and used by four MSMs
   pcd::MsmSharedSort g16_share_b;  // ... and a second one without the entries of the B queries' points at infinity (b_g1 / b_g2 only)
   std::map<uint64_t, pcd::FftTables> fft_tables;
