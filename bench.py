@@ -681,7 +681,9 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None):
             #  B1 and B leave theirs out)
             m4 = int(keys.a_query.shape[0]) + 4
             fin_b = 1.0 - float(np.mean(keys.b_g2_inf))
-            work = int(((n - 1) + (2 + fin_b) * m4) * W * madd_mads(curve) + fin_b * m4 * W * g2_mads + 7 * 3 * n * 5 * 2 * 27 * 27)
+            # (the key's queries run one window bit narrower than the standalone plan measured above -- pcdhip_g16_pk_upload -- hence more windows)
+            Wk = -(-754 // (c_bits - 1)) if m4 >= (1 << 18) else W
+            work = int(((n - 1) + (2 + fin_b) * m4) * Wk * madd_mads(curve) + fin_b * m4 * Wk * g2_mads + 7 * 3 * n * 5 * 2 * 27 * 27)
             info["whole_step_int_frac"] = {"main_mnt4_753": round(work / (info[name]["gpu_wall_ms"] * 1e-3) / MAD_PEAK, 4),
                                            "executed_mads": work, "note": "accumulations + transforms only; everything else counted as zero work"}
         if pk is not None:
