@@ -1001,9 +1001,11 @@ int witness_chain_dev(pcdhip_ctx* ctx, int field_id, const DevCsr& mat, int k, c
   return chain_transforms(ctx, field_id, d, v, tmp);
 }
 // h = coset_ifft((a o b - c) / Z) from the three transformed chains in ctx's AUX_A, AUX_B, AUX_C; h ends up in AUX_A
-int witness_finish_dev(pcdhip_ctx* ctx, int field_id, const Dom& d) {
+int witness_finish_dev(pcdhip_ctx* ctx, int field_id, const Dom& d, const uint32_t* b_at = nullptr, const uint32_t* c_at = nullptr) {
   const FieldEntry& fe = field_entry(field_id);
-  uint32_t *a = (uint32_t*)ctx->aux_ws.buf[AUX_A], *b = (uint32_t*)ctx->aux_ws.buf[AUX_B], *c = (uint32_t*)ctx->aux_ws.buf[AUX_C];
+  uint32_t* a = (uint32_t*)ctx->aux_ws.buf[AUX_A];
+  const uint32_t* b = b_at ? b_at : (const uint32_t*)ctx->aux_ws.buf[AUX_B];
+  const uint32_t* c = c_at ? c_at : (const uint32_t*)ctx->aux_ws.buf[AUX_C];
   uint32_t* tmp = (uint32_t*)ctx->aux_ws.buf[AUX_FFT_TMP];
   int rc;
   const FftTables* t;
@@ -1025,13 +1027,36 @@ int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const u
   if (rc) return rc;
   const uint32_t n = d.n;
   const size_t vb = (size_t)n * fe.words * 4;
+  hipStream_t st = ctx->stream;
+  if (d.m == 1) {
+    // radix-2 domain: the three chains live back to back in AUX_A (a | b | c) and every pass of their transforms is ONE launch for all
+    // three (grid.y): 6 launches instead of 18 -- inside a proof every launch of the map queues behind the MSMs' resident accumulation
+    // waves, so the map's length is its launch count as much as its work
+    TRY(ctx->aux_ws.ensure(AUX_A, 3 * vb));
+    TRY(ctx->aux_ws.ensure(AUX_FFT_TMP, 3 * vb));
+    uint32_t* a = (uint32_t*)ctx->aux_ws.buf[AUX_A];
+    uint32_t* tmp = (uint32_t*)ctx->aux_ws.buf[AUX_FFT_TMP];
+    const size_t ew = (size_t)n * fe.words;
+    for (int k = 0; k < 3; k++) TRY(fe.spmv(st, mats[k], z_dev, (uint32_t)num_inputs, k == 0 ? 1 : 0, n, a + k * ew));
+    if (after_spmv) TRY(hipEventRecord(after_spmv, st));
+    const FftTables* t;
+    rc = get_tables(ctx, field_id, d.a, &t);
+    if (rc) return rc;
+    int P = 0;
+    TRY(fe.fft_run_batched(st, *t, a, tmp, d.a, 1 | 4, 0, &P, 3));                 // ifft, result left where the last pass wrote it
+    uint32_t *s2 = (P & 1) ? tmp : a, *t2 = (P & 1) ? a : tmp;
+    TRY(fe.fft_run_batched(st, *t, s2, t2, d.a, 0 | 4, 1, &P, 3));                 // coset fft from there: lands in a | b | c
+    rc = witness_finish_dev(ctx, field_id, d, a + ew, a + 2 * ew);
+    if (rc) return rc;
+    *dom_out = d;
+    return PCDHIP_OK;
+  }
   TRY(ctx->aux_ws.ensure(AUX_A, vb));
   TRY(ctx->aux_ws.ensure(AUX_B, vb));
   TRY(ctx->aux_ws.ensure(AUX_C, vb));
   TRY(ctx->aux_ws.ensure(AUX_FFT_TMP, vb));
   uint32_t *a = (uint32_t*)ctx->aux_ws.buf[AUX_A], *b = (uint32_t*)ctx->aux_ws.buf[AUX_B], *c = (uint32_t*)ctx->aux_ws.buf[AUX_C];
   uint32_t* tmp = (uint32_t*)ctx->aux_ws.buf[AUX_FFT_TMP];
-  hipStream_t st = ctx->stream;
   uint32_t* vecs[3] = {a, b, c};
   for (int k = 0; k < 3; k++)
     TRY(fe.spmv(st, mats[k], z_dev, (uint32_t)num_inputs, k == 0 ? 1 : 0, n, vecs[k]));

@@ -198,6 +198,9 @@ struct FieldEntry {
                               uint32_t ni, const uint32_t* at, const uint32_t* bt, const uint32_t* ct, uint32_t* u, uint32_t* consts_dev,
                               uint32_t* err_dev, uint32_t* a_can, uint32_t* b_can, uint32_t* t_can, uint32_t* h_can, uint32_t* b2_can,
                               int phase);
+  // fft_run over `batch` vectors laid back to back in x (and in tmp): one launch per pass for all of them (the three chains of a witness map)
+  hipError_t (*fft_run_batched)(hipStream_t, const FftTables& t, uint32_t* x, uint32_t* tmp, int log_n, int inverse, int coset, int* npasses,
+                                uint32_t batch);
 };
 const FieldEntry& field_entry(int field_id);
 

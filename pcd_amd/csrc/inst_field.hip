@@ -140,6 +140,10 @@ hipError_t run_batched(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t
 hipError_t run(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t* tmp, int log_n, int inverse, int coset, float* pass_ms, int* npasses) {
   return run_batched(st, t, x, tmp, log_n, inverse, coset, pass_ms, npasses, 1);
 }
+hipError_t run_batched_entry(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t* tmp, int log_n, int inverse, int coset, int* npasses,
+                             uint32_t batch) {
+  return run_batched(st, t, x, tmp, log_n, inverse, coset, nullptr, npasses, batch);
+}
 
 // ---- mixed-radix domain n = m * 2^a
 struct MixedConsts { FT wn, wn_inv, wm, wm_inv, ninv, zinv; };
@@ -434,7 +438,7 @@ hipError_t setup_scalars(hipStream_t st, const void* domain_consts, const uint32
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const FieldEntry* PCD_CAT(pcd_field_entry_, PCD_FIELD_IDX)() {
   static const FieldEntry e = {EW, FT::ABI_WORDS, FT::Params::TWO_ADICITY, make_tables, run, convert, spmv, small_abi, mul_sub_divz,
-                               mixed_make_tables, mixed_run, mixed_mul_sub_divz, scale_canon, SETUP_CONSTS, setup_scalars};
+                               mixed_make_tables, mixed_run, mixed_mul_sub_divz, scale_canon, SETUP_CONSTS, setup_scalars, run_batched_entry};
   return &e;
 }
 
