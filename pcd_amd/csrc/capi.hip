@@ -1037,7 +1037,7 @@ int witness_map_dev(pcdhip_ctx* ctx, int field_id, const DevCsr mats[3], const u
     uint32_t* a = (uint32_t*)ctx->aux_ws.buf[AUX_A];
     uint32_t* tmp = (uint32_t*)ctx->aux_ws.buf[AUX_FFT_TMP];
     const size_t ew = (size_t)n * fe.words;
-    for (int k = 0; k < 3; k++) TRY(fe.spmv(st, mats[k], z_dev, (uint32_t)num_inputs, k == 0 ? 1 : 0, n, a + k * ew));
+    TRY(fe.spmv3(st, mats, z_dev, (uint32_t)num_inputs, n, a, ew));
     if (after_spmv) TRY(hipEventRecord(after_spmv, st));
     const FftTables* t;
     rc = get_tables(ctx, field_id, d.a, &t);

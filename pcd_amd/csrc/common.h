@@ -201,6 +201,8 @@ struct FieldEntry {
   // fft_run over `batch` vectors laid back to back in x (and in tmp): one launch per pass for all of them (the three chains of a witness map)
   hipError_t (*fft_run_batched)(hipStream_t, const FftTables& t, uint32_t* x, uint32_t* tmp, int log_n, int inverse, int coset, int* npasses,
                                 uint32_t batch);
+  // the three mat-vecs of a witness map in one launch (two with long rows): out, out + stride, out + 2 stride; matrix 0 appends the inputs
+  hipError_t (*spmv3)(hipStream_t, const DevCsr mats[3], const uint32_t* z, uint32_t num_inputs, uint32_t n, uint32_t* out, size_t stride_words);
 };
 const FieldEntry& field_entry(int field_id);
 

@@ -277,10 +277,9 @@ struct SpmvLight {
     cnt = 0;
   }
 };
-// one lane per row (rows of up to SPMV_LONG_ROW entries; longer ones are left to spmv_long_kernel), the tail of the vector too
-__global__ void __launch_bounds__(256) spmv_kernel(const DevCsr m, const uint32_t* __restrict__ z, uint32_t num_inputs, int append_inputs,
-                                                   uint32_t n, uint32_t* __restrict__ out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// one lane per row (rows of up to SPMV_LONG_ROW entries; longer ones are left to the long-row kernel), the tail of the vector too
+PCD_DEV void spmv_row(const DevCsr& m, const uint32_t* __restrict__ z, uint32_t num_inputs, int append_inputs, uint32_t n, uint32_t* __restrict__ out,
+                      uint32_t i) {
   if (i >= n) return;
   FT acc = FT::zero();
   if (i < m.rows) {
@@ -297,8 +296,7 @@ __global__ void __launch_bounds__(256) spmv_kernel(const DevCsr m, const uint32_
   acc.store(out + (size_t)i * EW);
 }
 // one wave per long row: lanes stride over the entries, then a butterfly of field additions over the wave
-__global__ void __launch_bounds__(64) spmv_long_kernel(const DevCsr m, const uint32_t* __restrict__ z, uint32_t* __restrict__ out) {
-  const uint32_t w = blockIdx.x, lane = threadIdx.x;
+PCD_DEV void spmv_long_row(const DevCsr& m, const uint32_t* __restrict__ z, uint32_t* __restrict__ out, uint32_t w, uint32_t lane) {
   if (w >= m.n_long) return;
   const uint32_t i = m.long_rows[w];
   const uint64_t lo = m.rp[i], hi = m.rp[i + 1], mid = lo + m.nl[i];
@@ -315,9 +313,33 @@ __global__ void __launch_bounds__(64) spmv_long_kernel(const DevCsr m, const uin
   }
   if (lane == 0) acc.store(out + (size_t)i * EW);
 }
+__global__ void __launch_bounds__(256) spmv_kernel(const DevCsr m, const uint32_t* __restrict__ z, uint32_t num_inputs, int append_inputs,
+                                                   uint32_t n, uint32_t* __restrict__ out) {
+  spmv_row(m, z, num_inputs, append_inputs, n, out, blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(64) spmv_long_kernel(const DevCsr m, const uint32_t* __restrict__ z, uint32_t* __restrict__ out) {
+  spmv_long_row(m, z, out, blockIdx.x, threadIdx.x);
+}
+// the three mat-vecs of a witness map in one launch each (blockIdx.y = the matrix; outputs `stride` words apart; matrix 0 appends the inputs)
+struct DevCsr3 { DevCsr m[3]; };
+__global__ void __launch_bounds__(256) spmv3_kernel(const DevCsr3 mm, const uint32_t* __restrict__ z, uint32_t num_inputs, uint32_t n,
+                                                    uint32_t* __restrict__ out, size_t stride) {
+  spmv_row(mm.m[blockIdx.y], z, num_inputs, blockIdx.y == 0 ? 1 : 0, n, out + blockIdx.y * stride, blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(64) spmv3_long_kernel(const DevCsr3 mm, const uint32_t* __restrict__ z, uint32_t* __restrict__ out, size_t stride) {
+  spmv_long_row(mm.m[blockIdx.y], z, out + blockIdx.y * stride, blockIdx.x, threadIdx.x);
+}
 hipError_t spmv(hipStream_t st, const DevCsr& m, const uint32_t* z, uint32_t num_inputs, int append_inputs, uint32_t n, uint32_t* out) {
   hipLaunchKernelGGL(spmv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, m, z, num_inputs, append_inputs, n, out);
   if (m.n_long) hipLaunchKernelGGL(spmv_long_kernel, dim3(m.n_long), dim3(64), 0, st, m, z, out);
+  return hipGetLastError();
+}
+hipError_t spmv3(hipStream_t st, const DevCsr mats[3], const uint32_t* z, uint32_t num_inputs, uint32_t n, uint32_t* out, size_t stride_words) {
+  DevCsr3 mm;
+  uint32_t max_long = 0;
+  for (int k = 0; k < 3; k++) { mm.m[k] = mats[k]; max_long = std::max(max_long, mats[k].n_long); }
+  hipLaunchKernelGGL(spmv3_kernel, dim3((n + 255) / 256, 3), dim3(256), 0, st, mm, z, num_inputs, n, out, stride_words);
+  if (max_long) hipLaunchKernelGGL(spmv3_long_kernel, dim3(max_long, 3), dim3(64), 0, st, mm, z, out, stride_words);
   return hipGetLastError();
 }
 // host: the C-ABI image of a small integer (the field templates are __host__ __device__)
@@ -438,7 +460,7 @@ hipError_t setup_scalars(hipStream_t st, const void* domain_consts, const uint32
 #define PCD_CAT(a, b) PCD_CAT_(a, b)
 const FieldEntry* PCD_CAT(pcd_field_entry_, PCD_FIELD_IDX)() {
   static const FieldEntry e = {EW, FT::ABI_WORDS, FT::Params::TWO_ADICITY, make_tables, run, convert, spmv, small_abi, mul_sub_divz,
-                               mixed_make_tables, mixed_run, mixed_mul_sub_divz, scale_canon, SETUP_CONSTS, setup_scalars, run_batched_entry};
+                               mixed_make_tables, mixed_run, mixed_mul_sub_divz, scale_canon, SETUP_CONSTS, setup_scalars, run_batched_entry, spmv3};
   return &e;
 }
 
