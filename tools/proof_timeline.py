@@ -2,7 +2,8 @@
 per 0.5 ms slice, which kernels were running (by family) -- where the device idles or runs latency-bound work alone.
 
     rocprofv3 --kernel-trace --output-format csv -d /tmp/pt -- python3 tools/proof_timeline.py run
-    python3 tools/proof_timeline.py report /tmp/pt"""
+    [PT_SLICE_US=200] python3 tools/proof_timeline.py report /tmp/pt
+(PT_CURVE / PT_NC choose the proof; under the tracer every launch costs the host ~50 us, so small proofs come out launch-bound and stretched)"""
 import glob, os, sys, time, csv, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -16,7 +17,7 @@ def run():
     curve = int(os.environ.get("PT_CURVE", "0"))
     ctx = capi.Context(0)
     fr = co.CURVE_FR[curve]
-    r = co.skewed_r1cs(fr, (1 << 20) - 8, 2, seed=77)
+    r = co.skewed_r1cs(fr, int(os.environ.get("PT_NC", (1 << 20) - 8)), 2, seed=77)
     keys = co.synthetic_keys(curve, r, seed=78, mt=True)
     rs = co.gen_field(fr, 2, seed=79)
     pk = ctx.g16_pk_upload(keys.host_struct(), curve)
@@ -48,7 +49,7 @@ def report(d):
     last = rows[cut:]
     t0, t1 = last[0][0], max(b for _, b, _ in last)
     print(f"{len(last)} kernels over {(t1 - t0) / 1e6:.2f} ms")
-    step = 500_000
+    step = int(os.environ.get("PT_SLICE_US", "500")) * 1000
     for s in range(t0, t1, step):
         busy = collections.Counter()
         for a, b, n in last:
