@@ -85,3 +85,41 @@ def test_bounds_the_interpreter_relies_on(gen, envs):
                         assert len(terms) == 1 and (kind == gen.K_MUL or terms[0][0] == terms[0][1])
         # a product closes on [0, 2p) without a final subtraction while 4 p^2 / R' + p < 2p; a LIN reduces values below 2^12 p
         assert 4 * env.p < (1 << (28 * env.N)) and gen.TMAX == 1 and 2 * gen.LIN_WEIGHT < (1 << 12)
+
+
+def test_schedule_depth_and_flat_records(gen, envs):
+    """What the verification's latency rests on: a doubling and an addition step are three product levels
+    deep -- six steps -- on all four curves, no step holds more than 64 instruction slots, and the flat record list the device walks is the
+    script with its programs expanded: same steps in the same order, the bank flip on each program's last step, the table selections and
+    the inversion attached to the step they precede."""
+    import re
+    for env in envs:
+        for name in ("dbl", "add"):
+            steps = env.compiled[name]["steps"]
+            assert len(steps) == 6 and [k == gen.K_LIN for k, _ in steps] == [False, True] * 3, (env.name, name, len(steps))
+        for c in env.compiled.values():
+            for kind, instrs in c["steps"]:
+                assert sum(2 if (kind == gen.K_LIN and len(t) > 8) else 1 for _, t, _ in instrs) <= gen.LANES
+    text = gen.emit(envs)
+    for env in envs:
+        for setname in env.sets:
+            T = f"{env.name}_{setname}"
+            grab = lambda what: [tuple(int(x.strip().rstrip("u"), 0) for x in m.group(1).split(","))
+                                 for m in re.finditer(r"\{([^{}]+)\}", re.search(rf"{T}_{what}\[\d+\]\[\d\] = \{{(.*?)\}};", text, re.S).group(1))]
+            progs, steps, flat = grab("progs"), grab("steps"), grab("flat")
+            names = [n for n in env.sets[setname]]
+            want, pending = [], 0
+            for e in env.scripts[setname]:
+                if isinstance(e, tuple) and e[0] == "inv":
+                    pending |= 4
+                elif isinstance(e, tuple):
+                    pending = (pending & ~0xF2) | 2 | (e[1] << 4)
+                else:
+                    first, cnt, mask = progs[names.index(e)]
+                    for q in range(cnt):
+                        k, o, n = steps[first + q]
+                        fl = (pending if q == 0 else 0) | (1 if q == cnt - 1 else 0)
+                        want.append((k | (fl << 16), o, n, mask if q == cnt - 1 else 0))
+                    pending = 0
+            nscript = int(re.search(rf"{T}_flat_script_len = (\d+);", text).group(1))
+            assert nscript == len(want) and flat[:nscript] == want, T
