@@ -324,9 +324,28 @@ def synthetic_keys(curve, r, seed, mt=False, consistent=True):
              gamma_g2=np.ascontiguousarray(g2[m + 1]), gamma_abc_g1=np.ascontiguousarray(g1[:ni]), gamma_abc_inf=z8(ni),
              a_inf=z8(m), b_g1_inf=z8(m), b_g2_inf=z8(m), h_inf=z8(n - 1), l_inf=z8(m - ni))
     if consistent:
-        for mat, names in ((r.col_a, ("a_inf",)), (r.col_b, ("b_g1_inf", "b_g2_inf"))):
+        for (rp, mat, cf), names in (((r.rp_a, r.col_a, r.coeff_a), ("a_inf",)), ((r.rp_b, r.col_b, r.coeff_b), ("b_g1_inf", "b_g2_inf"))):
+            col = np.asarray(mat, dtype=np.int64)
+            live = np.asarray(cf).any(axis=1)                        # (an entry with coefficient zero mentions nothing)
+            # entries of one row on the same column add up: a pair c, -c (the generator makes some) leaves the variable out of the row
+            rows = np.repeat(np.arange(len(rp) - 1, dtype=np.int64), np.diff(np.asarray(rp).astype(np.int64)))
+            key = rows * m + col
+            order = np.argsort(key, kind="stable")
+            ks = key[order]
+            dup = np.flatnonzero(ks[1:] == ks[:-1])
+            if len(dup):
+                starts = np.flatnonzero(np.concatenate(([True], ks[1:] != ks[:-1])))
+                ends = np.concatenate((starts[1:], [len(ks)]))
+                big = np.flatnonzero(ends - starts > 1)
+                for s0, e0 in zip(starts[big], ends[big]):
+                    if True:
+                        idx = order[s0:e0]
+                        acc = np.ascontiguousarray(np.asarray(cf)[idx[:1]])
+                        for j in idx[1:]:
+                            acc = fp_op(r.field, "add", acc, np.ascontiguousarray(np.asarray(cf)[j:j + 1]))
+                        live[idx] = bool(acc.any())
             absent = np.ones(m, dtype=np.uint8)
-            absent[np.asarray(mat, dtype=np.int64)] = 0
+            absent[col[live]] = 0
             if names[0] == "a_inf":
                 absent[:ni] = 0   # (the input-consistency rows of the QAP put every public input into A)
             for nm in names:
