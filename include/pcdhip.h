@@ -157,6 +157,9 @@ int pcdhip_msm_set_accumulate(pcdhip_ctx* ctx, int mode, int chunk, int min_pair
  * [digits, scan, scatter, accumulate, fixup, tail, horner, total]; enable with on != 0. */
 int pcdhip_msm_profile(pcdhip_ctx* ctx, int on);
 int pcdhip_msm_last_timings(pcdhip_ctx* ctx, float out_ms[8]);
+/* ... and what the device planned for that MSM: out[0] = entries of the sorted (bucket, base) list -- n x windows less the zero digits, the
+ * scalars equal to zero or one and the bases at infinity --, out[1] = entries per lane of the accumulate kernel chosen for it. */
+int pcdhip_msm_last_plan(pcdhip_ctx* ctx, uint32_t out[2]);
 /* Sum of n Jacobian points (the multi-GPU combine step after the all-gather of partial results). */
 int pcdhip_points_sum(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xyz_mont, size_t n,
                       uint64_t* out_xyz_mont);
@@ -248,12 +251,24 @@ int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode);
  * device to device, the pointwise step and the last transform run on device 0 -- about 45 % of the map's time leaves the critical path of
  * device 0, which also carries its share of the MSMs.  0: everything on device 0.  The proof is the same either way. */
 int pcdhip_groth16_set_witness_split(pcdhip_ctx* ctx, int on);
-/* Order of the stages of pcdhip_groth16_prove.  0 (default): the four MSMs over the assignment first, the witness map concurrently with them,
- * the h MSM behind the map.  1: the witness map first with the device to itself, then all five MSMs at once -- built in round 4 on the
- * suspicion that the map (whose short dependent kernels wait behind the MSMs' one-wave-per-SIMD grids) serialised the h MSM at the end;
- * measured SLOWER on every configuration (the proof is bound by the sum of its MSMs' throughput), kept as an A/B knob.
- * The proof is the same either way. */
+/* Order of the stages of pcdhip_groth16_prove (what ark-groth16 `create_proof_with_reduction` does one after the other on rayon:
+ * witness_map, then the five `VariableBaseMSM::multi_scalar_mul`; reference call sites src/ec_cycle_pcd/mod.rs:171,179).
+ *   0 (default)  the four MSMs over the assignment first, each on its own stream, the witness map concurrently with them, the h MSM behind
+ *      the map.  Measured in round 5 (profiles/r05_acc_probe.txt, r05_pt_serial.txt): the proof takes the SUM of its kernels' standalone
+ *      times to within a few per cent -- every kernel is bound by the same multiply-add issue slots, so no order can beat that sum;
+ *   1  the witness map first with the device to itself, then all five MSMs at once (round 4's A/B knob; slower);
+ *   2  the accumulate LANE (round 5): the map first while the MSMs sort beside it, then the MSMs' accumulate kernels one
+ *      after the other on a stream confined by a CU mask to all but a few compute units (pcdhip_set_lane_reserve), each MSM's fix-up,
+ *      bucket reduction and assembly products on a hardware queue of its own under the next accumulation.  A chain of one-wave launches
+ *      no longer waits for accumulate workgroups to retire (0.98 ms instead of 20 .. 38 ms behind a device-filling grid,
+ *      profiles/r05_k3_cu_mask.txt), but a masked queue runs the accumulate kernels 15 .. 45 % slower than an unmasked one (one CU less
+ *      in one shader engine of every XCD unbalances the workgroup dispatch), and unmasked the lane is as fast as mode 0 at best:
+ *      main proof MNT4-298 2^20: 15.7 (mode 0) / 18.0 (lane, 8 CUs reserved) / 16.4 .. 18.4 ms (lane, no mask); MNT4-753: 152 / 164 / 156.
+ * The proof is the same in every mode.  Not while submitted MSMs are pending (PCDHIP_E_ARG). */
 int pcdhip_groth16_set_schedule(pcdhip_ctx* ctx, int mode);
+/* Compute units the accumulate lane leaves to the context's other streams (schedule 2; also pcdhip_msm_submit): a multiple of the number
+ * of XCDs (8) keeps the same count free in every XCD.  -1 (default): the environment's PCDHIP_LANE_RESERVE, else 8; 0: no mask. */
+int pcdhip_set_lane_reserve(pcdhip_ctx* ctx, int cus);
 
 /* ---- the caller side of the path -- key generation -------------------------------------
  * Replaces ark-ec `FixedBaseMSM::{get_window_table, multi_scalar_mul}` + `batch_normalization_into_affine`:

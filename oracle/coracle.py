@@ -230,9 +230,7 @@ def synthetic_r1cs(field, nc, num_inputs, seed):
     return R1CS(field, num_inputs, rp_ab, col_a, ca, rp_ab.copy(), col_b, cb, rp_c, col_c, cc, z)
 
 
-def skewed_r1cs(field, nc, num_inputs, seed):
-    """a satisfied constraint system with the shape of a finalised verifier circuit: power-law row lengths (two rows above 4096
-    entries when nc >= 8192), >= 80 % unit coefficients, ~12 % small integers, the rest random (oracle_capi.cpp orc_skewed_r1cs)"""
+def _generated_r1cs(fn, field, nc, num_inputs, seed):
     L = FIELD_N64[field]
     m = lib().orc_synthetic_r1cs_num_vars(C.c_size_t(nc), C.c_size_t(num_inputs))
     cap = 8 * nc + 16384
@@ -241,12 +239,26 @@ def skewed_r1cs(field, nc, num_inputs, seed):
     cf = [np.zeros((cap, L), dtype=np.uint64) for _ in range(3)]
     z = np.zeros((m, L), dtype=np.uint64)
     nnz = np.zeros(3, dtype=np.uint64)
-    rc = lib().orc_skewed_r1cs(field, C.c_size_t(nc), C.c_size_t(num_inputs), C.c_uint64(seed), C.c_size_t(cap), _p(rp[0]), _p(col[0]),
-                               _p(cf[0]), _p(rp[1]), _p(col[1]), _p(cf[1]), _p(rp[2]), _p(col[2]), _p(cf[2]), _p(z), _p(nnz))
+    rc = fn(field, C.c_size_t(nc), C.c_size_t(num_inputs), C.c_uint64(seed), C.c_size_t(cap), _p(rp[0]), _p(col[0]),
+            _p(cf[0]), _p(rp[1]), _p(col[1]), _p(cf[1]), _p(rp[2]), _p(col[2]), _p(cf[2]), _p(z), _p(nnz))
     assert rc == 0, rc
     tr = lambda k: (rp[k], np.ascontiguousarray(col[k][:int(nnz[k])]), np.ascontiguousarray(cf[k][:int(nnz[k])]))
     (ra, ca, fa), (rb, cb, fb), (rc_, cc, fc) = tr(0), tr(1), tr(2)
     return R1CS(field, num_inputs, ra, ca, fa, rb, cb, fb, rc_, cc, fc, z)
+
+
+def skewed_r1cs(field, nc, num_inputs, seed):
+    """a satisfied constraint system with the shape of a finalised verifier circuit: power-law row lengths (two rows above 4096
+    entries when nc >= 8192), >= 80 % unit coefficients, ~12 % small integers, the rest random (oracle_capi.cpp orc_skewed_r1cs);
+    the assignment is uniformly random field elements"""
+    return _generated_r1cs(lib().orc_skewed_r1cs, field, nc, num_inputs, seed)
+
+
+def witness_r1cs(field, nc, num_inputs, seed):
+    """a satisfied constraint system whose ASSIGNMENT looks like a verifier circuit's (data_structures.rs:269-304: bit decompositions):
+    runs of K bits with their booleanity rows, a packing row, a few product rows -- ~45 % of z is 0, ~35 % is 1, ~20 % neither
+    (oracle_capi.cpp orc_witness_r1cs)"""
+    return _generated_r1cs(lib().orc_witness_r1cs, field, nc, num_inputs, seed)
 
 
 def domain_size(field, min_size):

@@ -399,6 +399,87 @@ int orc_skewed_r1cs(int field, size_t nc, size_t num_inputs, u64 seed, size_t ca
   return 0;
 }
 
+// A constraint system whose ASSIGNMENT looks like a verifier circuit's (round 5).  What MainCircuit / HelpCircuit allocate
+// (/root/reference src/ec_cycle_pcd/data_structures.rs:269-304 -- one in-circuit Groth16 verification per prior message -- and :381-389)
+// is mostly BITS: the scalars of the in-circuit pairing, the non-native limbs' range checks, the hash input, each with its booleanity row
+// b (b - 1) = 0, packed into words by a linear row.  Blocks of: K bits (K in {8, 16, 64, 128, 253}; new variables, value 0 or 1 with
+// P(1) = 0.44; row A = [b], B = [b - 1], C = []), one packing row (A = sum 2^k b_k, B = [1], C = [x]: x a new variable, a K-bit number), then
+// ~0.22 K product rows (z[new] = <A,z><B,z>, short +-1 combinations with one general coefficient: values spread over the field).  About 45 % of z is 0, 35 % is 1, 20 %
+// neither -- SURVEY.md 8d's distribution "W" -- and the 0 / 1 entries are ADJACENT in runs of K, as in a real assignment.  Satisfied by
+// construction; same calling convention as orc_skewed_r1cs (num_vars = num_inputs + 4 + nc: every row makes one variable).
+int orc_witness_r1cs(int field, size_t nc, size_t num_inputs, u64 seed, size_t cap, u64* rp_a, uint32_t* col_a, u64* coeff_a, u64* rp_b,
+                     uint32_t* col_b, u64* coeff_b, u64* rp_c, uint32_t* col_c, u64* coeff_c, u64* z_out, u64* nnz_out) {
+  DISPATCH_FIELD(field, {
+    SplitMix g(seed);
+    F* z = reinterpret_cast<F*>(z_out);
+    F* cf[3] = {reinterpret_cast<F*>(coeff_a), reinterpret_cast<F*>(coeff_b), reinterpret_cast<F*>(coeff_c)};
+    uint32_t* cl[3] = {col_a, col_b, col_c};
+    u64* rp[3] = {rp_a, rp_b, rp_c};
+    size_t cnt[3] = {0, 0, 0};
+    size_t m = 0;
+    z[m++] = F::one();
+    u64 tmp[F::N];
+    for (size_t i = 1; i < num_inputs + 4; i++) { rand_canonical<F>(g, tmp); z[m++] = F::from_raw(tmp); }
+    const F one = F::one(), minus_one = F::zero() - F::one();
+    auto put = [&](int w, const F& c, uint32_t col) -> bool {
+      if (cnt[w] >= cap) return false;
+      cf[w][cnt[w]] = c; cl[w][cnt[w]] = col; cnt[w]++;
+      return true;
+    };
+    size_t j = 0;
+    auto open_row = [&]() { for (int w = 0; w < 3; w++) rp[w][j] = cnt[w]; };
+    static const size_t KS[5] = {8, 16, 64, 128, 253};
+    while (j < nc) {
+      size_t K = KS[g.next() % 5];
+      if (K + 1 > nc - j) K = nc - j > 1 ? nc - j - 1 : 0;
+      const size_t first_bit = m;
+      for (size_t k = 0; k < K; k++, j++) {   // booleanity: b (b - 1) = 0
+        open_row();
+        z[m] = (g.next() % 100 < 44) ? one : F::zero();
+        if (!put(0, one, (uint32_t)m) || !put(1, one, (uint32_t)m) || !put(1, minus_one, 0)) return -2;
+        m++;
+      }
+      if (j < nc) {   // packing: (sum 2^k b_k) * 1 = x
+        open_row();
+        F acc = F::zero(), pw = one;
+        for (size_t k = 0; k < K; k++) {
+          if (!put(0, pw, (uint32_t)(first_bit + k))) return -2;
+          acc = acc + pw * z[first_bit + k];
+          pw = pw + pw;
+        }
+        if (K == 0 && !put(0, one, 0)) return -2;
+        if (K == 0) acc = one;
+        if (!put(1, one, 0) || !put(2, one, (uint32_t)m)) return -2;
+        z[m++] = acc;
+        j++;
+      }
+      const size_t prods = (K * 22 + 99) / 100;
+      for (size_t t = 0; t < prods && j < nc; t++, j++) {   // products of short +-1 combinations: uniform values
+        open_row();
+        F val[2];
+        for (int w = 0; w < 2; w++) {
+          const size_t len = 1 + g.next() % (w == 0 ? 3 : 2);
+          F acc = F::zero();
+          for (size_t e = 0; e < len; e++) {
+            F c = (g.next() & 1) ? one : minus_one;
+            if (w == 0 && e == 0) { rand_canonical<F>(g, tmp); c = F::from_raw(tmp); }   // (one general coefficient: the product is spread over the field)
+            // (mostly the non-bit variables: the words, the inputs and earlier products; now and then anything)
+            uint32_t col = (uint32_t)(g.next() % m);
+            if (g.next() % 4 && col >= first_bit && col < first_bit + K) col = (uint32_t)(g.next() % first_bit);
+            if (!put(w, c, col)) return -2;
+            acc = acc + c * z[col];
+          }
+          val[w] = acc;
+        }
+        if (!put(2, one, (uint32_t)m)) return -2;
+        z[m++] = val[0] * val[1];
+      }
+    }
+    for (int w = 0; w < 3; w++) { rp[w][nc] = cnt[w]; nnz_out[w] = cnt[w]; }
+  });
+  return 0;
+}
+
 int orc_witness_map(int field, size_t nc, size_t num_inputs, const u64* rp_a, const uint32_t* col_a, const u64* coeff_a,
                     const u64* rp_b, const uint32_t* col_b, const u64* coeff_b, const u64* rp_c,
                     const uint32_t* col_c, const u64* coeff_c, const u64* z, int nthreads, u64* h_out) {

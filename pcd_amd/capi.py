@@ -45,9 +45,9 @@ EXPORTS = [
     "pcdhip_field_limbs", "pcdhip_curve_base_field", "pcdhip_curve_scalar_field", "pcdhip_point_limbs",
     "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
     "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config", "pcdhip_msm_submit", "pcdhip_msm_collect", "pcdhip_msm_submit_partial", "pcdhip_msm_ticket_wait", "pcdhip_bases_info", "pcdhip_stream_wait",
-    "pcdhip_set_precompute", "pcdhip_set_precompute_budget", "pcdhip_msm_set_sort", "pcdhip_msm_set_accumulate", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
+    "pcdhip_set_precompute", "pcdhip_set_precompute_budget", "pcdhip_msm_set_sort", "pcdhip_msm_set_accumulate", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_msm_last_plan", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
-    "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_g16_witness_map_resident", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_groth16_set_witness_split", "pcdhip_groth16_set_schedule", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
+    "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_g16_witness_map_resident", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_groth16_set_witness_split", "pcdhip_groth16_set_schedule", "pcdhip_set_lane_reserve", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
     "pcdhip_serialized_size", "pcdhip_serialize_points", "pcdhip_deserialize_points", "pcdhip_deserialize_points_unchecked", "pcdhip_proof_serialized_size", "pcdhip_proof_serialize",
     "pcdhip_proof_deserialize", "pcdhip_vk_serialized_size", "pcdhip_vk_serialize", "pcdhip_vk_deserialize",
     "pcdhip_process_vk", "pcdhip_pvk_free", "pcdhip_groth16_verify_prepared", "pcdhip_groth16_verify_batch_rlc",
@@ -229,6 +229,12 @@ class Context:
         self._check(lib().pcdhip_msm_last_timings(self._ctx, out))
         return dict(zip(["digits", "scan", "scatter", "accumulate", "fixup", "tail", "horner", "total"], list(out)))
 
+    def msm_last_plan(self):
+        """(entries of the sorted list, entries per lane the device chose) of the last profiled MSM"""
+        out = (C.c_uint32 * 2)()
+        self._check(lib().pcdhip_msm_last_plan(self._ctx, out))
+        return int(out[0]), int(out[1])
+
     def points_sum(self, curve, group, xyz):
         xyz = _u64(xyz).reshape(-1, 3 * point_limbs(curve, group) // 2)
         out = np.zeros(xyz.shape[1], dtype=np.uint64)
@@ -327,8 +333,13 @@ class Context:
         self._check(lib().pcdhip_groth16_set_assembly(self._ctx, int(mode)))
 
     def groth16_set_schedule(self, mode):
-        """0 (default): the assignment MSMs first, the witness map under them; 1: the witness map first, then all five MSMs (measured slower)"""
+        """0 (default): the assignment MSMs first, the witness map under them; 1: the witness map first, then all five MSMs at once;
+        2: the witness map first, then the accumulate lane (round 5; measured slower, see include/pcdhip.h)"""
         self._check(lib().pcdhip_groth16_set_schedule(self._ctx, int(mode)))
+
+    def set_lane_reserve(self, cus):
+        """compute units the accumulate lane leaves to the other streams (-1: default 8 / PCDHIP_LANE_RESERVE; 0: no CU mask)"""
+        self._check(lib().pcdhip_set_lane_reserve(self._ctx, int(cus)))
 
     def groth16_set_witness_split(self, on):
         """multi-device contexts of >= 3 devices: the witness map's a / b / c chains on devices 0 / 1 / 2 (default) or all on device 0"""

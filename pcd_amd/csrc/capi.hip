@@ -278,6 +278,7 @@ void pcdhip_destroy(pcdhip_ctx* ctx) {
     if (ctx->g16_begin[k]) (void)hipEventDestroy(ctx->g16_begin[k]);
     if (ctx->g16_end[k]) (void)hipEventDestroy(ctx->g16_end[k]);
   }
+  if (ctx->lane_stream) (void)hipStreamDestroy(ctx->lane_stream);
   if (ctx->g16_ready) (void)hipEventDestroy(ctx->g16_ready);
   if (ctx->g16_share.ready) (void)hipEventDestroy(ctx->g16_share.ready);
   if (ctx->g16_share_b.ready) (void)hipEventDestroy(ctx->g16_share_b.ready);
@@ -515,10 +516,30 @@ int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode) {
   ctx->g16_assembly = mode;
   return PCDHIP_OK;
 }
+static int drop_side_streams(pcdhip_ctx* ctx);
+static bool pipe_pending(const pcdhip_ctx* ctx);
 int pcdhip_groth16_set_schedule(pcdhip_ctx* ctx, int mode) {
-  if (!ctx || mode < 0 || mode > 1) return PCDHIP_E_ARG;
-  ctx->g16_schedule = mode;
-  for (pcdhip_ctx* p : ctx->peers) if (p != ctx) p->g16_schedule = mode;
+  if (!ctx || mode < 0 || mode > 2) return PCDHIP_E_ARG;
+  if (pipe_pending(ctx)) return PCDHIP_E_ARG;
+  std::vector<pcdhip_ctx*> all = ctx->peers.empty() ? std::vector<pcdhip_ctx*>{ctx} : ctx->peers;
+  for (pcdhip_ctx* p : all) {
+    if (p->g16_schedule == mode) continue;
+    p->g16_schedule = mode;
+    int rc = drop_side_streams(p);  // (their priorities depend on the schedule)
+    if (rc) return rc;
+  }
+  return PCDHIP_OK;
+}
+int pcdhip_set_lane_reserve(pcdhip_ctx* ctx, int cus) {
+  if (!ctx || cus < -1 || cus > 128) return PCDHIP_E_ARG;
+  if (pipe_pending(ctx)) return PCDHIP_E_ARG;
+  std::vector<pcdhip_ctx*> all = ctx->peers.empty() ? std::vector<pcdhip_ctx*>{ctx} : ctx->peers;
+  for (pcdhip_ctx* p : all) {
+    if (p->lane_reserve == cus) continue;
+    p->lane_reserve = cus;
+    int rc = drop_side_streams(p);
+    if (rc) return rc;
+  }
   return PCDHIP_OK;
 }
 int pcdhip_groth16_set_witness_split(pcdhip_ctx* ctx, int on) {
@@ -529,6 +550,11 @@ int pcdhip_groth16_set_witness_split(pcdhip_ctx* ctx, int on) {
 int pcdhip_msm_profile(pcdhip_ctx* ctx, int on) {
   if (!ctx) return PCDHIP_E_ARG;
   ctx->msm_profile = on != 0;
+  return PCDHIP_OK;
+}
+int pcdhip_msm_last_plan(pcdhip_ctx* ctx, uint32_t out[2]) {
+  if (!ctx || !out) return PCDHIP_E_ARG;
+  out[0] = ctx->msm_tm.entries; out[1] = ctx->msm_tm.chunk;
   return PCDHIP_OK;
 }
 int pcdhip_msm_last_timings(pcdhip_ctx* ctx, float out_ms[8]) {
@@ -558,16 +584,65 @@ static int msm_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset,
 }
 
 // the context's side streams (created on first use): 0 and 1 with the highest priority, 2 with the default one, 3..5 with the lowest
+// ... and the accumulate lane: a stream whose queue may use all but `lane_reserve` compute units.  The mask bits are dealt to the XCDs
+// round-robin (bit i -> XCD i mod 8: tools/microbench/k3_cu_mask.hip, profiles/r05_k3_cu_mask.txt), so clearing the LAST 8 k bits leaves
+// k CUs free in every XCD -- an unmasked kernel's workgroups are dealt to the XCDs round-robin as well, so each needs a free CU of its own.
+static int lane_reserve_of(const pcdhip_ctx* ctx) {
+  int r = ctx->lane_reserve;
+  if (r < 0) { const char* e = getenv("PCDHIP_LANE_RESERVE"); r = e ? atoi(e) : 8; }
+  return r < 0 ? 0 : r;
+}
 static int ensure_side_streams(pcdhip_ctx* ctx) {
   if (ctx->g16_ready) return PCDHIP_OK;
-  TRY(hipEventCreateWithFlags(&ctx->g16_ready, hipEventDisableTiming));
   int least = 0, greatest = 0;
   TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  const bool lane_mode = ctx->g16_schedule == 2;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
   for (int k = 0; k < 6; k++) {
-    TRY(hipStreamCreateWithPriority(&ctx->g16_streams[k], hipStreamNonBlocking, k < 2 ? greatest : k == 2 ? (least + greatest) / 2 : least));
+    // The runtime multiplexes the streams of ONE priority over a few hardware queues (three for the high priority on this stack), and two
+    // streams that share a queue run in submission order: with four high-priority streams the sort of l' sat in the queue of the B MSM, behind
+    // that MSM's wait for its accumulation -- l' and h started 3 ms late (profiles/r05_pt_lane_aliased.txt: q5 carries s4 AND s5).  A stream
+    // created with a CU mask always gets a hardware queue of its own, so in lane mode the side streams are "masked" with every bit set; the
+    // older schedules keep round 4's priorities (2 high, 1 normal, 3 low).
+    if (lane_mode) {
+      std::vector<uint32_t> all((cus + 31) / 32, 0u);
+      for (int i = 0; i < cus; i++) all[i / 32] |= 1u << (i % 32);
+      TRY(hipExtStreamCreateWithCUMask(&ctx->g16_streams[k], (uint32_t)all.size(), all.data()));
+    } else {
+      TRY(hipStreamCreateWithPriority(&ctx->g16_streams[k], hipStreamNonBlocking, k < 2 ? greatest : k == 2 ? (least + greatest) / 2 : least));
+    }
     TRY(hipEventCreate(&ctx->g16_begin[k]));
     TRY(hipEventCreate(&ctx->g16_end[k]));
   }
+  int reserve = lane_reserve_of(ctx);
+  if (reserve >= cus) reserve = 0;
+  if (reserve > 0) {
+    std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+    for (int i = 0; i < cus - reserve; i++) mask[i / 32] |= 1u << (i % 32);
+    TRY(hipExtStreamCreateWithCUMask(&ctx->lane_stream, (uint32_t)mask.size(), mask.data()));
+  } else {
+    TRY(hipStreamCreateWithPriority(&ctx->lane_stream, hipStreamNonBlocking, least));
+  }
+  ctx->lane.stream = ctx->lane_stream;
+  ctx->lane.cus = cus - reserve;
+  TRY(hipEventCreateWithFlags(&ctx->g16_ready, hipEventDisableTiming));
+  return PCDHIP_OK;
+}
+// (a change of schedule or of the lane's reserve takes effect on streams made afresh)
+static int drop_side_streams(pcdhip_ctx* ctx) {
+  if (!ctx->g16_ready) return PCDHIP_OK;
+  BIND();
+  TRY(hipDeviceSynchronize());
+  for (int k = 0; k < 6; k++) {
+    if (ctx->g16_streams[k]) { (void)hipStreamDestroy(ctx->g16_streams[k]); ctx->g16_streams[k] = nullptr; }
+    if (ctx->g16_begin[k]) { (void)hipEventDestroy(ctx->g16_begin[k]); ctx->g16_begin[k] = nullptr; }
+    if (ctx->g16_end[k]) { (void)hipEventDestroy(ctx->g16_end[k]); ctx->g16_end[k] = nullptr; }
+  }
+  if (ctx->lane_stream) { (void)hipStreamDestroy(ctx->lane_stream); ctx->lane_stream = nullptr; }
+  ctx->lane = MsmLane();
+  (void)hipEventDestroy(ctx->g16_ready);
+  ctx->g16_ready = nullptr;
   return PCDHIP_OK;
 }
 static bool pipe_pending(const pcdhip_ctx* ctx) {
@@ -612,8 +687,12 @@ static int msm_submit_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t 
   TRY(hipEventRecord(ctx->g16_ready, ctx->stream));
   TRY(hipStreamWaitEvent(sk, ctx->g16_ready, 0));
   const size_t sw = (size_t)kFieldLimbs[scalars->field_id] * 2;
-  TRY(ge.msm(ws, sk, bases->view(offset), scalars->dptr + scalar_offset * sw, (uint32_t)n, out_dev, ctx->msm_c, ctx->msm_chunk, ctx->msm_sort, nullptr,
-             nullptr, MSM_SHARE_NONE));
+  // (the accumulations of the MSMs in flight run one after the other on the lane; sorts and bucket reductions beside them)
+  ws.lane = ctx->g16_schedule == 2 && ctx->pipe_lane && ctx->lane.stream ? &ctx->lane : nullptr;
+  const hipError_t me = ge.msm(ws, sk, bases->view(offset), scalars->dptr + scalar_offset * sw, (uint32_t)n, out_dev, ctx->msm_c, ctx->msm_chunk, ctx->msm_sort,
+                               nullptr, nullptr, MSM_SHARE_NONE);
+  ws.lane = nullptr;
+  TRY(me);
   TRY(ge.jac_out(sk, out_dev, 1, out_abi));
   uint64_t* host = ctx->pipe_host + (size_t)slot * pcdhip_ctx::PIPE_HOST_WORDS;
   host[pcdhip_ctx::PIPE_HOST_WORDS - 1] = 0;
@@ -1287,6 +1366,7 @@ struct G16Run {
   static constexpr int SHARE_B = 4;   // Job::share = role (MSM_SHARE_*) | SHARE_B: the sort shared by the two B MSMs (g16_share_b)
   Job jobs[6];
   int nj = 0;
+  bool use_lane = false;      // the jobs' accumulate kernels run one after the other on the context's lane (pcdhip_groth16_set_schedule 2)
   uint32_t* slot(int i) const { return (uint32_t*)((char*)msm_g1 + (size_t)i * j1); }
   size_t partial_bytes() const { return 6 * j1 + j2; }  // msm_g1 (six slots) and msm_g2 are contiguous
 
@@ -1322,12 +1402,12 @@ struct G16Run {
     j1 = (size_t)g1.point_words / 2 * 3 * 4;
     j2 = (size_t)g2.point_words / 2 * 3 * 4;
     const CurveEntry& ce = curve_entry(cid);
-    TRY(ctx->aux_ws.ensure(AUX_G16, 6 * j1 + j2 + 2 * 16 * j1 + ce.proof_abi_bytes + 256));
+    TRY(ctx->aux_ws.ensure(AUX_G16, 6 * j1 + j2 + 6 * 320 * j1 + ce.proof_abi_bytes + 256));  // (320 Jacobian slots per one-point product: inst_g16.hip)
     char* gbase = (char*)ctx->aux_ws.buf[AUX_G16];
     msm_g1 = (uint32_t*)gbase;  // h, l', A, s*A, r*B_1, B_1
     msm_g2 = (uint32_t*)(gbase + 6 * j1);
     mul_scratch = (uint32_t*)(gbase + 6 * j1 + j2);
-    proof_dev = (uint32_t*)(gbase + 6 * j1 + j2 + 2 * 16 * j1);
+    proof_dev = (uint32_t*)(gbase + 6 * j1 + j2 + 6 * 320 * j1);
     t1 = z_can + m * sw;  // [r, s, -rs, 1] canonical
     TRY(ce.prepare_scalars(st, rs_dev, t1, sz_can + m * sw, rz_can + m * sw));
     { int rc = ensure_side_streams(ctx); if (rc) return rc; }
@@ -1338,6 +1418,7 @@ struct G16Run {
     ctx->g16_share.valid = false;
     ctx->g16_share_b.valid = false;
     nj = 0;
+    use_lane = ctx->g16_schedule == 2 && ctx->lane.stream;
     return PCDHIP_OK;
   }
   int launch(int k, hipEvent_t after) {
@@ -1346,10 +1427,16 @@ struct G16Run {
     hipStream_t sk = ctx->g16_streams[k];
     TRY(hipStreamWaitEvent(sk, after, 0));
     TRY(hipEventRecord(ctx->g16_begin[k], sk));
-    TRY(jobs[k].ge->msm(ctx->g16_ws[k], sk, jobs[k].bv, jobs[k].sc, jobs[k].n, jobs[k].out, ctx->msm_c, ctx->msm_chunk, ctx->msm_sort, nullptr,
-                        (jobs[k].share & 3) ? ((jobs[k].share & SHARE_B) ? &ctx->g16_share_b : &ctx->g16_share) : nullptr, jobs[k].share & 3));
-    if (jobs[k].k) TRY(ce.scale_g1(sk, jobs[k].out, jobs[k].k, mul_scratch + (size_t)k * 16 * (j1 / 4), jobs[k].kout));
+    // (schedule 2: the accumulation goes to the lane, in the order the jobs are launched)
+    ctx->g16_ws[k].lane = use_lane ? &ctx->lane : nullptr;
+    const hipError_t me = jobs[k].ge->msm(ctx->g16_ws[k], sk, jobs[k].bv, jobs[k].sc, jobs[k].n, jobs[k].out, ctx->msm_c, ctx->msm_chunk, ctx->msm_sort, nullptr,
+                        (jobs[k].share & 3) ? ((jobs[k].share & SHARE_B) ? &ctx->g16_share_b : &ctx->g16_share) : nullptr, jobs[k].share & 3);
+    ctx->g16_ws[k].lane = nullptr;
+    TRY(me);
+    if (jobs[k].k) TRY(ce.scale_g1(sk, jobs[k].out, jobs[k].k, mul_scratch + (size_t)k * 320 * (j1 / 4), jobs[k].kout));
     TRY(hipEventRecord(ctx->g16_end[k], sk));
+    static const bool serial = getenv("PCDHIP_G16_SERIAL") != nullptr;  // developer knob: every MSM of a proof with the device to itself (kernel traces)
+    if (serial) TRY(hipDeviceSynchronize());
     return PCDHIP_OK;
   }
   // The MSMs that take the assignment (l', A, B_1 on G1; B on G2) over the entries [lo, lo + cnt) of z || t, which are the
@@ -1407,6 +1494,13 @@ struct G16Run {
     }
     for (int k = 0; k < nj; k++) { int rc = launch(k, after ? after : ctx->g16_ready); if (rc) return rc; }
     return PCDHIP_OK;
+  }
+  // ... behind `gate`: with the lane only the accumulations wait for it (the sorts start at once), otherwise the MSMs as a whole
+  int launch_assignment_gated(size_t lo, size_t cnt, bool folded, hipEvent_t gate) {
+    if (!use_lane) return launch_assignment(lo, cnt, folded, gate);
+    BIND();
+    TRY(hipStreamWaitEvent(ctx->lane.stream, gate, 0));
+    return launch_assignment(lo, cnt, folded);
   }
   // the h MSM over the entries [hlo, hlo + cnt) of h (entries [0, cnt) of this device's h query), once `after` has fired
   int launch_h(size_t hlo, size_t cnt, hipEvent_t after) {
@@ -1476,7 +1570,7 @@ int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_cs
                       pk->shards[1]->rows == rows && pk->shards[2]->rows == rows;
   // (pcdhip_groth16_set_schedule 1, off by default: measured slower) a device that carries a chain of the witness map starts its MSMs only
   // when that chain is through
-  const bool map_first = ctx->g16_schedule == 1;
+  const bool map_first = ctx->g16_schedule >= 1;  // (2: only the accumulate lane of such a device waits for its chain)
   auto carries_chain = [&](size_t g) { return g == 0 || (split3 && g <= 2); };
   std::vector<G16Run> runs(G);
   for (size_t g = 0; g < G; g++) {
@@ -1508,7 +1602,7 @@ int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_cs
       TRY(hipMemcpyPeerAsync(ctx->aux_ws.buf[g == 1 ? AUX_B : AUX_C], ctx->device, Cg->aux_ws.buf[AUX_A], Cg->device, vb, Cg->stream));
       if (!Cg->wm_ev) TRY(hipEventCreateWithFlags(&Cg->wm_ev, hipEventDisableTiming));
       TRY(hipEventRecord(Cg->wm_ev, Cg->stream));
-      if (map_first) { rc = runs[g].launch_assignment(pk->lo[g], pk->lo[g + 1] - pk->lo[g], true, Cg->wm_ev); if (rc) return rc; }
+      if (map_first) { rc = runs[g].launch_assignment_gated(pk->lo[g], pk->lo[g + 1] - pk->lo[g], true, Cg->wm_ev); if (rc) return rc; }
     }
     BIND();
     rc = witness_chain_dev(ctx, fr, mats[0], 0, runs[0].z_dev, ni, dom, AUX_A);
@@ -1524,7 +1618,7 @@ int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_cs
   }
   TRY(fe.convert(ctx->stream, (const uint32_t*)ctx->aux_ws.buf[AUX_A], runs[0].h_can, (uint32_t)n, 2));
   TRY(hipEventRecord(ev[1], ctx->stream));
-  if (map_first) { rc = runs[0].launch_assignment(pk->lo[0], pk->lo[1] - pk->lo[0], true, ev[1]); if (rc) return rc; BIND(); }
+  if (map_first) { rc = runs[0].launch_assignment_gated(pk->lo[0], pk->lo[1] - pk->lo[0], true, ev[1]); if (rc) return rc; BIND(); }
   const size_t sw = runs[0].sw, sb = runs[0].sb;
   for (size_t g = 0; g < G; g++) {
     const size_t hlo = std::min(pk->hlo[g], hl), hhi = std::min(pk->hlo[g + 1], hl);
@@ -1620,7 +1714,15 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   // first with the device to itself, then all five MSMs at once.  Measured on one box (tools/ab_step.py, profiles/r04_ab_prove_schedule.txt):
   // mode 1 is SLOWER -- 23.4 against 20.3 ms (MNT4-298, 2^20), 5.9 against 4.9 ms (MNT6-298, 2^16), 202 against 196.5 ms (MNT4-753, 2^20): the
   // proof is bound by the sum of its MSMs' throughput either way, and mode 1 adds the map's time in front while mode 0 hides it.
-  const bool map_first = ctx->g16_schedule == 1;
+  //   Round 5, mode 2: the accumulate LANE.  The map first while the MSMs sort beside it, then the accumulate kernels one after
+  // the other on a stream whose CU mask leaves a CU per XCD to everything else, each MSM's fix-up / bucket reduction / one-point product on a
+  // hardware queue of its own.  What the measurements say (profiles/r05_*): the accumulate kernels of this proof take 1.29 + 1.08 + 1.66 +
+  // 1.67 ms (G1: A, B_1, l', h) + ~3.7 ms (G2) ALONE, the sorts 1.7, fix-ups 1.0, first reduction levels 1.1, the map 1.5, upload and
+  // conversions 1.1 -- 15 .. 16 ms of work that all wants the same multiply-add issue slots, and mode 0 takes 15.7 .. 16.0 ms: the concurrency
+  // round 4's timeline made look destructive is within a few per cent of the sum of the parts.  The lane cannot beat that sum, and pays for
+  // the mask (a masked queue runs an accumulate kernel 15 .. 45 % slower: one CU less in ONE shader engine per XCD unbalances the dispatch) or,
+  // unmasked, for its own serialisation (18.0 / 16.4 .. 18.4 ms).  Mode 0 stays the default; what round 5 gained came from doing less work.
+  const bool map_first = ctx->g16_schedule >= 1;
   if (!map_first) { rc = run.launch_assignment(0, m + 4, folded); if (rc) return rc; }
   // ---- K1: h, on the context's stream
   DevCsr mats[3];
@@ -1632,7 +1734,7 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   if (dom_used.n != dom.n) return PCDHIP_E_ARG;
   TRY(fe.convert(st, (const uint32_t*)ctx->aux_ws.buf[AUX_A], run.h_can, (uint32_t)n, 2));
   TRY(hipEventRecord(ev[1], st));
-  if (map_first) { rc = run.launch_assignment(0, m + 4, folded, ev[1]); if (rc) return rc; }
+  if (map_first) { rc = run.launch_assignment_gated(0, m + 4, folded, ev[1]); if (rc) return rc; }  // (lane: no accumulation under the map; the sorts start at once)
   rc = run.launch_h(0, std::min<size_t>(pk->h_query->n, n), ev[1]);
   if (rc) return rc;
   rc = run.join();

@@ -67,18 +67,62 @@ __global__ void __launch_bounds__(64) g16_finish(const uint32_t* __restrict__ ms
   }
 }
 
-// out = k * in (k: canonical words, one lane; 4-bit window, table in `scratch`: 15 Jacobian slots)
-__global__ void __launch_bounds__(64) g16_scale_point(const uint32_t* __restrict__ in, const uint32_t* __restrict__ k,
-                                                      uint32_t* __restrict__ scratch, uint32_t* __restrict__ out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  typedef EC<GA> E1;
-  Jac<F1> table[15];
-  (void)scratch;
-  E1::mul_w4(Jac<F1>::load(in), k, SWA, table).store(out);
+// out = k * in (k: canonical words).  Round 4's form was ONE lane (4-bit window: ~300 / 750 doublings and ~75 / 190 additions of 9 .. 16
+// dependent products each: 4.6 ms over the 298-bit fields, ~60 ms over the 753-bit ones -- the longest kernel of a proof, harmless only
+// while it hid under three other accumulations).  Now one workgroup of four waves:
+//   1. lanes 0 / 1 run the doubling chain with two lanes per doubling (EC2::dbl2: 5 product slots instead of 9 products) and leave
+//      T_j = 16^j P behind for every 4-bit window j;
+//   2. every lane PAIR takes windows j, j + 128, ..: d_j T_j by double-and-add over the digit's four bits (the pairs of a wave run in
+//      lockstep, so a pair pays the four doublings and four additions whatever its digit), summed per pair;
+//   3. a tree over the 128 pairs through `scratch`.
+// The doublings that remain are the chain itself (bits of the scalar field many); everything else is ~20 group operations deep.
+// scratch: SCALE_SLOTS Jacobian slots (window table, then one partial per pair).
+constexpr int SCALE_W = 4, SCALE_NW = (GA::FR::BITS + SCALE_W - 1) / SCALE_W, SCALE_PAIRS = 128, SCALE_SLOTS = SCALE_NW + SCALE_PAIRS;
+static_assert(SCALE_SLOTS <= 320, "G16Run::prepare reserves 320 Jacobian slots per product");
+__global__ void __launch_bounds__(2 * SCALE_PAIRS) g16_scale_point(const uint32_t* __restrict__ in, const uint32_t* __restrict__ k,
+                                                                  uint32_t* __restrict__ scratch, uint32_t* __restrict__ out) {
+  if (blockIdx.x != 0) return;
+  typedef EC2<GA> E2;
+  typedef Jac<F1> J;
+  const uint32_t pair = threadIdx.x >> 1;
+  const bool writer = (threadIdx.x & 1u) == 0;
+  uint32_t* table = scratch;
+  uint32_t* partial = scratch + (size_t)SCALE_NW * J1;
+  if (pair == 0) {
+    J t = J::load(in);
+    for (int j = 0; j < SCALE_NW; j++) {
+      if (writer) t.store(table + (size_t)j * J1);
+      if (j + 1 < SCALE_NW)
+        for (int d = 0; d < SCALE_W; d++) t = E2::dbl2(t);
+    }
+  }
+  __syncthreads();
+  J acc = J::infinity();
+  for (uint32_t j = pair; j < (uint32_t)SCALE_NW; j += SCALE_PAIRS) {
+    const uint32_t bit0 = j * SCALE_W;
+    const uint32_t dgt = bit0 / 32 < (uint32_t)SWA ? (k[bit0 / 32] >> (bit0 % 32)) & 15u : 0u;  // (4 divides 32: a digit never straddles words)
+    const J t = J::load(table + (size_t)j * J1);
+    J r = J::infinity();
+    for (int b = SCALE_W - 1; b >= 0; b--) {
+      r = E2::dbl2(r);
+      if ((dgt >> b) & 1u) r = E2::add2(r, t);
+    }
+    acc = E2::add2(acc, r);
+  }
+  if (writer) acc.store(partial + (size_t)pair * J1);
+  __syncthreads();
+  for (uint32_t s = SCALE_PAIRS / 2; s > 0; s >>= 1) {
+    if (pair < s) {
+      acc = E2::add2(acc, J::load(partial + (size_t)(pair + s) * J1));
+      if (writer) acc.store(partial + (size_t)pair * J1);
+    }
+    __syncthreads();
+  }
+  if (pair == 0 && writer) acc.store(out);
 }
 
 hipError_t scale_g1(hipStream_t st, const uint32_t* in, const uint32_t* k, uint32_t* scratch, uint32_t* out) {
-  hipLaunchKernelGGL(g16_scale_point, dim3(1), dim3(64), 0, st, in, k, scratch, out);
+  hipLaunchKernelGGL(g16_scale_point, dim3(1), dim3(2 * SCALE_PAIRS), 0, st, in, k, scratch, out);
   return hipGetLastError();
 }
 hipError_t prepare_scalars(hipStream_t st, const uint32_t* rs_dev, uint32_t* t1, uint32_t* ts, uint32_t* tr) {

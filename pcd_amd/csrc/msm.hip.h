@@ -402,6 +402,21 @@ static __global__ void __launch_bounds__(1024) scan_apply(const uint32_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
+// Entries per lane of msm_accumulate_kernel, chosen ON THE DEVICE from the actual list length M = off[nkeys] (round 5).  The host only knows
+// the largest possible list (n W entries); the real one is shorter by the zero digits, the scalars equal to zero or one (a witness: 80 % of
+// them) and the points at infinity of a key (28 .. 41 % of a real a / b query), and a grid planned for n W entries then runs a last round
+// that is nearly empty (A of the bench's proof: 2.07 rounds of work took three) or, for a short list, gives a quarter of the lanes 40
+// entries each while the others idle (2^16 pairs: 10 entries per lane on average).  `lanes` = chunks the device runs at a time; the list
+// is spread over whole rounds of them, `lo` <= chunk <= `hi`.
+static __global__ void msm_plan_chunk_kernel(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t lanes, uint32_t lo, uint32_t hi,
+                                             uint32_t* __restrict__ chunk_out) {
+  if (blockIdx.x || threadIdx.x) return;
+  const uint64_t M = off[nkeys];
+  const uint64_t rounds = (M + (uint64_t)lanes * hi - 1) / ((uint64_t)lanes * hi);
+  uint32_t chunk = rounds ? (uint32_t)((M + lanes * rounds - 1) / (lanes * rounds)) : lo;
+  *chunk_out = min(max(chunk, lo), hi);
+}
+
 // key of sorted position p: largest key with off[key] <= p (skipping empty buckets)
 PCD_DEV uint32_t msm_find_key(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t p) {
   uint32_t lo = 0, hi = nkeys;  // invariant off[lo] <= p < off[hi]
@@ -631,7 +646,9 @@ template <class G, bool COMPACT>
 __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kernel(const uint32_t* __restrict__ bases, const MsmEntrySource src,
                                                             const uint32_t* __restrict__ off, uint32_t nkeys,
                                                             uint32_t chunk, uint32_t* __restrict__ buckets,
-                                                            uint32_t* __restrict__ piece_first, uint32_t* __restrict__ piece_last) {
+                                                            uint32_t* __restrict__ piece_first, uint32_t* __restrict__ piece_last,
+                                                            const uint32_t* __restrict__ chunk_dev /* msm_plan_chunk_kernel's choice */) {
+  if (chunk_dev) chunk = *chunk_dev;
   // GA: the configuration the arithmetic runs in -- G itself, or its lane-split form (Fq2 over lane pairs, Fq3 over lane triples:
   // the lanes of a group share one chunk, each holding one coefficient of every coordinate; memory images are the same)
   typedef typename AccOf<G>::type GA;
@@ -1423,10 +1440,26 @@ hipError_t msm_precompute(hipStream_t st, uint32_t* pts, uint32_t n, int groups,
 }
 
 // ------------------------------------------------------------------------------------------------ host driver
+// The accumulate lane (round 5).  When several MSMs share the device -- the five of a Groth16 proof, the commitments of a Marlin round --
+// their accumulate kernels go, one after the other, to ONE stream whose queue is confined to `cus` compute units by a CU mask
+// (hipExtStreamCreateWithCUMask: the mask bits are dealt to the XCDs round-robin, tools/microbench/k3_cu_mask.hip, so clearing the last
+// 8 k bits leaves k CUs free in every XCD), while everything latency-bound (sorts, fix-ups, bucket reductions, the assembly) stays on the
+// MSM's own unmasked stream: an accumulate workgroup lives 0.5 .. 6 ms, and a dependent one-wave launch that has to wait for one of them to
+// retire costs that much PER LAUNCH (measured: a chain of 20 one-wave launches 0.9 ms on an idle device, 20 .. 38 ms behind an unmasked
+// grid of long-lived workgroups, 0.98 ms behind a masked one).  Accumulate grids are planned for the lane's CUs.
+// MEASURED SLOWER than plain concurrency and off by default (pcdhip_groth16_set_schedule 2 turns it on): a masked queue runs the
+// accumulate kernels 15 .. 45 % slower, and a proof already takes the sum of its kernels' standalone times (include/pcdhip.h).
+struct MsmLane {
+  hipStream_t stream = nullptr;
+  int cus = 0;  // compute units the lane's queue may use
+};
+
 struct MsmWorkspace {
   // device buffers, grown on demand and reused across calls (no allocation on the hot path once warm)
   void* buf[28] = {nullptr};
   size_t cap[28] = {0};
+  const MsmLane* lane = nullptr;                     // set by the caller around an msm_run whose accumulation goes to the lane
+  hipEvent_t lane_in = nullptr, lane_out = nullptr;  // sorted list ready -> lane; accumulation done -> this MSM's own stream
   const uint32_t* last_err_dev = nullptr;  // device word raised by the last MSM's digit pass when a scalar was not reduced (null: not checked)
   int cus = 0;                             // compute units of the device this workspace lives on (queried on first use)
   hipError_t ensure(int slot, size_t bytes) {
@@ -1438,11 +1471,16 @@ struct MsmWorkspace {
     cap[slot] = want;
     return hipSuccess;
   }
-  void release() { for (int i = 0; i < 28; i++) if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; } }
+  void release() {
+    for (int i = 0; i < 28; i++) if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
+    if (lane_in) { (void)hipEventDestroy(lane_in); lane_in = nullptr; }
+    if (lane_out) { (void)hipEventDestroy(lane_out); lane_out = nullptr; }
+  }
 };
 
 struct MsmTimings {  // milliseconds, filled when events are requested
   float digits = 0, scan = 0, scatter = 0, accumulate = 0, fixup = 0, tail = 0, horner = 0, total = 0;
+  uint32_t entries = 0, chunk = 0;  // the sorted list's length and the entries per lane the device chose for it (pcdhip_msm_last_plan)
 };
 
 enum { WS_CNT = 0, WS_OFF, WS_BSUM, WS_SORTED, WS_BUCKETS, WS_PFIRST, WS_PLAST, WS_BIG, WS_BIGSCR, WS_A0, WS_A1, WS_C0, WS_C1, WS_OUT, WS_SCAL,
@@ -1519,14 +1557,17 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
       pl.chunk = tree_cap;
     }
   }
+  const MsmLane* lane = ws.lane;
+  const int plan_cus = lane && lane->cus > 0 ? lane->cus : cus;  // the accumulate grid fills whole rounds of the CUs its queue may use
+  // (round 5: the chunk is chosen on the device from the actual list length -- msm_plan_chunk_kernel -- between chunk_lo and 56; the host
+  //  sizes grids and piece arrays for chunk_lo, which is 40 as before for a list that is long even when sparse and goes down to 16 for one
+  //  that cannot fill four rounds of the lanes)
+  uint32_t acc_lanes = 0, chunk_lo = 0;
+  const uint32_t chunk_hi = 56;
   if (!chunk_override && !use_tree) {
-    const double slots = (double)cus * 4 * MsmAccWaves<G>::value, per_wave = 64 / AccOf<G>::LANES;
-    double best = 1e300;
-    for (uint32_t ch = 40; ch <= 56; ch += 2) {
-      const double x = ceil(ceil((double)maxM / ch) / per_wave) / slots;
-      const double waste = ceil(x) / x;
-      if (waste < best - 0.01) { best = waste; pl.chunk = ch; }
-    }
+    acc_lanes = (uint32_t)plan_cus * 4 * MsmAccWaves<G>::value * (64 / AccOf<G>::LANES);
+    chunk_lo = (uint32_t)std::min<uint64_t>(40, std::max<uint64_t>(16, (maxM + 4ull * acc_lanes - 1) / (4ull * acc_lanes)));
+    pl.chunk = chunk_lo;
   }
   if (maxM >= 0xFFFFFFF0ull || (uint64_t)bv.n_total * bv.groups >= 0x7FFFFFF0ull) return hipErrorInvalidValue;  // bit 31 of an entry: sign
 
@@ -1556,7 +1597,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   uint32_t* ones_idx = (uint32_t*)ws.buf[WS_ONES];
   uint32_t* flag = ones_idx + n;  // cap-overflow flag of the single-pass binning
   uint32_t* err = flag + 1;       // a scalar >= 2^bits was seen (msm_scalar_too_wide)
-  uint32_t* big_count = flag + 2; // [#big buckets, #segments] of the fix-up pass; flag + 4: the pair tree's chunk word
+  uint32_t* big_count = flag + 2; // [#big buckets, #segments] of the fix-up pass; flag + 4: the chunk word (entries per lane, chosen on the device)
   auto zero_start = [&](uint32_t n_cnt) {  // cnt[0 .. n_cnt) and the four control words, one launch
     hipLaunchKernelGGL(msm_zero_kernel, dim3(std::max<uint32_t>(1u, (n_cnt + 255) / 256)), dim3(256), 0, st, cnt, n_cnt, flag);
   };
@@ -1656,7 +1697,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   if (use_tree) {
     // persistent waves; at most lanes x rounds chunks whatever the device picks (msm_tree_plan_kernel), or the forced chunk's count
     // (every SIMD gets a wave as soon as the list allows chunks of 32: a mid-size list is spread thin rather than over few waves)
-    tree_grid = std::min<uint32_t>(tree_chunk ? (nchunks + 63) / 64 : (uint32_t)((maxM / 32 + 63) / 64), (uint32_t)cus * 4);
+    tree_grid = std::min<uint32_t>(tree_chunk ? (nchunks + 63) / 64 : (uint32_t)((maxM / 32 + 63) / 64), (uint32_t)plan_cus * 4);
     if (!tree_chunk) nchunks = tree_grid * 64 * (uint32_t)((maxM + (uint64_t)tree_grid * 64 * tree_cap - 1) / ((uint64_t)tree_grid * 64 * tree_cap));
   }
   typedef MsmStored<typename SplitOf<G>::type> Stored;
@@ -1678,6 +1719,14 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   // (no memset of the bucket array -- 69 MB at c = 19: every bucket is written by exactly one of msm_accumulate, msm_fixup
   //  (also the empty ones: Z = 0) and msm_big_bucket)
   PCD_HIP_TRY(mark(8));  // the accumulate stage time is the kernel alone (mark 8 -> mark 4)
+  hipStream_t own = st;
+  if (lane) {  // the accumulation runs on the lane, behind the other MSMs' accumulations queued there before it
+    if (!ws.lane_in) PCD_HIP_TRY(hipEventCreateWithFlags(&ws.lane_in, hipEventDisableTiming));
+    if (!ws.lane_out) PCD_HIP_TRY(hipEventCreateWithFlags(&ws.lane_out, hipEventDisableTiming));
+    PCD_HIP_TRY(hipEventRecord(ws.lane_in, own));
+    PCD_HIP_TRY(hipStreamWaitEvent(lane->stream, ws.lane_in, 0));
+    st = lane->stream;
+  }
   {
     constexpr uint32_t per_wave = 64 / AccOf<G>::LANES;  // chunks per workgroup
     const dim3 acc_grid((nchunks + per_wave - 1) / per_wave);
@@ -1705,9 +1754,19 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
       }
     }
     if (!launched) {
-      if (src.slots) hipLaunchKernelGGL((msm_accumulate_kernel<G, false>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast);
-      hipLaunchKernelGGL((msm_accumulate_kernel<G, true>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast);
+      if (acc_lanes) {
+        uint32_t* chunk_word = big_count + 2;
+        hipLaunchKernelGGL(msm_plan_chunk_kernel, dim3(1), dim3(1), 0, st, off, tkeys, acc_lanes, chunk_lo, chunk_hi, chunk_word);
+        tree_chunk_dev = chunk_word;
+      }
+      if (src.slots) hipLaunchKernelGGL((msm_accumulate_kernel<G, false>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast, tree_chunk_dev);
+      hipLaunchKernelGGL((msm_accumulate_kernel<G, true>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast, tree_chunk_dev);
     }
+  }
+  if (lane) {
+    PCD_HIP_TRY(hipEventRecord(ws.lane_out, st));
+    st = own;
+    PCD_HIP_TRY(hipStreamWaitEvent(st, ws.lane_out, 0));
   }
   PCD_HIP_TRY(mark(4));
   // 5. pieces
@@ -1783,6 +1842,9 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; };
     tm->digits = el(0, 1); tm->scan = el(1, 2); tm->scatter = el(2, 8); tm->accumulate = el(8, 4);
     tm->fixup = el(4, 5); tm->tail = el(5, 6); tm->horner = el(6, 7); tm->total = el(0, 7);
+    PCD_HIP_TRY(hipMemcpy(&tm->entries, off + tkeys, 4, hipMemcpyDeviceToHost));
+    tm->chunk = pl.chunk;
+    if (tree_chunk_dev) PCD_HIP_TRY(hipMemcpy(&tm->chunk, tree_chunk_dev, 4, hipMemcpyDeviceToHost));
   }
   return hipSuccess;
 }

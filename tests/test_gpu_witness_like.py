@@ -1,0 +1,99 @@
+"""Proofs over the assignment a verifier circuit actually produces (round 5): >= 70 % of z is 0 or 1, in runs -- the
+in-circuit Groth16 verifier of /root/reference src/ec_cycle_pcd/data_structures.rs:269-304 (one per prior message) and :381-389 is bit
+decompositions with their booleanity rows (coracle.witness_r1cs).  In one proof this combines what the MSM-level tests cover one at a
+time: zeros that never enter a list, ones in the pseudo bucket (msm_merge_ones_kernel, the big-bucket kernels), sorts shared between the
+MSMs of a proof, the infinity bitmaps of a real key's a / b queries -- through both assembly forms, every schedule, sharded and not, keys
+as a setup makes them and dense ones, on all four curves; every proof byte-equal to the CPU oracle's.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THREADS = min(os.cpu_count() or 1, 64)
+
+
+def _devices(k):
+    from pcd_amd import capi
+    n = capi.lib().pcdhip_device_count()
+    return [i % n for i in range(k)]
+
+
+def _assignment_shape(co, r):
+    z = co.fp_op(r.field, "to_canonical", np.ascontiguousarray(r.z))
+    zero = ~z.any(axis=1)
+    one = (z[:, 0] == 1) & ~z[:, 1:].any(axis=1)
+    return float(zero.mean()), float(one.mean())
+
+
+@pytest.mark.parametrize("cid,nc", [(0, 40000), (1, 9000), (2, 5000), (3, 4000)])
+def test_prove_witness_like_all_forms(co, gpu_ctx, cid, nc):
+    fr = co.CURVE_FR[cid]
+    r = co.witness_r1cs(fr, nc, 2, seed=4400 + cid)
+    fz, fo = _assignment_shape(co, r)
+    assert fz + fo >= 0.70 and fz >= 0.35 and fo >= 0.25
+    rs = co.gen_field(fr, 2, seed=4410 + cid)
+    for consistent in (True, False):
+        keys = co.synthetic_keys(cid, r, seed=4420 + cid, consistent=consistent)
+        want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)
+        pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
+        try:
+            for sched in (0, 1, 2):
+                gpu_ctx.groth16_set_schedule(sched)
+                for mode in (1, 2):   # folded / chained assembly
+                    gpu_ctx.groth16_set_assembly(mode)
+                    got, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
+                    assert np.array_equal(got, want) and np.array_equal(inf, winf), (cid, consistent, sched, mode)
+        finally:
+            gpu_ctx.groth16_set_assembly(0)
+            gpu_ctx.groth16_set_schedule(0)
+            pk.free()
+
+
+@pytest.mark.parametrize("cid,nc,parts", [(0, 30000, 2), (3, 3000, 3)])
+def test_prove_witness_like_sharded(co, gpu_ctx, cid, nc, parts):
+    """the same assignment through a multi-device context (logical shards of one device when only one is visible): entry ranges of the
+    a' / b' / l' queries per device, the assembly products folded in -- equal to the oracle, with and without resident matrices"""
+    from pcd_amd import capi
+    fr = co.CURVE_FR[cid]
+    r = co.witness_r1cs(fr, nc, 2, seed=4500 + cid)
+    rs = co.gen_field(fr, 2, seed=4510 + cid)
+    keys = co.synthetic_keys(cid, r, seed=4520 + cid)
+    want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)
+    mctx = capi.Context(devices=_devices(parts))
+    try:
+        pk = mctx.g16_pk_upload(keys.host_struct(), cid)
+        got, inf = mctx.groth16_prove(pk, r, rs[0], rs[1])
+        assert np.array_equal(got, want) and np.array_equal(inf, winf)
+        mctx.g16_pk_set_r1cs(pk, r)
+        for sched in (0, 2):
+            mctx.groth16_set_schedule(sched)
+            got, inf = mctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
+            assert np.array_equal(got, want) and np.array_equal(inf, winf), sched
+        pk.free()
+    finally:
+        mctx.close()
+
+
+def test_main_proof_mnt4_298_2p20_witness_like(co, gpu_ctx):
+    """BASELINE configs[1]/[2]'s main proof shape at 2^20 rows with the witness-like assignment, consistent key, resident matrices,
+    chained and folded assembly"""
+    cid, fr = 0, co.CURVE_FR[0]
+    r = co.witness_r1cs(fr, (1 << 20) - 8, 2, seed=4600)
+    fz, fo = _assignment_shape(co, r)
+    assert fz + fo >= 0.70
+    keys = co.synthetic_keys(cid, r, seed=4601, mt=True)
+    rs = co.gen_field(fr, 2, seed=4602)
+    want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)
+    pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
+    gpu_ctx.g16_pk_set_r1cs(pk, r)
+    try:
+        for mode in (2, 1):
+            gpu_ctx.groth16_set_assembly(mode)
+            got, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
+            assert np.array_equal(got, want) and np.array_equal(inf, winf), mode
+    finally:
+        gpu_ctx.groth16_set_assembly(0)
+        pk.free()

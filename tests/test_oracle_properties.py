@@ -110,3 +110,25 @@ def test_skewed_r1cs_generator(co):
     vals = [f.unlimbs(x) for x in r.coeff_a[:20000]]
     assert sum(v in (one, mone) for v in vals) / len(vals) > 0.75
     assert max(r.col_a.max(), r.col_b.max(), r.col_c.max()) < r.num_vars and r.num_vars == r.z.shape[0]
+
+
+def test_witness_r1cs_generator(co):
+    """coracle.witness_r1cs (round 5: the assignment a verifier circuit produces -- runs of bits with booleanity rows, packing rows, a few
+    products; /root/reference src/ec_cycle_pcd/data_structures.rs:269-304): every row satisfied on two fields, >= 70 % of z is 0 or 1 with
+    both values frequent, the rest spread over the field, every column in range, one variable per row"""
+    from oracle import pyoracle as po
+    for field, nc in ((1, 6000), (3, 700)):
+        r = co.witness_r1cs(field, nc, 2, seed=11 + field)
+        f = po.FIELDS[field]
+        z = [f.from_mont(f.unlimbs(x)) for x in r.z]
+
+        def row(rp, col, cf, j):
+            return sum(f.from_mont(f.unlimbs(cf[k])) * z[col[k]] for k in range(int(rp[j]), int(rp[j + 1]))) % f.p
+        for j in range(nc):
+            assert row(r.rp_a, r.col_a, r.coeff_a, j) * row(r.rp_b, r.col_b, r.coeff_b, j) % f.p == row(r.rp_c, r.col_c, r.coeff_c, j), j
+        zeros, ones = sum(v == 0 for v in z), sum(v == 1 for v in z)
+        assert (zeros + ones) / len(z) >= 0.70 and zeros / len(z) >= 0.35 and ones / len(z) >= 0.25
+        big = [v for v in z if v.bit_length() > f.p.bit_length() - 8]
+        assert len(big) >= len(z) // 20
+        assert max(r.col_a.max(), r.col_b.max(), r.col_c.max()) < r.num_vars and r.num_vars == r.z.shape[0] == nc + 2 + 4
+        assert r.rp_c[nc] < r.rp_a[nc]   # booleanity rows have an empty C row

@@ -18,3 +18,16 @@ def test_consistent_flags_match_a_real_setup(co):
         assert not getattr(dense, name).any()
     assert np.array_equal(real.b_g1_inf, real.b_g2_inf)
     assert not syn.l_inf.any() and not syn.h_inf.any()
+
+
+def test_consistent_flags_match_a_real_setup_witness_shape(co):
+    """the same for the witness-like generator (coracle.witness_r1cs: booleanity rows put every bit into A AND B, a packed word only
+    into C): flags from the matrices == flags out of a real setup's arithmetic"""
+    cid = 1
+    fr = co.CURVE_FR[cid]
+    r = co.witness_r1cs(fr, 700, 2, seed=4811)
+    real = co.groth16_setup(cid, r, co.gen_field(fr, 5, seed=4812), nthreads=8)
+    syn = co.synthetic_keys(cid, r, seed=4813)
+    assert 0.02 < real.a_inf.mean() < 0.5
+    for name in ("a_inf", "b_g1_inf", "b_g2_inf"):
+        assert np.array_equal(getattr(syn, name), getattr(real, name)), name

@@ -9,18 +9,23 @@ torch.zeros(1, device="cuda:0")
 from oracle import coracle as co
 from pcd_amd import capi
 curve = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-nc = (1 << int(sys.argv[2])) - 8 if len(sys.argv) > 2 else (1 << 20) - 8
+nc = int(os.environ['AB_NC']) if os.environ.get('AB_NC') else (1 << int(sys.argv[2])) - 8 if len(sys.argv) > 2 else (1 << 20) - 8
 ctx = capi.Context(0)
 fr = co.CURVE_FR[curve]
-r = co.skewed_r1cs(fr, nc, 2, seed=77)
-keys = co.synthetic_keys(curve, r, seed=78, mt=True)
+r = (co.witness_r1cs if os.environ.get("AB_WITNESS") else co.skewed_r1cs)(fr, nc, 2, seed=77)   # AB_WITNESS=1: >= 70 % of z is 0 / 1
+keys = co.synthetic_keys(curve, r, seed=78, mt=True, consistent=os.environ.get("AB_DENSE", "0") != "1")
 rs = co.gen_field(fr, 2, seed=79)
 pk = ctx.g16_pk_upload(keys.host_struct(), curve)
 ctx.g16_pk_set_r1cs(pk, r)
 r.z = capi.pinned_like(r.z)
 first = None
-for sched in [int(x) for x in os.environ.get("AB_SCHEDULES", "0,1,0,1").split(",")]:   # 0: assignment MSMs first (default); 1: witness map first
+# AB_SCHEDULES: comma list of `schedule` or `schedule:reserved CUs` (2: accumulate lane, the default; 0: rounds 1-4; 1: map first, all MSMs at once)
+for item in os.environ.get("AB_SCHEDULES", "0,2:8,0,2:8").split(","):
+    sched, _, res = item.partition(":")
+    sched = int(sched)
     ctx.groth16_set_schedule(sched)
+    if res:
+        ctx.set_lane_reserve(int(res))
     for _ in range(3):
         proof, _ = ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
     first = proof if first is None else first
@@ -29,4 +34,4 @@ for sched in [int(x) for x in os.environ.get("AB_SCHEDULES", "0,1,0,1").split(",
     for _ in range(7):
         t0 = time.perf_counter(); ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True); walls.append((time.perf_counter() - t0) * 1e3)
     tm = {k: round(float(v), 2) for k, v in ctx.groth16_last_timings().items()}
-    print(f"lib={os.environ.get('PCDHIP_LIB', 'in-tree')} curve={curve} schedule={sched} prove wall ms median {np.median(walls):.3f} min {min(walls):.3f}; device {tm}", flush=True)
+    print(f"lib={os.environ.get('PCDHIP_LIB', 'in-tree')} curve={curve} schedule={item} prove wall ms median {np.median(walls):.3f} min {min(walls):.3f}; device {tm}", flush=True)

@@ -17,12 +17,17 @@ def run():
     curve = int(os.environ.get("PT_CURVE", "0"))
     ctx = capi.Context(0)
     fr = co.CURVE_FR[curve]
-    r = co.skewed_r1cs(fr, int(os.environ.get("PT_NC", (1 << 20) - 8)), 2, seed=77)
+    r = (co.witness_r1cs if os.environ.get("PT_WITNESS") else co.skewed_r1cs)(fr, int(os.environ.get("PT_NC", (1 << 20) - 8)), 2, seed=77)
     keys = co.synthetic_keys(curve, r, seed=78, mt=True)
     rs = co.gen_field(fr, 2, seed=79)
     pk = ctx.g16_pk_upload(keys.host_struct(), curve)
     ctx.g16_pk_set_r1cs(pk, r)
     r.z = capi.pinned_like(r.z)
+    if os.environ.get("PT_SCHED"):   # `schedule` or `schedule:reserved CUs` (pcdhip_groth16_set_schedule, pcdhip_set_lane_reserve)
+        sched, _, res = os.environ["PT_SCHED"].partition(":")
+        ctx.groth16_set_schedule(int(sched))
+        if res:
+            ctx.set_lane_reserve(int(res))
     for _ in range(4):
         ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
     torch.cuda.synchronize()
@@ -49,6 +54,15 @@ def report(d):
     last = rows[cut:]
     t0, t1 = last[0][0], max(b for _, b, _ in last)
     print(f"{len(last)} kernels over {(t1 - t0) / 1e6:.2f} ms")
+    # every accumulate kernel and every kernel of 0.3 ms and more: start, duration, grid
+    rows_full = {(int(r["Start_Timestamp"]), r["Kernel_Name"]): r for r in csv.DictReader(open(f))}
+    for a, b, n in last:
+        if "msm_accumulate" in n or b - a >= int(os.environ.get("PT_MIN_US", "300")) * 1000:
+            r = rows_full[(a, n)]
+            grid = r.get("Grid_Size_X") or r.get("Grid_Size") or "?"
+            wg = r.get("Workgroup_Size_X") or r.get("Workgroup_Size") or "?"
+            short = n.split("(")[0].replace("void pcd::", "").replace("pcd::", "")[:70]
+            print(f"  {(a - t0) / 1e6:7.3f} ms  +{(b - a) / 1e6:6.3f} ms  q{r.get('Queue_Id', '?')} s{r.get('Stream_Id', '?')}  grid {grid}/{wg}  {short}")
     step = int(os.environ.get("PT_SLICE_US", "500")) * 1000
     for s in range(t0, t1, step):
         busy = collections.Counter()
