@@ -44,7 +44,9 @@ enum {
   PCDHIP_E_SIZE_UNSUPPORTED = -2, /* e.g. log_n above the field's 2-adicity (mixed-radix domain needed) */
   PCDHIP_E_NO_DEVICE = -3,
   PCDHIP_E_OOM = -4,
-  PCDHIP_E_HIP = -5               /* any other HIP runtime failure; see pcdhip_last_hip_error */
+  PCDHIP_E_HIP = -5,              /* any other HIP runtime failure; see pcdhip_last_hip_error */
+  PCDHIP_E_PREV_TICKET = -6       /* pcdhip_msm_submit_partial only: the PREVIOUS ticket of the slot had an unreduced scalar (its result is
+                                     wrong); THIS submission was enqueued all the same and *ticket is valid */
 };
 
 typedef struct pcdhip_ctx pcdhip_ctx;
@@ -113,10 +115,16 @@ int pcdhip_msm_collect(pcdhip_ctx* ctx, int ticket, uint64_t* out_xyz_mont);
  * collective is enqueued on) wait for that MSM -- no host wait -- and frees the ticket.  Before a slot is written again its reader
  * must have been ordered in front of the context's stream (pcdhip_stream_wait direction 0), which every submission follows.
  * Several shard MSMs then overlap each other and the exchange of earlier ones, like pcdhip_msm_submit / collect on one GPU.
- * An unreduced scalar (PCDHIP_E_ARG from pcdhip_msm_dev) is reported on this path by the NEXT submission that reuses the ticket's slot. */
+ * An unreduced scalar (PCDHIP_E_ARG from pcdhip_msm_dev) is reported on this path by the NEXT submission that reuses the ticket's slot, as
+ * PCDHIP_E_PREV_TICKET: a code of its own, so that a pipelined caller can tell "an earlier MSM of this slot was wrong" from "this submission
+ * was refused" -- the new submission IS enqueued and *ticket valid in that case.  pcdhip_msm_ticket_status polls a released ticket's word
+ * without submitting (e.g. after the last step of a loop). */
 int pcdhip_msm_submit_partial(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset,
                               size_t n, uint64_t* out_xyz_device_slots, size_t slot_stride_bytes, int* ticket);
 int pcdhip_msm_ticket_wait(pcdhip_ctx* ctx, int ticket, void* other_stream);
+/* The error word of the last MSM that used `slot` (0 .. 3) and was released by pcdhip_msm_ticket_wait: waits for that MSM, then
+ * PCDHIP_OK, or PCDHIP_E_PREV_TICKET when one of its scalars was not reduced.  PCDHIP_E_ARG for a slot that is busy or was never released. */
+int pcdhip_msm_ticket_status(pcdhip_ctx* ctx, int slot);
 /* Precomputed window-shifted copies of bases uploaded AFTER this call through this context
  * (HBM capacity traded against the serial window combine; the proving key of a PCD is fixed for the whole
  * computation, so the one-time cost amortises over every step):
@@ -185,6 +193,11 @@ int pcdhip_fft_dev(pcdhip_ctx* ctx, pcdhip_buf* data, uint32_t log_n, int invers
  * F298A, 5 for F753A: `MixedRadixEvaluationDomain`, what upstream selects for the HELP proof of a PCD step once its
  * circuit exceeds 2^17 / 2^15 rows); b = 0 is the radix-2 domain.  group_gen = GENERATOR^((p-1)/n). */
 int pcdhip_fft_general(pcdhip_ctx* ctx, int field_id, uint64_t* data_mont, size_t n, int inverse, int coset);
+/* n_ops transforms of ONE host vector, one after the other, with a single trip over PCIe (seam S2: ark-poly callers chain transforms on a
+ * polynomial -- `ifft` then `coset_fft` in R1CSToQAP::witness_map and in Marlin's AHP rounds, reference path tests/mnt4_marlin.rs:141-204 --
+ * and pcdhip_fft pays the 2 x n x 40 / 96 bytes per call).  ops[i]: bit 0 = inverse, bit 1 = coset; every transform over the domain of
+ * n = 2^a q^b elements (GeneralEvaluationDomain).  Same results as n_ops calls of pcdhip_fft_general. */
+int pcdhip_fft_seq(pcdhip_ctx* ctx, int field_id, uint64_t* data_mont, size_t n, const int* ops, int n_ops);
 /* Size `GeneralEvaluationDomain::new(min_size)` would pick (0 if none exists): the witness map uses it. */
 size_t pcdhip_domain_size(int field_id, size_t min_size);
 /* Per-pass device time of the last transform; returns the number of passes written (<= 8). */
@@ -222,6 +235,9 @@ typedef struct {
 } pcdhip_g16_pk_host;
 int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* host, pcdhip_g16_pk** out);
 void pcdhip_g16_pk_free(pcdhip_ctx* ctx, pcdhip_g16_pk* pk);
+/* The MSM plan of a resident key's queries, in the order a, b_g1, b_g2, l, h: window bits and scalar windows (what a bench needs to count
+ * the multiply-adds a proof executes; a key's large queries run one bit under the lone MSM's window, pcdhip_g16_pk_upload). */
+int pcdhip_g16_pk_info(const pcdhip_g16_pk* pk, int window_bits[5], int windows[5]);
 /* Keep the circuit's constraint matrices (`ConstraintMatrices` from `cs.to_matrices()`, fixed per circuit like
  * the key) resident on the device; pcdhip_groth16_prove then accepts A = B = C = NULL and only the assignment
  * z crosses PCIe per proof. */

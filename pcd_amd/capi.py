@@ -22,6 +22,15 @@ class PcdHipError(RuntimeError):
     pass
 
 
+class PrevTicketError(PcdHipError):
+    """PCDHIP_E_PREV_TICKET: an EARLIER MSM of the slot had an unreduced scalar; `ticket` (when not None) is the NEW submission, which was
+    enqueued all the same and must be waited for / released like any other"""
+
+    def __init__(self, msg, ticket=None):
+        super().__init__(msg)
+        self.ticket = ticket
+
+
 class Csr(C.Structure):
     _fields_ = [("num_rows", C.c_uint64), ("row_ptr", C.c_void_p), ("col", C.c_void_p), ("coeff", C.c_void_p)]
 
@@ -44,10 +53,10 @@ EXPORTS = [
     "pcdhip_strerror", "pcdhip_device_count", "pcdhip_init", "pcdhip_init_devices", "pcdhip_ctx_devices", "pcdhip_destroy", "pcdhip_sync", "pcdhip_host_alloc", "pcdhip_host_free", "pcdhip_last_hip_error",
     "pcdhip_field_limbs", "pcdhip_curve_base_field", "pcdhip_curve_scalar_field", "pcdhip_point_limbs",
     "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
-    "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config", "pcdhip_msm_submit", "pcdhip_msm_collect", "pcdhip_msm_submit_partial", "pcdhip_msm_ticket_wait", "pcdhip_bases_info", "pcdhip_stream_wait",
+    "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config", "pcdhip_msm_submit", "pcdhip_msm_collect", "pcdhip_msm_submit_partial", "pcdhip_msm_ticket_wait", "pcdhip_msm_ticket_status", "pcdhip_bases_info", "pcdhip_stream_wait",
     "pcdhip_set_precompute", "pcdhip_set_precompute_budget", "pcdhip_msm_set_sort", "pcdhip_msm_set_accumulate", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_msm_last_plan", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
-    "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
-    "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_g16_witness_map_resident", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_groth16_set_witness_split", "pcdhip_groth16_set_schedule", "pcdhip_set_lane_reserve", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
+    "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_fft_seq", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
+    "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_g16_pk_info", "pcdhip_g16_witness_map_resident", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_groth16_set_witness_split", "pcdhip_groth16_set_schedule", "pcdhip_set_lane_reserve", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
     "pcdhip_serialized_size", "pcdhip_serialize_points", "pcdhip_deserialize_points", "pcdhip_deserialize_points_unchecked", "pcdhip_proof_serialized_size", "pcdhip_proof_serialize",
     "pcdhip_proof_deserialize", "pcdhip_vk_serialized_size", "pcdhip_vk_serialize", "pcdhip_vk_deserialize",
     "pcdhip_process_vk", "pcdhip_pvk_free", "pcdhip_groth16_verify_prepared", "pcdhip_groth16_verify_batch_rlc",
@@ -172,12 +181,22 @@ class Context:
         apart) -> ticket number; release it with msm_ticket_wait(ticket, stream), which makes `stream` wait for the MSM."""
         n = scalars.n if n is None else n
         t = C.c_int(-1)
-        self._check(lib().pcdhip_msm_submit_partial(self._ctx, bases._h, C.c_size_t(offset), scalars._h, C.c_size_t(0), C.c_size_t(n),
-                                                    C.c_void_p(out_slots_device_ptr), C.c_size_t(slot_stride_bytes), C.byref(t)))
+        rc = lib().pcdhip_msm_submit_partial(self._ctx, bases._h, C.c_size_t(offset), scalars._h, C.c_size_t(0), C.c_size_t(n),
+                                             C.c_void_p(out_slots_device_ptr), C.c_size_t(slot_stride_bytes), C.byref(t))
+        if rc == -6:   # PCDHIP_E_PREV_TICKET: this submission is in flight; an earlier one of the slot was wrong
+            raise PrevTicketError(lib().pcdhip_strerror(rc).decode(), t.value)
+        self._check(rc)
         return t.value
 
     def msm_ticket_wait(self, ticket, other_stream):
         self._check(lib().pcdhip_msm_ticket_wait(self._ctx, int(ticket), C.c_void_p(other_stream)))
+
+    def msm_ticket_status(self, slot):
+        """waits for the last released MSM of `slot`; raises PrevTicketError when one of its scalars was not reduced"""
+        rc = lib().pcdhip_msm_ticket_status(self._ctx, int(slot))
+        if rc == -6:
+            raise PrevTicketError(lib().pcdhip_strerror(rc).decode())
+        self._check(rc)
 
     def msm_partial_to_device(self, bases, scalars, out_device_ptr, offset=0, n=None):
         """The MSM of a shard with its Jacobian result left at `out_device_ptr` (device memory of the caller, e.g. a torch
@@ -268,6 +287,13 @@ class Context:
         self._check(lib().pcdhip_fft_general(self._ctx, field, _p(data), C.c_size_t(data.shape[0]), int(inverse), int(coset)))
         return data
 
+    def fft_seq(self, field, data, ops):
+        """the transforms `ops` = [(inverse, coset), ..] applied one after the other to one host vector, one trip over PCIe"""
+        data = _u64(data).copy()
+        codes = (C.c_int * len(ops))(*[int(bool(i)) | (int(bool(c)) << 1) for i, c in ops])
+        self._check(lib().pcdhip_fft_seq(self._ctx, field, _p(data), C.c_size_t(data.shape[0]), codes, len(ops)))
+        return data
+
     def fft_last_timings(self):
         out = (C.c_float * 8)()
         k = lib().pcdhip_fft_last_timings(self._ctx, out)
@@ -327,6 +353,12 @@ class Context:
         self._check(lib().pcdhip_groth16_prove(self._ctx, pk._h, C.byref(A), C.byref(B), C.byref(Cm), _p(r1cs.z),
                                                _p(_u64(r_mont)), _p(_u64(s_mont)), _p(proof), _p(inf)))
         return proof, inf
+
+    def g16_pk_info(self, pk):
+        """{query: (window bits, windows)} of a resident key's a / b_g1 / b_g2 / l / h queries"""
+        c, w = (C.c_int * 5)(), (C.c_int * 5)()
+        self._check(lib().pcdhip_g16_pk_info(pk._h, c, w))
+        return {k: (int(c[i]), int(w[i])) for i, k in enumerate(("a", "b_g1", "b_g2", "l", "h"))}
 
     def groth16_set_assembly(self, mode):
         """0: automatic (default); 1: s*A, r*B_1 folded into two extra MSMs; 2: chained one-lane products overlapping the other MSMs."""

@@ -191,6 +191,7 @@ const char* pcdhip_strerror(int code) {
     case PCDHIP_E_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
     case PCDHIP_E_OOM: return "out of device memory";
     case PCDHIP_E_HIP: return "HIP runtime error (see pcdhip_last_hip_error)";
+    case PCDHIP_E_PREV_TICKET: return "the previous ticket of this slot had an unreduced scalar (this submission was enqueued)";
     default: return "unknown error";
   }
 }
@@ -486,6 +487,17 @@ int pcdhip_bases_info(const pcdhip_bases* bases, size_t n, int* window_bits, int
   *copies = bases->groups;
   return PCDHIP_OK;
 }
+int pcdhip_g16_pk_info(const pcdhip_g16_pk* pk, int window_bits[5], int windows[5]) {
+  if (!pk || !window_bits || !windows) return PCDHIP_E_ARG;
+  if (!pk->shards.empty()) return pcdhip_g16_pk_info(pk->shards[0], window_bits, windows);  // (the plan of device 0's shard)
+  const pcdhip_bases* q[5] = {pk->a_query, pk->b_g1_query, pk->b_g2_query, pk->l_query, pk->h_query};
+  for (int i = 0; i < 5; i++) {
+    int copies = 0;
+    int rc = q[i] ? pcdhip_bases_info(q[i], 0, &window_bits[i], &windows[i], &copies) : PCDHIP_E_ARG;
+    if (rc) return rc;
+  }
+  return PCDHIP_OK;
+}
 int pcdhip_stream_wait(pcdhip_ctx* ctx, void* other_stream, int direction) {
   if (!ctx || direction < 0 || direction > 1) return PCDHIP_E_ARG;
   BIND();
@@ -667,13 +679,16 @@ static int msm_submit_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t 
   ctx->pipe_next = (slot + 1) % pcdhip_ctx::PIPE_SLOTS;
   if (!ctx->pipe_host) TRY(hipHostMalloc((void**)&ctx->pipe_host, pcdhip_ctx::PIPE_SLOTS * pcdhip_ctx::PIPE_HOST_WORDS * 8, hipHostMallocDefault));
   if (!ctx->pipe_done[slot]) TRY(hipEventCreateWithFlags(&ctx->pipe_done[slot], hipEventDisableTiming));
+  bool prev_bad = false;
   if (ctx->pipe_partial[slot]) {
     // the slot's previous ticket was handed to another stream (pcdhip_msm_ticket_wait), so nobody has looked at its error word and its
     // device-to-host copy may still be in flight: wait for that MSM (long finished in a pipelined loop: it was submitted PIPE_SLOTS
     // submissions ago and its gather has been consumed) before the word is reset, and report an unreduced scalar HERE
     TRY(hipEventSynchronize(ctx->pipe_done[slot]));
     ctx->pipe_partial[slot] = false;
-    if ((uint32_t)ctx->pipe_host[(size_t)slot * pcdhip_ctx::PIPE_HOST_WORDS + pcdhip_ctx::PIPE_HOST_WORDS - 1]) return PCDHIP_E_ARG;
+    // (a code of its own, and the new submission goes ahead -- the caller learns that an EARLIER result was wrong without losing
+    //  this one or mistaking the code for a refusal)
+    prev_bad = (uint32_t)ctx->pipe_host[(size_t)slot * pcdhip_ctx::PIPE_HOST_WORDS + pcdhip_ctx::PIPE_HOST_WORDS - 1] != 0;
   }
   const GroupEntry& ge = group_entry(bases->curve_id, bases->group_id);
   const size_t jac_b = (size_t)ge.point_words / 2 * 3 * 4, jac_abi_b = (size_t)ge.point_abi_words / 2 * 3 * 4;
@@ -702,7 +717,14 @@ static int msm_submit_common(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t 
   ctx->pipe_busy[slot] = true;
   ctx->pipe_out_bytes[slot] = out_xyz_device ? 0 : jac_abi_b;
   *ticket = slot;
-  return PCDHIP_OK;
+  return prev_bad ? PCDHIP_E_PREV_TICKET : PCDHIP_OK;
+}
+int pcdhip_msm_ticket_status(pcdhip_ctx* ctx, int slot) {
+  if (!ctx || slot < 0 || slot >= pcdhip_ctx::PIPE_SLOTS || ctx->pipe_busy[slot] || !ctx->pipe_partial[slot]) return PCDHIP_E_ARG;
+  BIND();
+  TRY(hipEventSynchronize(ctx->pipe_done[slot]));
+  ctx->pipe_partial[slot] = false;
+  return (uint32_t)ctx->pipe_host[(size_t)slot * pcdhip_ctx::PIPE_HOST_WORDS + pcdhip_ctx::PIPE_HOST_WORDS - 1] ? PCDHIP_E_PREV_TICKET : PCDHIP_OK;
 }
 int pcdhip_msm_submit(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset, size_t n,
                       int* ticket) {
@@ -939,6 +961,35 @@ int pcdhip_fft_general(pcdhip_ctx* ctx, int field_id, uint64_t* data, size_t n, 
   if (rc) return rc;
   BIND();
   return fft_host_general(ctx, field_id, data, d, inverse, coset);
+}
+// Several transforms of ONE host vector with one trip over PCIe (round 5): pcdhip_fft moves the vector both ways per
+// transform (2^20 elements over the 298-bit field: 42 MB each way for 0.3 ms of passes), and what ark-poly's callers do with a polynomial
+// is usually a chain -- Marlin's `ifft` of evaluations followed by `coset_fft` on a larger domain, the witness map's `ifft; coset_fft` --
+// that seam S2 (rust/src/s2.rs) can hand over whole.  ops[i]: bit 0 inverse, bit 1 coset; all on the domain of n = 2^a q^b elements.
+int pcdhip_fft_seq(pcdhip_ctx* ctx, int field_id, uint64_t* data, size_t n, const int* ops, int n_ops) {
+  if (!ctx || !data || !valid_field(field_id) || !ops || n_ops < 1 || n_ops > 64) return PCDHIP_E_ARG;
+  for (int i = 0; i < n_ops; i++) if (ops[i] < 0 || ops[i] > 3) return PCDHIP_E_ARG;
+  Dom d;
+  int rc = split_domain(field_id, n, &d);
+  if (rc) return rc;
+  BIND();
+  const FieldEntry& fe = field_entry(field_id);
+  const size_t bytes = (size_t)d.n * fe.abi_words * 4, vb = (size_t)d.n * fe.words * 4;
+  TRY(ctx->aux_ws.ensure(AUX_SCAL, bytes));
+  TRY(ctx->aux_ws.ensure(AUX_FFT_X, vb));
+  TRY(ctx->aux_ws.ensure(AUX_FFT_TMP, vb));
+  uint32_t* abi = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
+  uint32_t* x = (uint32_t*)ctx->aux_ws.buf[AUX_FFT_X];
+  TRY(hipMemcpyAsync(abi, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+  TRY(fe.convert(ctx->stream, abi, x, d.n, 0));
+  for (int i = 0; i < n_ops; i++) {  // (the vector stays in the device image between the transforms: neither conversion in between)
+    rc = domain_transform(ctx, field_id, d, x, (uint32_t*)ctx->aux_ws.buf[AUX_FFT_TMP], ops[i] & 1, (ops[i] >> 1) & 1, ctx->fft_ms, &ctx->fft_passes);
+    if (rc) return rc;
+  }
+  TRY(fe.convert(ctx->stream, x, abi, d.n, 1));
+  TRY(hipMemcpyAsync(data, abi, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  TRY(hipStreamSynchronize(ctx->stream));
+  return PCDHIP_OK;
 }
 size_t pcdhip_domain_size(int field_id, size_t min_size) {
   if (!valid_field(field_id) || min_size == 0) return 0;
@@ -1482,7 +1533,11 @@ struct G16Run {
       else jobs[nj++] = {&g1, plain(va), zc, n, slot(2), 3, t1 + sw, slot(3), PRODUCE};
       if (sparse_b && pk->b_inf_same) {
         jobs[nj++] = {&g1, vb1, zc, n, slot(5), 4, t1, slot(4), PRODUCE | SHARE_B};                          // B_1, then r * B_1
-        jobs[nj++] = {&g2, vb2, zc, n, msm_g2, 5, nullptr, nullptr, CONSUME | SHARE_B};                      // B
+        // (b_g1 and b_g2 flag the same entries -- compared byte for byte at upload -- so B names B_1's bitmap: the shared list's identity,
+        //  which msm_run checks before it consumes a filtered list)
+        MsmBasesView vb2s = vb2;
+        vb2s.inf_bits = vb1.inf_bits;
+        jobs[nj++] = {&g2, vb2s, zc, n, msm_g2, 5, nullptr, nullptr, CONSUME | SHARE_B};                     // B
       } else if (sparse_b) {
         jobs[nj++] = {&g1, vb1, zc, n, slot(5), 4, t1, slot(4), NONE};
         jobs[nj++] = {&g2, vb2, zc, n, msm_g2, 5, nullptr, nullptr, NONE};
@@ -1570,7 +1625,7 @@ int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_cs
                       pk->shards[1]->rows == rows && pk->shards[2]->rows == rows;
   // (pcdhip_groth16_set_schedule 1, off by default: measured slower) a device that carries a chain of the witness map starts its MSMs only
   // when that chain is through
-  const bool map_first = ctx->g16_schedule >= 1;  // (2: only the accumulate lane of such a device waits for its chain)
+  const bool map_first = ctx->g16_schedule == 1 || ctx->g16_schedule == 2;  // (2: only the accumulate lane of such a device waits for its chain)
   auto carries_chain = [&](size_t g) { return g == 0 || (split3 && g <= 2); };
   std::vector<G16Run> runs(G);
   for (size_t g = 0; g < G; g++) {
@@ -1734,6 +1789,10 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   if (dom_used.n != dom.n) return PCDHIP_E_ARG;
   TRY(fe.convert(st, (const uint32_t*)ctx->aux_ws.buf[AUX_A], run.h_can, (uint32_t)n, 2));
   TRY(hipEventRecord(ev[1], st));
+  // (round 5 also tried the map's launches merely ENQUEUED first with the h MSM right behind it and the assignment MSMs after, nothing
+  //  gated -- the critical path of a proof over a witness-like assignment is upload -> map -> h MSM: slower everywhere, 11.2 against 8.0 ms
+  //  there, 19.0 against 15.8 ms on a uniform assignment, because the G2 MSM and the one-point products then start last:
+  //  profiles/r05_ab_prove_schedule.txt)
   if (map_first) { rc = run.launch_assignment_gated(0, m + 4, folded, ev[1]); if (rc) return rc; }  // (lane: no accumulation under the map; the sorts start at once)
   rc = run.launch_h(0, std::min<size_t>(pk->h_query->n, n), ev[1]);
   if (rc) return rc;

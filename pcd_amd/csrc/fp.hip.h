@@ -601,7 +601,7 @@ struct Fp {
   // The value of a signed limb-wise sum of small multiples of field elements: s[i] = sum_t c_t a_t[i] with every a_t in [0, 2p) and
   // sum |c_t| <= 2000, so V = sum s[i] 2^(28 i) has |V| < 2^12 p and every |s[i]| < 2^40.  ONE pass: the quotient is estimated BEFORE
   // any carry runs, in double precision from the three top columns -- d = s[N-1] 2^56 + s[N-2] 2^28 + s[N-3] is V / 2^(28 (N - 3)) up to
-  // 2^-15 from the columns below and 2^43 from rounding, against p / 2^(28 (N - 3)) > 2^72: x = d * RECIP3_D is V / p to within 2^-28 --
+  // ~2^12 from the columns below (|s[N-4]| < 2^40 weighs 2^-28) and 2^43 from rounding, against p / 2^(28 (N - 3)) > 2^72: x = d * RECIP3_D is V / p to within 2^-28 --
   // and q = floor(x - 1/2) puts V - q p in (0.49 p, 1.51 p): inside [0, 2p) with no correction step, for negative V as well (no offset
   // K p).  Then one signed carry chain over s[i] - q p_i.  (Before: a chain with K p added, the estimate, a second chain, and the two
   // chains of norm_reduce: 134 instructions at 11 limbs against 75 now.)  The LIN instruction of the pairing VM, the small-coefficient

@@ -138,11 +138,13 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
   bool live = i < n && !msm_base_is_inf(inf_bits, base_offset + i);
   uint32_t s[NS];
   bool is_one = false;
-  if (live) {
+  // (the width check looks at EVERY scalar, also those whose base is the point at infinity and so never enter a list: an unreduced
+  //  scalar is a caller's error wherever it sits -- include/pcdhip.h promises PCDHIP_E_ARG for it)
+  if (live || (i < n && MODE != MODE_SCATTER && err)) {
     uint32_t hi = 0;
 #pragma unroll
     for (int k = 0; k < NS; k++) { s[k] = scalars[(size_t)i * NS + k]; if (k) hi |= s[k]; }
-    is_one = (hi == 0 && s[0] == 1);
+    is_one = live && (hi == 0 && s[0] == 1);
     if (MODE != MODE_SCATTER && err && msm_scalar_too_wide<NS>(s, scalar_bits)) *err = 1u;
   }
   // scalars equal to one: one atomic per wave on the pseudo bucket
@@ -222,11 +224,11 @@ __global__ void __launch_bounds__(256) msm_coarse_kernel(const uint32_t* __restr
     bool live = i < n && !msm_base_is_inf(inf_bits, base_offset + i);
     uint32_t s[NS];
     bool is_one = false;
-    if (live) {
+    if (live || (i < n && !WRITE)) {   // (pass 0 checks the width of every scalar, those on bases at infinity included)
       uint32_t hi = 0;
 #pragma unroll
       for (int q = 0; q < NS; q++) { s[q] = scalars[(size_t)i * NS + q]; if (q) hi |= s[q]; }
-      is_one = (hi == 0 && s[0] == 1);
+      is_one = live && (hi == 0 && s[0] == 1);
       if (!WRITE && msm_scalar_too_wide<NS>(s, scalar_bits)) *err = 1u;
     }
     if (!WRITE) {  // the ones are listed once, in pass 0: staged in LDS, ONE global atomic per workgroup (a bit-heavy witness is a
@@ -407,15 +409,17 @@ static __global__ void __launch_bounds__(1024) scan_apply(const uint32_t* __rest
 // them) and the points at infinity of a key (28 .. 41 % of a real a / b query), and a grid planned for n W entries then runs a last round
 // that is nearly empty (A of the bench's proof: 2.07 rounds of work took three) or, for a short list, gives a quarter of the lanes 40
 // entries each while the others idle (2^16 pairs: 10 entries per lane on average).  `lanes` = chunks the device runs at a time; the list
-// is spread over whole rounds of them, `lo` <= chunk <= `hi`.
-static __global__ void msm_plan_chunk_kernel(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t lanes, uint32_t lo, uint32_t hi,
-                                             uint32_t* __restrict__ chunk_out) {
-  if (blockIdx.x || threadIdx.x) return;
-  const uint64_t M = off[nkeys];
-  const uint64_t rounds = (M + (uint64_t)lanes * hi - 1) / ((uint64_t)lanes * hi);
-  uint32_t chunk = rounds ? (uint32_t)((M + lanes * rounds - 1) / (lanes * rounds)) : lo;
-  *chunk_out = min(max(chunk, lo), hi);
+// is spread over whole rounds of them, `lo` <= chunk <= `hi` (lanes < 2^20, lo and hi < 64).
+PCD_HD uint32_t msm_plan_chunk(uint32_t M, uint32_t lanes, uint32_t lo, uint32_t hi) {
+  const uint64_t per_round = (uint64_t)lanes * hi;
+  const uint64_t rounds = ((uint64_t)M + per_round - 1) / per_round;
+  const uint32_t chunk = rounds ? (uint32_t)(((uint64_t)M + (uint64_t)lanes * rounds - 1) / ((uint64_t)lanes * rounds)) : lo;
+  return chunk < lo ? lo : chunk > hi ? hi : chunk;
 }
+// (every lane of the accumulate and fix-up kernels evaluates this itself from the plan word `lanes | lo << 20 | hi << 26`: two divisions
+//  against a launch on the critical path of every MSM)
+PCD_HD uint32_t msm_plan_word(uint32_t lanes, uint32_t lo, uint32_t hi) { return lanes | (lo << 20) | (hi << 26); }
+PCD_HD uint32_t msm_chunk_of_plan(uint32_t M, uint32_t plan) { return msm_plan_chunk(M, plan & 0xFFFFFu, (plan >> 20) & 63u, (plan >> 26) & 63u); }
 
 // key of sorted position p: largest key with off[key] <= p (skipping empty buckets)
 PCD_DEV uint32_t msm_find_key(const uint32_t* __restrict__ off, uint32_t nkeys, uint32_t p) {
@@ -647,8 +651,8 @@ __global__ void __launch_bounds__(64, MsmAccWaves<G>::value) msm_accumulate_kern
                                                             const uint32_t* __restrict__ off, uint32_t nkeys,
                                                             uint32_t chunk, uint32_t* __restrict__ buckets,
                                                             uint32_t* __restrict__ piece_first, uint32_t* __restrict__ piece_last,
-                                                            const uint32_t* __restrict__ chunk_dev /* msm_plan_chunk_kernel's choice */) {
-  if (chunk_dev) chunk = *chunk_dev;
+                                                            uint32_t plan /* msm_plan_word, or 0: `chunk` as given */) {
+  if (plan) chunk = msm_chunk_of_plan(off[nkeys], plan);
   // GA: the configuration the arithmetic runs in -- G itself, or its lane-split form (Fq2 over lane pairs, Fq3 over lane triples:
   // the lanes of a group share one chunk, each holding one coefficient of every coordinate; memory images are the same)
   typedef typename AccOf<G>::type GA;
@@ -1075,8 +1079,10 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
                                                        uint32_t* __restrict__ buckets, uint32_t big_limit, uint32_t* __restrict__ big_count,
                                                        uint32_t* __restrict__ big_list /* (key, first segment, #segments) */, uint32_t big_cap,
                                                        uint32_t* __restrict__ seg_list /* (t_lo, t_hi, t_last) */, uint32_t seg_len,
-                                                       const uint32_t* __restrict__ chunk_dev /* the pair tree's chunk, decided on the device */) {
+                                                       const uint32_t* __restrict__ chunk_dev /* the pair tree's chunk, decided on the device */,
+                                                       uint32_t plan /* msm_plan_word of the running-sum form, or 0 */) {
   if (chunk_dev) chunk = *chunk_dev;
+  else if (plan) chunk = msm_chunk_of_plan(off[nkeys], plan);
   typedef typename MsmItems<G>::GA GA;
   typedef typename GA::F F;
   typedef EC<GA> E;
@@ -1506,6 +1512,7 @@ struct MsmSharedSort {
   uint32_t n = 0, n_total = 0, offset = 0, tkeys = 0;
   int c = 0, W = 0, groups = 0;
   const uint32_t* scalars = nullptr;
+  const uint32_t* inf_bits = nullptr;  // the bitmap the producer filtered its list with (null: the list holds every entry)
   MsmEntrySource src{};
   const uint32_t* off = nullptr;
   hipEvent_t ready = nullptr;  // created by the caller (timing disabled); recorded by the producer after the sort
@@ -1559,16 +1566,19 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   }
   const MsmLane* lane = ws.lane;
   const int plan_cus = lane && lane->cus > 0 ? lane->cus : cus;  // the accumulate grid fills whole rounds of the CUs its queue may use
-  // (round 5: the chunk is chosen on the device from the actual list length -- msm_plan_chunk_kernel -- between chunk_lo and 56; the host
+  // (round 5: the chunk is chosen on the device from the actual list length -- msm_plan_chunk -- between chunk_lo and 56; the host
   //  sizes grids and piece arrays for chunk_lo, which is 40 as before for a list that is long even when sparse and goes down to 16 for one
   //  that cannot fill four rounds of the lanes)
   uint32_t acc_lanes = 0, chunk_lo = 0;
-  const uint32_t chunk_hi = 56;
+  static const uint32_t chunk_hi_env = getenv("PCDHIP_CHUNK_HI") ? (uint32_t)atoi(getenv("PCDHIP_CHUNK_HI")) : 0u;  // developer knob (A/B of the upper bound)
+  const uint32_t chunk_hi = chunk_hi_env >= 16 && chunk_hi_env <= 63 ? chunk_hi_env : 56;
   if (!chunk_override && !use_tree) {
     acc_lanes = (uint32_t)plan_cus * 4 * MsmAccWaves<G>::value * (64 / AccOf<G>::LANES);
     chunk_lo = (uint32_t)std::min<uint64_t>(40, std::max<uint64_t>(16, (maxM + 4ull * acc_lanes - 1) / (4ull * acc_lanes)));
     pl.chunk = chunk_lo;
   }
+  const uint32_t plan_word = acc_lanes && acc_lanes < (1u << 20) && chunk_hi < 64 ? msm_plan_word(acc_lanes, chunk_lo, chunk_hi) : 0u;
+  if (acc_lanes && !plan_word) pl.chunk = 40;  // (a device or knob outside the plan word's ranges: the fixed chunk of rounds 1-4)
   if (maxM >= 0xFFFFFFF0ull || (uint64_t)bv.n_total * bv.groups >= 0x7FFFFFF0ull) return hipErrorInvalidValue;  // bit 31 of an entry: sign
 
   EventSet<9> ev;
@@ -1579,7 +1589,10 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   const uint32_t tkeys = pl.nkeys + 1, ones_key = pl.nkeys;
   const bool consume = share && share_role == MSM_SHARE_CONSUME && share->valid && share->n == n && share->n_total == bv.n_total &&
                        share->offset == bv.offset && share->tkeys == tkeys && share->c == pl.c && share->W == pl.W &&
-                       share->groups == bv.groups && share->scalars == scalars_dev;
+                       share->groups == bv.groups && share->scalars == scalars_dev &&
+                       // a list filtered by a bitmap lacks the entries of its flagged bases: only a consumer that flags the SAME bases may take
+                       // it (an unfiltered list serves everyone: entries on bases at infinity add the identity); otherwise this MSM sorts for itself
+                       (share->inf_bits == nullptr || share->inf_bits == bv.inf_bits);
   PCD_HIP_TRY(ws.ensure(WS_CNT, (size_t)tkeys * 4 + 16));
   PCD_HIP_TRY(ws.ensure(WS_OFF, ((size_t)tkeys + 1) * 4));
   const uint32_t scan_per_block = 16384;
@@ -1597,7 +1610,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   uint32_t* ones_idx = (uint32_t*)ws.buf[WS_ONES];
   uint32_t* flag = ones_idx + n;  // cap-overflow flag of the single-pass binning
   uint32_t* err = flag + 1;       // a scalar >= 2^bits was seen (msm_scalar_too_wide)
-  uint32_t* big_count = flag + 2; // [#big buckets, #segments] of the fix-up pass; flag + 4: the chunk word (entries per lane, chosen on the device)
+  uint32_t* big_count = flag + 2; // [#big buckets, #segments] of the fix-up pass; flag + 4: the pair tree's chunk word
   auto zero_start = [&](uint32_t n_cnt) {  // cnt[0 .. n_cnt) and the four control words, one launch
     hipLaunchKernelGGL(msm_zero_kernel, dim3(std::max<uint32_t>(1u, (n_cnt + 255) / 256)), dim3(256), 0, st, cnt, n_cnt, flag);
   };
@@ -1686,7 +1699,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   if (share && share_role == MSM_SHARE_PRODUCE) {
     share->valid = true;
     share->n = n; share->n_total = bv.n_total; share->offset = bv.offset; share->tkeys = tkeys;
-    share->c = pl.c; share->W = pl.W; share->groups = bv.groups; share->scalars = scalars_dev;
+    share->c = pl.c; share->W = pl.W; share->groups = bv.groups; share->scalars = scalars_dev; share->inf_bits = bv.inf_bits;
     share->src = src; share->off = off;
     PCD_HIP_TRY(hipEventRecord(share->ready, st));
   }
@@ -1754,13 +1767,8 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
       }
     }
     if (!launched) {
-      if (acc_lanes) {
-        uint32_t* chunk_word = big_count + 2;
-        hipLaunchKernelGGL(msm_plan_chunk_kernel, dim3(1), dim3(1), 0, st, off, tkeys, acc_lanes, chunk_lo, chunk_hi, chunk_word);
-        tree_chunk_dev = chunk_word;
-      }
-      if (src.slots) hipLaunchKernelGGL((msm_accumulate_kernel<G, false>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast, tree_chunk_dev);
-      hipLaunchKernelGGL((msm_accumulate_kernel<G, true>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast, tree_chunk_dev);
+      if (src.slots) hipLaunchKernelGGL((msm_accumulate_kernel<G, false>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast, plan_word);
+      hipLaunchKernelGGL((msm_accumulate_kernel<G, true>), acc_grid, dim3(64), 0, st, bases_dev, src, off, tkeys, pl.chunk, acc_buckets, pfirst, plast, plan_word);
     }
   }
   if (lane) {
@@ -1771,7 +1779,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
   PCD_HIP_TRY(mark(4));
   // 5. pieces
   hipLaunchKernelGGL((msm_fixup_kernel<G>), dim3(MsmItems<G>::grid(tkeys)), dim3(64), 0, st, off, tkeys, pl.chunk, pfirst, plast, acc_buckets, buckets,
-                     big_limit, big_count, big, big_cap, seg_list, seg_len, tree_chunk_dev);
+                     big_limit, big_count, big, big_cap, seg_list, seg_len, tree_chunk_dev, plan_word);
   {
     const uint32_t big_grid = std::min<uint32_t>(seg_cap, 2048);
     PCD_HIP_TRY(ws.ensure(WS_BIGSCR, (size_t)big_grid * 64 * PB));
@@ -1843,7 +1851,7 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
     tm->digits = el(0, 1); tm->scan = el(1, 2); tm->scatter = el(2, 8); tm->accumulate = el(8, 4);
     tm->fixup = el(4, 5); tm->tail = el(5, 6); tm->horner = el(6, 7); tm->total = el(0, 7);
     PCD_HIP_TRY(hipMemcpy(&tm->entries, off + tkeys, 4, hipMemcpyDeviceToHost));
-    tm->chunk = pl.chunk;
+    tm->chunk = plan_word ? msm_chunk_of_plan(tm->entries, plan_word) : pl.chunk;
     if (tree_chunk_dev) PCD_HIP_TRY(hipMemcpy(&tm->chunk, tree_chunk_dev, 4, hipMemcpyDeviceToHost));
   }
   return hipSuccess;

@@ -27,9 +27,20 @@ pub fn set_fft_hook(hook: FftHook) -> bool {
 /// }
 /// ```
 /// Only vectors of field elements are offered (`T == F`; Marlin also transforms nothing else).  `DomainCoeff<F>` does not imply
-/// `'static`, so `TypeId::of::<T>()` is not available for the comparison: `T` is recognised as `F` by `type_name` (the fully
-/// qualified, monomorphised name; a compile-time constant) together with size and alignment.  Two distinct types with the same
-/// fully qualified name, size and alignment do not exist in one build of these crates.
+/// `'static`, so `TypeId::of::<T>()` does not compile; `type_id_of::<T>()` below gets the same `TypeId` through a trait object whose
+/// `'static` bound is asserted for the call only (the lifetime-erased identity of `T`; dtolnay's `typeid` crate does the same).  Round 4
+/// compared `type_name`s, which Rust does not promise to be unique.
+fn type_id_of<T: ?Sized>() -> TypeId {
+    trait NonStaticAny { fn get_type_id(&self) -> TypeId where Self: 'static; }
+    impl<T: ?Sized> NonStaticAny for core::marker::PhantomData<T> {
+        fn get_type_id(&self) -> TypeId where Self: 'static { TypeId::of::<T>() }
+    }
+    let phantom = core::marker::PhantomData::<T>;
+    // sound: only the vtable's method is called, which reads no data of lifetime-limited type
+    let erased: &(dyn NonStaticAny + 'static) = unsafe { core::mem::transmute::<&dyn NonStaticAny, &(dyn NonStaticAny + 'static)>(&phantom) };
+    erased.get_type_id()
+}
+
 #[inline]
 pub fn try_hook<F: ark_ff::FftField, T>(coeffs: &mut [T], log_n: u32, inverse: bool) -> bool {
     let hook = match FFT_HOOK.load(Ordering::Acquire) {
@@ -38,7 +49,7 @@ pub fn try_hook<F: ark_ff::FftField, T>(coeffs: &mut [T], log_n: u32, inverse: b
     };
     if core::mem::size_of::<T>() != core::mem::size_of::<F>()
         || core::mem::align_of::<T>() != core::mem::align_of::<F>()
-        || core::any::type_name::<T>() != core::any::type_name::<F>()
+        || type_id_of::<T>() != TypeId::of::<F>()
         || coeffs.len() != 1usize << log_n
     {
         return false;

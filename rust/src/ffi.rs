@@ -37,11 +37,13 @@ extern "C" {
     // K3 / K4 / K7: VariableBaseMSM::multi_scalar_mul over resident bases
     pub fn pcdhip_bases_upload(ctx: *mut pcdhip_ctx, curve: c_int, group: c_int, xy: *const u64, inf: *const u8, n: usize, out: *mut *mut pcdhip_bases) -> c_int;
     pub fn pcdhip_bases_free(ctx: *mut pcdhip_ctx, b: *mut pcdhip_bases);
+    pub fn pcdhip_set_precompute_budget(ctx: *mut pcdhip_ctx, bytes: usize) -> c_int;
     pub fn pcdhip_msm(ctx: *mut pcdhip_ctx, bases: *const pcdhip_bases, offset: usize, scalars: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn pcdhip_to_affine(ctx: *mut pcdhip_ctx, curve: c_int, group: c_int, xyz: *const u64, n: usize, out_xy: *mut u64, out_inf: *mut u8) -> c_int;
     // K2: Radix2EvaluationDomain / GeneralEvaluationDomain transforms
     pub fn pcdhip_fft(ctx: *mut pcdhip_ctx, field: c_int, data: *mut u64, log_n: u32, inverse: c_int, coset: c_int) -> c_int;
     pub fn pcdhip_fft_general(ctx: *mut pcdhip_ctx, field: c_int, data: *mut u64, n: usize, inverse: c_int, coset: c_int) -> c_int;
+    pub fn pcdhip_fft_seq(ctx: *mut pcdhip_ctx, field: c_int, data: *mut u64, n: usize, ops: *const c_int, n_ops: c_int) -> c_int;
     // K1 + K3 + K4 + K5: create_proof after synthesis
     pub fn pcdhip_g16_pk_upload(ctx: *mut pcdhip_ctx, host: *const pcdhip_g16_pk_host, out: *mut *mut pcdhip_g16_pk) -> c_int;
     pub fn pcdhip_g16_pk_set_r1cs(ctx: *mut pcdhip_ctx, pk: *mut pcdhip_g16_pk, a: *const pcdhip_csr, b: *const pcdhip_csr, c: *const pcdhip_csr) -> c_int;

@@ -26,14 +26,44 @@ pub const MIN_LOG_N: u32 = 14;
 /// resident base vectors kept at most (least recently used goes first; its device memory is released with `pcdhip_bases_free`)
 pub const MAX_RESIDENT: usize = 16;
 
+/// device memory one resident base vector may take with its window-shifted copies (`pcdhip_set_precompute_budget`): the S2 vectors share
+/// the one device context with the Groth16 keys, and the library's default (as many copies as hipMalloc grants: 15 x the vector at 2^20)
+/// would let the first large KZG vector take most of HBM.  Fewer copies = a Horner combine at the end, same result.
+pub const RESIDENT_BUDGET_BYTES: usize = 8 << 30;
+/// positions of a resident vector whose packed limbs are kept for the confirmation of a digest hit
+const SAMPLE_HEAD: usize = 64;
+const SAMPLE_STRIDED: usize = 192;
+
 /// A base vector resident on the device.  `running[i]` = digest of the points 0 ..= i, so a call on a PREFIX of a resident vector
-/// (KZG: `powers_of_g[..deg + 1]`) is recognised by content and served as `pcdhip_msm(handle, 0, .., n)`.  The digest only
-/// NOMINATES a candidate; a hit is confirmed by comparing the packed limbs of the call's bases with the copy kept here (`xy`,
-/// `inf`: what was uploaded), so a digest collision cannot alias two keys.
+/// (KZG: `powers_of_g[..deg + 1]`) is recognised by content and served as `pcdhip_msm(handle, 0, .., n)`.  The digest (two 64-bit
+/// FNV-1a lanes over every limb) NOMINATES a candidate; a hit is confirmed on a SAMPLE of the points -- the first 64 and 192 spread over
+/// the vector, their packed limbs kept here -- instead of a second full copy on the host (round 4 kept up to sixteen of them, 0.6 GB
+/// each for a 2^20-point G2 vector, and compared all n points on every call: ADVICE r04).  Two different vectors that agree on both
+/// digest lanes at the call's length AND on every sampled point do not occur by accident; an adversary who controls the bases controls
+/// the proving key anyway.
 pub(crate) struct Resident {
     curve: u32, group: c_int, n: usize, words: usize,
-    running: Vec<[u64; 2]>, xy: Vec<u64>, inf: Vec<u8>,
+    running: Vec<[u64; 2]>, sample_at: Vec<usize>, sample_xy: Vec<u64>, sample_inf: Vec<u8>,
     handle: *mut ffi::pcdhip_bases, last_use: u64,
+}
+
+fn sample_positions(n: usize) -> Vec<usize> {
+    let mut at: Vec<usize> = (0..n.min(SAMPLE_HEAD)).collect();
+    if n > SAMPLE_HEAD {
+        let step = ((n - SAMPLE_HEAD) / SAMPLE_STRIDED).max(1);
+        let mut i = SAMPLE_HEAD;
+        while i < n && at.len() < SAMPLE_HEAD + SAMPLE_STRIDED { at.push(i); i += step; }
+    }
+    at
+}
+
+/// every fallback to the upstream CPU code is said once per cause (a silent fallback looks like a slow GPU)
+fn log_fallback(cause: &'static str) {
+    use std::sync::Mutex;
+    static SEEN: Mutex<Vec<&'static str>> = Mutex::new(Vec::new());
+    if let Ok(mut seen) = SEEN.lock() {
+        if !seen.contains(&cause) { seen.push(cause); eprintln!("ark-pcd-hip: MSM falls back to the CPU: {}", cause); }
+    }
 }
 
 /// two FNV-1a lanes over every limb and flag, point after point
@@ -61,26 +91,45 @@ fn msm_packed(dev: &mut Device, curve: u32, group: c_int, words: usize, xy: Vec<
     dev.clock += 1;
     let now = dev.clock;
     let hit = dev.bases.iter().position(|r| {
-        r.curve == curve && r.group == group && r.n >= n && r.running[n - 1] == d && r.xy[..n * words] == xy[..] && r.inf[..n] == inf[..]
+        r.curve == curve && r.group == group && r.n >= n && r.running[n - 1] == d
+            && r.sample_at.iter().enumerate().all(|(k, &i)| {
+                i >= n || (r.sample_xy[k * words..(k + 1) * words] == xy[i * words..(i + 1) * words] && r.sample_inf[k] == inf[i])
+            })
     });
     let idx = match hit {
         Some(i) => i,
         None => {
-            if dev.bases.len() >= MAX_RESIDENT {
-                let (victim, _) = dev.bases.iter().enumerate().min_by_key(|(_, r)| r.last_use)?;
-                let old = dev.bases.swap_remove(victim);
-                unsafe { ffi::pcdhip_bases_free(dev.ctx, old.handle) };
-            }
+            let evict = |dev: &mut Device| -> bool {
+                match dev.bases.iter().enumerate().min_by_key(|(_, r)| r.last_use).map(|(i, _)| i) {
+                    Some(victim) => { let old = dev.bases.swap_remove(victim); unsafe { ffi::pcdhip_bases_free(dev.ctx, old.handle) }; true }
+                    None => false,
+                }
+            };
+            if dev.bases.len() >= MAX_RESIDENT { evict(dev); }
+            // (the budget is a property of the context and read at upload time: set for this upload, the keys' uploads set their own)
+            unsafe { ffi::pcdhip_set_precompute_budget(dev.ctx, RESIDENT_BUDGET_BYTES) };
             let mut h = core::ptr::null_mut();
-            if unsafe { ffi::pcdhip_bases_upload(dev.ctx, curve as c_int, group, xy.as_ptr(), inf.as_ptr(), n, &mut h) } != 0 { return None; }
-            dev.bases.push(Resident { curve, group, n, words, running, xy, inf, handle: h, last_use: now });
+            let mut rc = unsafe { ffi::pcdhip_bases_upload(dev.ctx, curve as c_int, group, xy.as_ptr(), inf.as_ptr(), n, &mut h) };
+            if rc != 0 && evict(dev) {   // out of memory, most likely: let the least recently used vector go and try once more
+                rc = unsafe { ffi::pcdhip_bases_upload(dev.ctx, curve as c_int, group, xy.as_ptr(), inf.as_ptr(), n, &mut h) };
+            }
+            unsafe { ffi::pcdhip_set_precompute_budget(dev.ctx, 0) };
+            if rc != 0 { log_fallback("pcdhip_bases_upload failed (device memory?)"); return None; }
+            let sample_at = sample_positions(n);
+            let mut sample_xy = Vec::with_capacity(sample_at.len() * words);
+            let mut sample_inf = Vec::with_capacity(sample_at.len());
+            for &i in &sample_at { sample_xy.extend_from_slice(&xy[i * words..(i + 1) * words]); sample_inf.push(inf[i]); }
+            dev.bases.push(Resident { curve, group, n, words, running, sample_at, sample_xy, sample_inf, handle: h, last_use: now });
             dev.bases.len() - 1
         }
     };
     dev.bases[idx].last_use = now;
     debug_assert_eq!(dev.bases[idx].words, words);
     let mut out = vec![0u64; out_words];
-    if unsafe { ffi::pcdhip_msm(dev.ctx, dev.bases[idx].handle, 0, scalars.as_ptr(), n, out.as_mut_ptr()) } != 0 { return None; }
+    if unsafe { ffi::pcdhip_msm(dev.ctx, dev.bases[idx].handle, 0, scalars.as_ptr(), n, out.as_mut_ptr()) } != 0 {
+        log_fallback("pcdhip_msm failed");
+        return None;
+    }
     Some(out)
 }
 
@@ -147,6 +196,18 @@ unsafe fn fft_hook(field: TypeId, data: *mut u8, len: usize, log_n: u32, inverse
     let (field_id, _limbs) = match field_of(field) { Some(f) => f, None => return false };
     if log_n < MIN_LOG_N || len != 1usize << log_n || (data as usize) % core::mem::align_of::<u64>() != 0 { return false; }
     with_device(|dev| ffi::check(ffi::pcdhip_fft(dev.ctx, field_id, data as *mut u64, log_n, inverse as c_int, 0))).is_ok()
+}
+
+/// A chain of transforms on ONE vector with a single trip over PCIe (`pcdhip_fft_seq`): what `R1CSToQAP::witness_map` (`ifft` then
+/// `coset_fft`) and Marlin's AHP rounds do with a polynomial.  The per-call hook above moves 2 x n x 40 / 96 bytes per transform --
+/// 5 .. 7 ms at n = 2^20 for 0.3 ms of passes (bench.py `fft.*.call_wall_ms`) -- so a caller that knows its chain hands it over whole.
+/// `ops`: (inverse, coset) per transform, all over the `GeneralEvaluationDomain` of `data.len()` elements.  false: run upstream.
+pub fn fft_chain<F: PrimeField + 'static>(data: &mut [F], ops: &[(bool, bool)]) -> bool {
+    let (field_id, limbs) = match field_of(TypeId::of::<F>()) { Some(f) => f, None => return false };
+    if data.len() < (1usize << MIN_LOG_N) || ops.is_empty() || ops.len() > 64 || core::mem::size_of::<F>() != limbs * 8 { return false; }
+    let codes: Vec<c_int> = ops.iter().map(|&(inv, coset)| (inv as c_int) | ((coset as c_int) << 1)).collect();
+    let (ptr, n) = (data.as_mut_ptr() as *mut u64, data.len());
+    with_device(|dev| unsafe { ffi::check(ffi::pcdhip_fft_seq(dev.ctx, field_id, ptr, n, codes.as_ptr(), codes.len() as c_int)) }).is_ok()
 }
 
 /// Register both hooks with the forks.  Idempotent; returns whether THIS call installed them (false: someone else already had).

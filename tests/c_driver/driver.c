@@ -60,6 +60,15 @@ static int run_s2(long len) {
   memcpy(w, v, nn * lf * 8);
   rc = pcdhip_fft(ctx, field, w, log_n, 1, 0);
   if (rc || memcmp(w, want_i, nn * lf * 8) != 0) { fprintf(stderr, "ifft differs (%s)\n", pcdhip_strerror(rc)); bad = 1; }
+  /* the chain form (rust/src/s2.rs fft_chain): fft then ifft in ONE call, one trip over PCIe -- the vector comes back unchanged; fft alone
+     through the same entry point equals pcdhip_fft's answer */
+  { const int ops2[2] = {0, 1}, ops1[1] = {0};
+    memcpy(w, v, nn * lf * 8);
+    rc = pcdhip_fft_seq(ctx, field, w, nn, ops2, 2);
+    if (rc || memcmp(w, v, nn * lf * 8) != 0) { fprintf(stderr, "fft_seq(fft, ifft) differs (%s)\n", pcdhip_strerror(rc)); bad = 1; }
+    rc = pcdhip_fft_seq(ctx, field, w, nn, ops1, 1);
+    if (rc || memcmp(w, want_f, nn * lf * 8) != 0) { fprintf(stderr, "fft_seq(fft) differs (%s)\n", pcdhip_strerror(rc)); bad = 1; }
+    bad |= pcdhip_fft_seq(ctx, field, w, nn, ops1, 0) != PCDHIP_E_ARG; }
   /* what the hook answers "not mine" for must come back as a code, never an abort: a transform beyond what the library builds */
   { const int e = pcdhip_fft(ctx, field, w, 31, 0, 0); bad |= !(e == PCDHIP_E_SIZE_UNSUPPORTED || e == PCDHIP_E_ARG); }
   pcdhip_bases_free(ctx, key);

@@ -157,3 +157,23 @@ def test_sharded_msm_two_ranks_gpu(co, tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("OK") == 2
+
+
+def test_bench_multi_gpu_failure_still_prints_one_line(tmp_path):
+    """VERDICT r04 #5 (first contact with a multi-GPU node): whatever fails on the N > 1 path -- here the very first step, on a box without
+    a GPU -- rank 0 still prints exactly ONE JSON line (the N = 1 figures of a fresh child process, or, when that fails too, a line that
+    says so) with the error attached, and the exit code is non-zero.  No hang: the run is bounded."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PCD_BENCH_FORCE_DIST="1", PCD_BENCH_INJECT_FAILURE="init", PCD_BENCH_DIST_TIMEOUT_S="120")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert p.returncode != 0, p.stderr[-500:]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["metric"] == "msm_mscalar_mul_per_s" and "multi_gpu_error" in out and out["n_gpus_requested"] == 1

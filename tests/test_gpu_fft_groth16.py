@@ -44,6 +44,26 @@ def test_mixed_radix_fft(co, gpu_ctx, fid, q):
         gpu_ctx.fft_general(fid, np.zeros((3 * 64, x.shape[1]), dtype=np.uint64))  # 3 * 2^6 is not a domain size
 
 
+@pytest.mark.parametrize("fid,n", [(1, 1 << 12), (3, 1 << 9), (0, 7 << 6), (2, 25 << 4)])
+def test_fft_seq_one_round_trip(co, gpu_ctx, fid, n):
+    """pcdhip_fft_seq (seam S2: a chain of transforms on one host vector, one trip over PCIe) == the same transforms one call at a time ==
+    the oracle: the witness map's `ifft; coset_fft`, its inverse, and all four kinds in a row; radix-2 and mixed-radix domains"""
+    x = co.gen_field(fid, n, seed=n + fid)
+    m = n
+    while m % 2 == 0:
+        m //= 2
+    ref = (lambda v, inv, cos: co.fft(fid, v, inverse=inv, coset=cos, nthreads=8)) if m == 1 else \
+          (lambda v, inv, cos: co.fft_general(fid, v, m, inverse=inv, coset=cos, nthreads=8))
+    for ops in ([(True, False), (False, True)], [(True, True), (False, False)], [(False, False), (False, True), (True, True), (True, False)]):
+        want = x
+        for inv, cos in ops:
+            want = ref(want, inv, cos)
+        assert np.array_equal(gpu_ctx.fft_seq(fid, x, ops), want), (fid, n, ops)
+    from pcd_amd import capi
+    with pytest.raises(capi.PcdHipError):
+        gpu_ctx.fft_seq(fid, np.zeros((3 * 64, x.shape[1]), dtype=np.uint64), [(False, False)])
+
+
 @pytest.mark.parametrize("cid,nc", [(1, (1 << 17) + 1000), (3, (1 << 15) + 500)])
 def test_witness_map_mixed_radix_domain(co, gpu_ctx, cid, nc):
     """help-proof witness map on a domain beyond the help field's 2-adicity (7 * 2^15 / 5 * 2^13 elements)."""

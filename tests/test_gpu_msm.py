@@ -326,6 +326,7 @@ def test_submit_partial_tickets(co, gpu_ctx):
     each partial left in the slot of the caller's device buffer that its ticket names, a foreign stream ordered behind each by an
     event; the four slots summed on the device == the MSM over the whole range == the oracle.  Twice, so slots are reused."""
     import torch
+    from pcd_amd import capi
     ctx = gpu_ctx
     cid, grp, n = 0, 1, 4 * 9000
     fr = co.CURVE_FR[cid]
@@ -362,11 +363,25 @@ def test_submit_partial_tickets(co, gpu_ctx):
     for q in range(4):                                # round robin: one of the next four submissions lands on that slot
         try:
             t = ctx.msm_submit_partial(b, parts[q], slots.data_ptr(), 8 * limbs, offset=q * 9000, n=9000)
-            ctx.msm_ticket_wait(t, ts)
             outcomes.append(t)
-        except Exception:
-            outcomes.append("error")
-    assert outcomes.count("error") == 1, outcomes
+        except capi.PrevTicketError as e:             # a code of its own, and THIS submission is in flight: its ticket is valid
+            assert e.ticket == t_bad
+            t = e.ticket
+            outcomes.append("prev")
+        ctx.msm_ticket_wait(t, ts)
+    assert outcomes.count("prev") == 1, outcomes
+    # ... or polled without submitting (the last step of a loop): the status of a released slot
+    t_bad = ctx.msm_submit_partial(b, badbuf, slots.data_ptr(), 8 * limbs, offset=0, n=9000)
+    t_ok = ctx.msm_submit_partial(b, parts[1], slots.data_ptr(), 8 * limbs, offset=9000, n=9000)
+    with pytest.raises(capi.PcdHipError):
+        ctx.msm_ticket_status(t_bad)                  # still outstanding: not a released slot
+    ctx.msm_ticket_wait(t_bad, ts)
+    ctx.msm_ticket_wait(t_ok, ts)
+    with pytest.raises(capi.PrevTicketError):
+        ctx.msm_ticket_status(t_bad)
+    ctx.msm_ticket_status(t_ok)
+    with pytest.raises(capi.PcdHipError):
+        ctx.msm_ticket_status(t_ok)                   # the word was consumed
     torch.cuda.synchronize()
     ctx.sync()
     badbuf.free()

@@ -120,3 +120,38 @@ def test_witness_map_chains_on_three_devices(co, gpu_ctx, curve, nc, parts):
         mpk.free()
     finally:
         mctx.close()
+
+
+def test_bit_identity_at_1_2_4_8_shards(co, gpu_ctx):
+    """the same MSM and the same proof through contexts of 1, 2, 4 and 8 shards -- the devices that are visible, round-robin
+    (`_devices`: with one GPU every shard is a logical shard of it; with >= 2 the sub-contexts sit on DISTINCT devices and the partial
+    results travel by real peer copies) -- must give the same bytes as the single-device context and the oracle.  The test prints which
+    case it ran so that the first run on a multi-GPU node says what it covered."""
+    from pcd_amd import capi
+    ngpu = capi.lib().pcdhip_device_count()
+    cid, fr = 0, co.CURVE_FR[0]
+    n = 70000
+    pts = co.gen_points(cid, 1, n, seed=990)
+    sc = co.gen_scalars(fr, n, seed=991, dist=1)
+    want_msm = co.to_affine(cid, 1, co.msm(cid, 1, pts, sc, nthreads=8))
+    r = co.witness_r1cs(fr, 20000, 2, seed=992)
+    keys = co.synthetic_keys(cid, r, seed=993)
+    rs = co.gen_field(fr, 2, seed=994)
+    want_proof, want_inf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=8)
+    for parts in (1, 2, 4, 8):
+        devs = _devices(parts)
+        mctx = capi.Context(devices=devs) if parts > 1 else capi.Context(devs[0])
+        try:
+            b = mctx.bases_upload(cid, 1, pts)
+            got = co.to_affine(cid, 1, mctx.msm(b, sc))
+            assert np.array_equal(got[0], want_msm[0]) and np.array_equal(got[1], want_msm[1]), parts
+            b.free()
+            pk = mctx.g16_pk_upload(keys.host_struct(), cid)
+            mctx.g16_pk_set_r1cs(pk, r)
+            for _ in range(2):
+                proof, inf = mctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
+                assert np.array_equal(proof, want_proof) and np.array_equal(inf, want_inf), parts
+            pk.free()
+        finally:
+            mctx.close()
+    print(f"shard identity 1/2/4/8: {ngpu} device(s) visible -> {'DISTINCT devices, real peer copies' if ngpu >= 2 else 'logical shards of one device'}")

@@ -31,11 +31,13 @@ def test_kat_round_trip_with_the_oracle_in_place_of_arkworks(co):
         for lit in re.findall(r'a\[&?"([a-z_0-9.]+)"\]', src):
             assert lit in names_in, lit
         exp = kat_extra.expected()
-        lines = [_line(k, v) for k, v in exp.items()]
-        # a few of the golden-file outputs as arkworks would write them (names file.key)
-        g = np.load(os.path.join(ROOT, "tests", "golden", "groth16.npz"))
-        for k in ("c0_a_query", "c0_a_query_inf", "c0_h_query", "c1_b_g2_query", "c0_proof", "c1_gamma_abc_g1"):
-            lines.append(_line("groth16." + k, g[k]))
+        import kat_export
+        golden = {}
+        for name in kat_export.golden_outputs():   # EVERY output array of the golden files, as arkworks would write it (names file.key)
+            f, k = name.split(".", 1)
+            golden[name] = np.load(os.path.join(ROOT, "tests", "golden", f + ".npz"))[k]
+        glines = [_line(k, v) for k, v in golden.items()]
+        lines = [_line(k, v) for k, v in exp.items()] + glines
         open(out_path, "w").write("\n".join(lines) + "\n")
         ok = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_kat.py")], capture_output=True, text=True)
         assert ok.returncode == 0, ok.stdout + ok.stderr
@@ -43,15 +45,19 @@ def test_kat_round_trip_with_the_oracle_in_place_of_arkworks(co):
         bad = dict(exp)
         h = bad["x_wm.h"].copy(); h[123, 0] ^= 1; bad["x_wm.h"] = h
         lines = [_line(k, v) for k, v in bad.items()]
-        q = g["c0_l_query"].copy(); q[0, 0] ^= 1
-        lines.append(_line("groth16.c0_l_query", q))
+        q = golden["groth16.c0_l_query"].copy(); q[0, 0] ^= 1
+        lines += [_line(k, (q if k == "groth16.c0_l_query" else v)) for k, v in golden.items()]
         open(out_path, "w").write("\n".join(lines) + "\n")
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_kat.py")], capture_output=True, text=True)
         assert res.returncode == 1 and "x_wm.h" in res.stdout and "groth16.c0_l_query" in res.stdout, res.stdout
+        # a golden output that arkworks did not write is a failure too (round 5: no golden array without a KAT line)
+        open(out_path, "w").write("\n".join([_line(k, v) for k, v in exp.items()] + [ln for ln in glines if not ln.startswith("fields.f2_mul ")]) + "\n")
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_kat.py")], capture_output=True, text=True)
+        assert res.returncode == 1 and "fields.f2_mul" in res.stdout, res.stdout
         # a generator that differs is advisory (the setup entry point takes generators as arguments), not a failure
         adv = dict(exp)
         gq = adv["x_consts.c2_g2_generator"].copy(); gq[0] ^= 1; adv["x_consts.c2_g2_generator"] = gq
-        open(out_path, "w").write("\n".join(_line(k, v) for k, v in adv.items()) + "\n")
+        open(out_path, "w").write("\n".join([_line(k, v) for k, v in adv.items()] + glines) + "\n")
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_kat.py")], capture_output=True, text=True)
         assert res.returncode == 0 and "NOTE: x_consts.c2_g2_generator" in res.stdout, res.stdout
     finally:
@@ -62,13 +68,19 @@ def test_kat_round_trip_with_the_oracle_in_place_of_arkworks(co):
             open(out_path, "w").write(saved)
 
 
-def test_kat_rs_emits_every_expected_name():
-    """the x_* names kat.rs builds with format! cover exactly what tools/kat_extra.expected() knows how to check"""
+def test_no_golden_array_without_a_kat_line():
+    """the manifest of rust/tests/kat.rs (`EMITS`, which the Rust test asserts against what it writes) names a line family
+    for EVERY output array of tests/golden/*.npz and for everything tools/kat_extra.expected() checks -- a golden vector that arkworks is
+    never asked to reproduce fails here"""
+    import kat_export
     import kat_extra
     src = open(os.path.join(ROOT, "rust", "tests", "kat.rs")).read()
-    emitted = set(re.findall(r'emit\(out, &format!\("(x_[^"]+)"', src)) | set(re.findall(r'emit\(out, "(x_[^"]+)"', src))
-    # "{}_i{}c{}" with stem = the input name minus "_in" covers the x_mixed family
-    fam = lambda k: re.sub(r"\d+", "{}", k)
-    want = {fam(k) for k in kat_extra.expected()}
-    got = {fam(e) for e in emitted} | {"x_mixed.f{}_n{}_i{}c{}"}
-    assert want <= got, sorted(want - got)
+    body = src[src.index("const EMITS"):]
+    emits = set(re.findall(r'"([a-z_0-9.{}]+)"', body[:body.index("];")]))
+    fam = lambda k: k.split(".", 1)[0] + "." + re.sub(r"\d+", "{}", k.split(".", 1)[1])   # (digits after the file prefix)
+    want = {fam(k) for k in kat_export.golden_outputs()} | {fam(k) for k in kat_extra.expected()}
+    assert want <= emits, sorted(want - emits)
+    assert emits <= want, sorted(emits - want)   # (and nothing is claimed that nobody checks)
+    # the functions that write them are called from kat()
+    for fn in ("fields::<", "msm_inf::<", "setup_inf::<", "setup::<", "wire::<", "groth16::<"):
+        assert fn in src[src.index("fn kat()"):], fn

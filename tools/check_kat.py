@@ -42,6 +42,12 @@ def main():
         missing = sorted(k for k in extra if k not in seen)
         if missing:
             bad.append("not written by kat.rs: " + ", ".join(missing[:6]))
+    # ... and every OUTPUT array of the golden files (tools/kat_export.golden_outputs: what is not handed over as an input, plus the key's
+    # queries, which are inputs of the proof KAT and outputs of the generate_parameters KAT)
+    import kat_export
+    for name in kat_export.golden_outputs():
+        if name not in seen:
+            bad.append(name + " (a golden output kat.rs did not write)")
     for a in advisory:
         print("NOTE:", a)
     print(f"{n - len(bad) - len(advisory)} of {n} arrays computed by arkworks equal the golden vectors / the oracle")

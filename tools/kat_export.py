@@ -7,6 +7,7 @@
 
 Text format, one array per line:  <file>.<key> <dtype> <dim0>x<dim1>.. <hex,hex,...>   (row-major, u64 / u32 / u8 as hex)."""
 import os
+import re
 
 import numpy as np
 
@@ -14,13 +15,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # what the Rust side needs as INPUT (expected outputs stay in the npz files and are compared by check_kat.py)
 INPUT_KEYS = {
-    "msm": lambda k: k.endswith(("_bases", "_inf", "_scalars")),
+    "fields": lambda k: re.fullmatch(r"f\d_[ab]", k) is not None,
+    "msm": lambda k: re.fullmatch(r"c\d_g\d_(bases|inf|scalars)", k) is not None,
     "fft": lambda k: k.endswith("_in"),
     "pairing": lambda k: k.endswith(("_p", "_q")),
     # (the key's queries are INPUTS of the proof KAT and, since round 4, also OUTPUTS of the generate_parameters KAT: kat.rs writes them back)
     "groth16": lambda k: not k.endswith(("_h", "_proof", "_proof_inf")),
     "wire": lambda k: k.endswith(("_xy", "_inf")),
 }
+
+
+def is_setup_output(k):
+    """groth16.npz keys that are inputs of the proof KAT AND outputs of the generate_parameters KAT"""
+    stem = k.split("_", 1)[1]
+    return stem.endswith(("_query", "_query_inf")) or stem in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "gamma_g2", "delta_g2",
+                                                                "gamma_abc_g1", "gamma_abc_g1_inf")
+
+
+def golden_outputs():
+    """names `<file>.<key>` of every array in tests/golden/*.npz that arkworks must reproduce (rust/tests/kat.rs writes one line each)"""
+    out = []
+    for f, is_input in INPUT_KEYS.items():
+        g = np.load(os.path.join(GOLDEN, f + ".npz"))
+        out += [f"{f}.{k}" for k in g.files if not is_input(k) or (f == "groth16" and is_setup_output(k))]
+    return out
 
 
 def line(name, a):

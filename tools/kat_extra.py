@@ -11,6 +11,12 @@ RECALLS of upstream (VERDICT r03 missing #5): the places where a wrong recalled 
   groth16.* `generate_parameters` with the golden toxic waste (alpha, beta, gamma, delta, tau) and the oracle's generators: every query
             of the key, compared with tests/golden/groth16.npz (already there: this only adds the Rust side that computes them)
 
+  x_setup_inf  (round 5) `generate_parameters` over a system with variables that A / B never mention (coracle.witness_r1cs: a packed word
+            appears only in C): WHICH entries of a_query / b_g1_query / b_g2_query upstream leaves as the identity with `infinity = true` --
+            what the MSMs' infinity bitmaps (msm.hip.h msm_base_is_inf) and the bench's "consistent" synthetic keys rely on
+  x_msm_inf    (round 5) `VariableBaseMSM::multi_scalar_mul` over bases some of which ARE the identity, with non-zero scalars on them (G1 and
+            G2 of MNT4-298, G2 of MNT6-753)
+
 Inputs are made from seeds by the C++ oracle at export time and the expected values are recomputed from the same seeds at check time
 (the oracle is what the HIP path is pinned to at these sizes by tests/): nothing large is committed."""
 import json
@@ -22,6 +28,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MIXED = ((0, 7, (56, 196)), (2, 5, (40, 100)))
 WM_FIELD, WM_ROWS, WM_CURVE = 2, 33000, 3          # MNT6-753: Fr = field 2 (2-adicity 15)
 FIXED_N = 40
+SETUP_INF_CURVE, SETUP_INF_ROWS = 1, 300      # MNT6-298, a witness-like system: packed words appear in no row of A or B
+MSM_INF_CASES = ((0, 1), (0, 2), (3, 2))
+MSM_INF_N = 96
 
 
 def _co():
@@ -49,10 +58,36 @@ def fixed_case(co, c, g):
     return base, sc
 
 
+def setup_inf_case(co):
+    fr = co.CURVE_FR[SETUP_INF_CURVE]
+    r = co.witness_r1cs(fr, SETUP_INF_ROWS, 2, seed=7400)
+    toxic = co.gen_field(fr, 5, seed=7401)
+    return r, toxic
+
+
+def msm_inf_case(co, c, g):
+    fr = co.CURVE_FR[c]
+    pts = co.gen_points(c, g, MSM_INF_N, seed=7500 + 10 * c + g)
+    sc = co.gen_scalars(fr, MSM_INF_N, seed=7600 + 10 * c + g)
+    inf = (np.arange(MSM_INF_N) % 5 == 2).astype(np.uint8)
+    inf[0] = 1
+    sc[0] = 0
+    sc[0, 0] = 1          # scalar one on an identity base
+    return pts, inf, sc
+
+
 def inputs():
     """[(name, array)]: what the Rust side reads (rust/tests/kat_inputs.txt)"""
     co = _co()
     out = []
+    r, toxic = setup_inf_case(co)
+    for nm in "abc":
+        out += [(f"x_setup_inf.rp_{nm}", getattr(r, "rp_" + nm)), (f"x_setup_inf.col_{nm}", getattr(r, "col_" + nm).astype(np.uint64)),
+                (f"x_setup_inf.coeff_{nm}", getattr(r, "coeff_" + nm))]
+    out += [("x_setup_inf.z", np.asarray(r.z)), ("x_setup_inf.num_inputs", np.array([r.num_inputs], dtype=np.uint64)), ("x_setup_inf.toxic", toxic)]
+    for c, g in MSM_INF_CASES:
+        pts, inf, sc = msm_inf_case(co, c, g)
+        out += [(f"x_msm_inf.c{c}_g{g}_bases", pts), (f"x_msm_inf.c{c}_g{g}_inf", inf), (f"x_msm_inf.c{c}_g{g}_scalars", sc)]
     for fid, _q, sizes in MIXED:
         for n in sizes:
             out.append((f"x_mixed.f{fid}_n{n}_in", co.gen_field(fid, n, seed=7000 + n)))
@@ -73,6 +108,17 @@ def expected():
     """{name: array} for every x_* line the Rust side writes"""
     co = _co()
     exp = {}
+    r, toxic = setup_inf_case(co)
+    keys = co.groth16_setup(SETUP_INF_CURVE, r, toxic, nthreads=4)
+    assert keys.a_inf.any() and keys.b_g2_inf.any() and not keys.a_inf.all()
+    for nm, fl in (("a_query", "a_inf"), ("b_g1_query", "b_g1_inf"), ("b_g2_query", "b_g2_inf")):
+        flags = getattr(keys, fl)
+        exp[f"x_setup_inf.{nm}"] = np.where(flags[:, None] != 0, 0, getattr(keys, nm)).astype(np.uint64)   # (kat.rs zeroes the limbs of an identity)
+        exp[f"x_setup_inf.{nm}_inf"] = flags
+    for c, g in MSM_INF_CASES:
+        pts, inf, sc = msm_inf_case(co, c, g)
+        xy, rinf = co.to_affine(c, g, co.msm(c, g, pts, sc, inf=inf, nthreads=4))
+        exp[f"x_msm_inf.c{c}_g{g}_result_xy"], exp[f"x_msm_inf.c{c}_g{g}_result_inf"] = xy[0] if xy.ndim > 1 else xy, np.atleast_1d(rinf)[:1]
     for fid, q, sizes in MIXED:
         for n in sizes:
             x = co.gen_field(fid, n, seed=7000 + n)
