@@ -1791,8 +1791,9 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   TRY(hipEventRecord(ev[1], st));
   // (round 5 also tried the map's launches merely ENQUEUED first with the h MSM right behind it and the assignment MSMs after, nothing
   //  gated -- the critical path of a proof over a witness-like assignment is upload -> map -> h MSM: slower everywhere, 11.2 against 8.0 ms
-  //  there, 19.0 against 15.8 ms on a uniform assignment, because the G2 MSM and the one-point products then start last:
-  //  profiles/r05_ab_prove_schedule.txt)
+  //  there, 19.0 against 15.8 ms on a uniform assignment, because the G2 MSM and the one-point products then start last; and mode 0 with only
+  //  the map's launches moved ahead of the MSMs' in host order: no difference beyond noise on either assignment, as in round 4:
+  //  profiles/r05_ab_prove_schedule3.txt)
   if (map_first) { rc = run.launch_assignment_gated(0, m + 4, folded, ev[1]); if (rc) return rc; }  // (lane: no accumulation under the map; the sorts start at once)
   rc = run.launch_h(0, std::min<size_t>(pk->h_query->n, n), ev[1]);
   if (rc) return rc;
