@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 
 #include "common.h"
@@ -604,6 +605,23 @@ static int lane_reserve_of(const pcdhip_ctx* ctx) {
   if (r < 0) { const char* e = getenv("PCDHIP_LANE_RESERVE"); r = e ? atoi(e) : 8; }
   return r < 0 ? 0 : r;
 }
+// CU-masked streams are made once per (device, reserve) and NEVER destroyed: on this stack (ROCm 7.2) hipStreamDestroy of a stream created
+// by hipExtStreamCreateWithCUMask stalls for good now and then once such streams have been created and destroyed before in the process
+// (round 5: a soak that toggled the schedule per proof hung in the second round of destructions, profiles/r05_stress_proof.log).  Contexts
+// of one device share the lane: stream order only adds dependencies between their accumulations, and the mode is not the default.
+static hipStream_t masked_lane_of(int device, int cus, int reserve, hipError_t* err) {
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, hipStream_t> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = pool.find({device, reserve});
+  if (it != pool.end()) { *err = hipSuccess; return it->second; }
+  std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+  for (int i = 0; i < cus - reserve; i++) mask[i / 32] |= 1u << (i % 32);
+  hipStream_t s = nullptr;
+  *err = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
+  if (*err == hipSuccess) pool[{device, reserve}] = s;
+  return s;
+}
 static int ensure_side_streams(pcdhip_ctx* ctx) {
   if (ctx->g16_ready) return PCDHIP_OK;
   int least = 0, greatest = 0;
@@ -611,33 +629,31 @@ static int ensure_side_streams(pcdhip_ctx* ctx) {
   const bool lane_mode = ctx->g16_schedule == 2;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
+  const int normal = (least + greatest) / 2;
   for (int k = 0; k < 6; k++) {
     // The runtime multiplexes the streams of ONE priority over a few hardware queues (three for the high priority on this stack), and two
     // streams that share a queue run in submission order: with four high-priority streams the sort of l' sat in the queue of the B MSM, behind
-    // that MSM's wait for its accumulation -- l' and h started 3 ms late (profiles/r05_pt_lane_aliased.txt: q5 carries s4 AND s5).  A stream
-    // created with a CU mask always gets a hardware queue of its own, so in lane mode the side streams are "masked" with every bit set; the
-    // older schedules keep round 4's priorities (2 high, 1 normal, 3 low).
-    if (lane_mode) {
-      std::vector<uint32_t> all((cus + 31) / 32, 0u);
-      for (int i = 0; i < cus; i++) all[i / 32] |= 1u << (i % 32);
-      TRY(hipExtStreamCreateWithCUMask(&ctx->g16_streams[k], (uint32_t)all.size(), all.data()));
-    } else {
-      TRY(hipStreamCreateWithPriority(&ctx->g16_streams[k], hipStreamNonBlocking, k < 2 ? greatest : k == 2 ? (least + greatest) / 2 : least));
-    }
+    // that MSM's wait for its accumulation on the lane -- l' and h started 3 ms late (profiles/r05_pt_lane_aliased.txt: q5 carries s4 AND s5).
+    // Lane mode therefore spreads its six side streams two per priority (with the context's own stream: three at the normal one); the other
+    // schedules keep round 4's mix (2 high, 1 normal, 3 low).
+    const int prio = lane_mode ? (k < 2 ? greatest : k < 4 ? normal : least) : (k < 2 ? greatest : k == 2 ? normal : least);
+    TRY(hipStreamCreateWithPriority(&ctx->g16_streams[k], hipStreamNonBlocking, prio));
     TRY(hipEventCreate(&ctx->g16_begin[k]));
     TRY(hipEventCreate(&ctx->g16_end[k]));
   }
-  int reserve = lane_reserve_of(ctx);
-  if (reserve >= cus) reserve = 0;
-  if (reserve > 0) {
-    std::vector<uint32_t> mask((cus + 31) / 32, 0u);
-    for (int i = 0; i < cus - reserve; i++) mask[i / 32] |= 1u << (i % 32);
-    TRY(hipExtStreamCreateWithCUMask(&ctx->lane_stream, (uint32_t)mask.size(), mask.data()));
-  } else {
-    TRY(hipStreamCreateWithPriority(&ctx->lane_stream, hipStreamNonBlocking, least));
+  if (lane_mode) {
+    int reserve = lane_reserve_of(ctx);
+    if (reserve >= cus) reserve = 0;
+    if (reserve > 0) {
+      hipError_t e = hipSuccess;
+      ctx->lane.stream = masked_lane_of(ctx->device, cus, reserve, &e);
+      TRY(e);
+    } else {
+      TRY(hipStreamCreateWithPriority(&ctx->lane_stream, hipStreamNonBlocking, least));   // (owned: an ordinary stream can be destroyed)
+      ctx->lane.stream = ctx->lane_stream;
+    }
+    ctx->lane.cus = cus - reserve;
   }
-  ctx->lane.stream = ctx->lane_stream;
-  ctx->lane.cus = cus - reserve;
   TRY(hipEventCreateWithFlags(&ctx->g16_ready, hipEventDisableTiming));
   return PCDHIP_OK;
 }
@@ -651,7 +667,7 @@ static int drop_side_streams(pcdhip_ctx* ctx) {
     if (ctx->g16_begin[k]) { (void)hipEventDestroy(ctx->g16_begin[k]); ctx->g16_begin[k] = nullptr; }
     if (ctx->g16_end[k]) { (void)hipEventDestroy(ctx->g16_end[k]); ctx->g16_end[k] = nullptr; }
   }
-  if (ctx->lane_stream) { (void)hipStreamDestroy(ctx->lane_stream); ctx->lane_stream = nullptr; }
+  if (ctx->lane_stream) { (void)hipStreamDestroy(ctx->lane_stream); ctx->lane_stream = nullptr; }   // (only the unmasked lane is owned)
   ctx->lane = MsmLane();
   (void)hipEventDestroy(ctx->g16_ready);
   ctx->g16_ready = nullptr;

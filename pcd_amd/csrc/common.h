@@ -123,8 +123,9 @@ struct pcdhip_ctx {
   hipEvent_t wm_ev = nullptr;       // sharded prove: this device's chain of the witness map has landed in device 0's buffers
   bool wm_split = true;             // pcdhip_groth16_set_witness_split
   int g16_schedule = 0;             // pcdhip_groth16_set_schedule: 0 assignment MSMs first, the map under them (default: fastest, measured again in round 5); 1 the map first, then all MSMs at once; 2 the map first, then the accumulate lane
-  // the accumulate lane (msm.hip.h MsmLane): one stream confined by a CU mask to all but `lane_reserve` compute units, for the accumulate
-  // kernels of the MSMs that share the device (a proof's five; submitted MSMs); created with the side streams
+  // the accumulate lane (msm.hip.h MsmLane; schedule 2 only): one stream confined by a CU mask to all but `lane_reserve` compute units, for
+  // the accumulate kernels of the MSMs that share the device (a proof's five; submitted MSMs).  The masked stream comes from a process-wide
+  // pool and is never destroyed (capi.hip masked_lane_of); `lane_stream` is the owned, unmasked one of reserve 0.
   hipStream_t lane_stream = nullptr;
   pcd::MsmLane lane;
   int lane_reserve = -1;            // CUs the lane leaves to the other streams (pcdhip_set_lane_reserve; -1: default, PCDHIP_LANE_RESERVE or 8; 0: no mask)

@@ -46,7 +46,8 @@ while time.time() - t0 < budget:
         nc = rnd.randrange(10, 3000 if cid < 2 else 600)
         if rnd.random() < 0.15:   # beyond the help field's 2-adicity: the mixed-radix domain
             nc = {0: rnd.randrange(10, 3000), 1: (1 << 17) + rnd.randrange(1, 2000), 2: rnd.randrange(10, 600), 3: (1 << 15) + rnd.randrange(1, 500)}[cid]
-        make = co.skewed_r1cs if rnd.random() < 0.5 and nc >= 50 else co.synthetic_r1cs
+        u = rnd.random()
+        make = co.synthetic_r1cs if nc < 50 or u < 0.35 else co.skewed_r1cs if u < 0.65 else co.witness_r1cs
         r = make(fr, nc, rnd.randrange(2, 5), seed=rnd.randrange(1 << 30))
         want = co.witness_map(r, nthreads=16)
         got = ctx.witness_map(fr, r)

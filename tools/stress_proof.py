@@ -20,7 +20,8 @@ while time.time() - t0 < budget:
     fr = co.CURVE_FR[cid]
     nc = rnd.randrange(20, 250) if cid >= 2 else rnd.randrange(20, 4000)
     ni = rnd.randrange(2, 5)
-    make = co.skewed_r1cs if rnd.random() < 0.5 and nc >= 50 else co.synthetic_r1cs
+    u = rnd.random()   # banded / skewed matrices with a uniform assignment, or (round 5) the witness-like system: >= 70 % of z is 0 / 1
+    make = co.synthetic_r1cs if nc < 50 or u < 0.35 else co.skewed_r1cs if u < 0.65 else co.witness_r1cs
     r = make(fr, nc, ni, seed=rnd.randrange(1 << 30))
     keys = co.groth16_setup(cid, r, co.gen_field(fr, 5, seed=rnd.randrange(1 << 30)), nthreads=32)
     rs = co.gen_field(fr, 2, seed=rnd.randrange(1 << 30))
@@ -30,16 +31,25 @@ while time.time() - t0 < budget:
     if resident: ctx.g16_pk_set_r1cs(pk, r)
     asm = rnd.randrange(3)
     acc = rnd.choice(((0, 0, 0), (2, rnd.randrange(2, 200), rnd.randrange(0, 16))))
-    ctx.groth16_set_assembly(asm); ctx.msm_set_accumulate(*acc)
+    sched = rnd.choice((0, 0, 1, 2))   # (2: the accumulate lane)
+    bad_at = rnd.randrange(r.num_inputs - 1)
+    if os.environ.get("STRESS_ONLY_CASE") and cases != int(os.environ["STRESS_ONLY_CASE"]):   # replay the random choices, skip the GPU work
+        pk.free(); cases += 1
+        continue
+    if os.environ.get("STRESS_VERBOSE"):
+        import faulthandler
+        faulthandler.dump_traceback_later(45, exit=False)   # (a stalled case says where it stalls)
+        print("case", cases, dict(cid=cid, nc=nc, ni=ni, make=make.__name__, resident=resident, asm=asm, acc=acc, sched=sched), flush=True)
+    ctx.groth16_set_assembly(asm); ctx.msm_set_accumulate(*acc); ctx.groth16_set_schedule(sched)
     proof, inf = ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=resident)
-    ctx.groth16_set_assembly(0); ctx.msm_set_accumulate(0)
+    ctx.groth16_set_assembly(0); ctx.msm_set_accumulate(0); ctx.groth16_set_schedule(0)
     pk.free()
     if not (np.array_equal(proof, want) and np.array_equal(inf, winf)):
-        print("PROOF MISMATCH", dict(cid=cid, nc=nc, ni=ni, make=make.__name__, resident=resident, asm=asm, acc=acc, case=cases), flush=True)
+        print("PROOF MISMATCH", dict(cid=cid, nc=nc, ni=ni, make=make.__name__, resident=resident, asm=asm, acc=acc, sched=sched, case=cases), flush=True)
         sys.exit(1)
     pub = co.fp_op(fr, "to_canonical", np.ascontiguousarray(r.z[1:r.num_inputs]))
     args = (cid, keys.alpha_g1, keys.beta_g2, keys.gamma_g2, keys.delta_g2, keys.gamma_abc_g1)
-    bad = pub.copy(); bad[rnd.randrange(len(bad)), 0] ^= 1
+    bad = pub.copy(); bad[bad_at, 0] ^= 1
     for mode in (0, 1):
         ctx.pairing_set_mode(mode)
         if not ctx.groth16_verify(*args, pub, proof) or ctx.groth16_verify(*args, bad, proof):
