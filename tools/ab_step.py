@@ -13,7 +13,12 @@ nc = int(os.environ['AB_NC']) if os.environ.get('AB_NC') else (1 << int(sys.argv
 ctx = capi.Context(0)
 fr = co.CURVE_FR[curve]
 r = (co.witness_r1cs if os.environ.get("AB_WITNESS") else co.skewed_r1cs)(fr, nc, 2, seed=77)   # AB_WITNESS=1: >= 70 % of z is 0 / 1
-keys = co.synthetic_keys(curve, r, seed=78, mt=True, consistent=os.environ.get("AB_DENSE", "0") != "1")
+if os.environ.get("AB_BENCH_INPUTS"):   # exactly what bench.py's pcd_step proves (its seeds; keys from the sequential point walk, not gen_points_mt)
+    SEED = 0x5043443031
+    r = co.skewed_r1cs(fr, nc, 2, seed=SEED + curve)
+    keys = co.synthetic_keys(curve, r, seed=SEED + 10 + curve)
+else:
+    keys = co.synthetic_keys(curve, r, seed=78, mt=True, consistent=os.environ.get("AB_DENSE", "0") != "1")
 rs = co.gen_field(fr, 2, seed=79)
 pk = ctx.g16_pk_upload(keys.host_struct(), curve)
 ctx.g16_pk_set_r1cs(pk, r)
