@@ -1438,7 +1438,8 @@ struct G16Run {
   size_t partial_bytes() const { return 6 * j1 + j2; }  // msm_g1 (six slots) and msm_g2 are contiguous
 
   // buffers, z -> device image and canonical words (plain, times s, times r), the scalar tails; ends with g16_ready recorded
-  int prepare(const uint64_t* z, const uint64_t* r_mont, const uint64_t* s_mont, size_t n_dom) {
+  // (need_scaled: the folded assembly multiplies every scalar by s / r -- the chained form does not read those copies, 2 n products less)
+  int prepare(const uint64_t* z, const uint64_t* r_mont, const uint64_t* s_mont, size_t n_dom, bool need_scaled = true) {
     BIND();
     cid = pk->curve_id;
     const FieldEntry& fe = field_entry(kCurveFr[cid]);
@@ -1462,8 +1463,10 @@ struct G16Run {
     TRY(hipMemcpyAsync(rs_dev + sw, s_mont, sb, hipMemcpyHostToDevice, st));
     TRY(fe.convert(st, z_abi, z_dev, (uint32_t)m, 0));
     TRY(fe.scale_canon(st, z_dev, nullptr, z_can, (uint32_t)m, 1));
-    TRY(fe.scale_canon(st, z_dev, rs_dev + sw, sz_can, (uint32_t)m, 1));
-    TRY(fe.scale_canon(st, z_dev, rs_dev, rz_can, (uint32_t)m, 1));
+    if (need_scaled) {
+      TRY(fe.scale_canon(st, z_dev, rs_dev + sw, sz_can, (uint32_t)m, 1));
+      TRY(fe.scale_canon(st, z_dev, rs_dev, rz_can, (uint32_t)m, 1));
+    }
     const GroupEntry& g1 = group_entry(cid, 1);
     const GroupEntry& g2 = group_entry(cid, 2);
     j1 = (size_t)g1.point_words / 2 * 3 * 4;
@@ -1771,14 +1774,14 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   // device (device image).
   G16Run run;
   run.ctx = ctx; run.pk = pk;
-  rc = run.prepare(z, r_mont, s_mont, n);
-  if (rc) return rc;
-  // automatic choice: the one-lane products cost ~5 ms (298-bit) / ~75 ms (753-bit) of latency that hides under the other
-  // MSMs of a large proof; two more MSMs cost 2 x 3.5 ms (298-bit, 2^20) / 2 x 1 ms (298-bit, 2^16) / 2 x 8 ms (753-bit, 2^16)
-  // of throughput.  Measured (folded vs chained): 28.4 vs 26.7 ms (298-bit, 2^20), 7.9 vs 8.2 ms (298-bit, 2^16),
-  // 580 vs 536 ms (753-bit, 2^20), 99 vs 120 ms (753-bit, 5 * 2^14).
+  // automatic choice of the assembly form: the one-point products cost ~2.5 ms (298-bit) / ~14 ms (753-bit; rounds 1-4: one lane, ~5 / ~75 ms) of
+  // latency that hides under the other MSMs of a large proof; two more MSMs cost 2 x 3.5 ms (298-bit, 2^20) / 2 x 1 ms (298-bit, 2^16) / 2 x 8 ms
+  // (753-bit, 2^16) of throughput.  Measured (folded vs chained, round 5): 17.6 vs 16.2 ms (298-bit, 2^20), 3.8 vs 5.0 ms (298-bit, 2^16),
+  // 202 vs 180 ms (753-bit, 2^20), 29.7 vs 42.0 ms (753-bit, 5 * 2^14).
   const size_t fold_below = fe.abi_words > 12 ? (1u << 18) : (1u << 17);
   const bool folded = ctx->g16_assembly == 1 || (ctx->g16_assembly == 0 && m + 4 <= fold_below);
+  rc = run.prepare(z, r_mont, s_mont, n, folded);
+  if (rc) return rc;
   // Schedule (pcdhip_groth16_set_schedule).  Default 0: the four assignment MSMs are launched BEFORE the witness map and run concurrently
   // with it; the h MSM follows the map.  Inside a proof the map's ~30 short dependent kernels wait behind the MSMs' accumulate grids (the 8 ms
   // map of a 753-bit proof ends at 160 ms) and the h MSM runs last -- which LOOKS like a serialised tail, so round 4 built mode 1: the map
