@@ -388,3 +388,38 @@ def test_submit_partial_tickets(co, gpu_ctx):
     b.free()
     for p in parts:
         p.free()
+
+
+def test_device_chosen_chunk_and_plan_report(co, gpu_ctx):
+    """round 5: the entries per lane of the accumulate kernel are chosen on the device from the REAL list length (msm.hip.h msm_plan_chunk) -- a
+    witness-like vector (45 % zeros, 35 % ones) leaves a fifth of the n W entries a uniform one makes, and a short list gets short chunks
+    instead of a few lanes with 40 entries each; pcdhip_msm_last_plan reports both.  Results equal the oracle at every size / distribution,
+    also with the chunk forced (the host-chosen form of rounds 1-4)."""
+    ctx = gpu_ctx
+    cid, grp = 0, 1
+    fr = co.CURVE_FR[cid]
+    for n, dist in ((3000, 0), (70000, 1), (70000, 0), (1 << 18, 1)):
+        pts = co.gen_points(cid, grp, n, seed=1700 + n)
+        sc = co.gen_scalars(fr, n, seed=1701 + n + dist, dist=dist)
+        want = co.to_affine(cid, grp, co.msm(cid, grp, pts, sc, nthreads=8))
+        b = ctx.bases_upload(cid, grp, pts)
+        sb = ctx.buf_upload(fr, sc)
+        try:
+            ctx.msm_profile(True)
+            got = co.to_affine(cid, grp, ctx.msm(b, sb))
+            entries, chunk = ctx.msm_last_plan()
+            ctx.msm_profile(False)
+            c_bits, W, _ = ctx.bases_info(b)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (n, dist)
+            assert 16 <= chunk <= 56 and 0 < entries <= n * W, (n, dist, entries, chunk)
+            if dist == 1:
+                assert entries < 0.3 * n * W, (entries, n * W)      # zeros and ones never enter the list
+            else:
+                assert entries > 0.9 * n * (W - 1)
+            ctx.msm_config(0, 33)                                   # a forced chunk: no device plan
+            got = co.to_affine(cid, grp, ctx.msm(b, sb))
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (n, dist, "forced chunk")
+        finally:
+            ctx.msm_profile(False)
+            ctx.msm_config(0, 0)
+            b.free(); sb.free()

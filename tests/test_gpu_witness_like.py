@@ -97,3 +97,29 @@ def test_main_proof_mnt4_298_2p20_witness_like(co, gpu_ctx):
     finally:
         gpu_ctx.groth16_set_assembly(0)
         pk.free()
+
+
+def test_key_plan_report_and_lane_reserve(co, gpu_ctx):
+    """pcdhip_g16_pk_info (the window plan of a resident key's five queries: what bench.py counts a proof's executed multiply-adds with) and
+    pcdhip_set_lane_reserve (the CUs the accumulate lane of schedule 2 leaves to the other streams: 0 = no mask, 8 = default, 16): same proof."""
+    cid, fr = 0, co.CURVE_FR[0]
+    r = co.witness_r1cs(fr, 30000, 2, seed=4700)
+    keys = co.synthetic_keys(cid, r, seed=4701)
+    rs = co.gen_field(fr, 2, seed=4702)
+    want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)
+    pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
+    try:
+        plan = gpu_ctx.g16_pk_info(pk)
+        assert set(plan) == {"a", "b_g1", "b_g2", "l", "h"}
+        for name, (c_bits, W) in plan.items():
+            assert 6 <= c_bits <= 22 and W == (298 + c_bits) // c_bits, (name, c_bits, W)   # signed digits: ceil((bits + 1) / c) windows
+        assert plan["a"] == plan["b_g1"] == plan["b_g2"] == plan["l"]                       # the four queries over the assignment are laid out alike
+        gpu_ctx.groth16_set_schedule(2)
+        for reserve in (0, 16, 8, -1):
+            gpu_ctx.set_lane_reserve(reserve)
+            got, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
+            assert np.array_equal(got, want) and np.array_equal(inf, winf), reserve
+    finally:
+        gpu_ctx.groth16_set_schedule(0)
+        gpu_ctx.set_lane_reserve(-1)
+        pk.free()
