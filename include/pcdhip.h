@@ -270,7 +270,7 @@ int pcdhip_groth16_set_witness_split(pcdhip_ctx* ctx, int on);
 /* Order of the stages of pcdhip_groth16_prove (what ark-groth16 `create_proof_with_reduction` does one after the other on rayon:
  * witness_map, then the five `VariableBaseMSM::multi_scalar_mul`; reference call sites src/ec_cycle_pcd/mod.rs:171,179).
  *   0 (default)  the four MSMs over the assignment first, each on its own stream, the witness map concurrently with them, the h MSM behind
- *      the map.  Measured in round 5 (profiles/r05_acc_probe.txt, r05_pt_serial.txt): the proof takes the SUM of its kernels' standalone
+ *      the map.  Measured in round 5 (profiles/r05_acc_probe_mnt4_298_2p20.txt, r05_pt_serial_lane8.txt): the proof takes the SUM of its kernels' standalone
  *      times to within a few per cent -- every kernel is bound by the same multiply-add issue slots, so no order can beat that sum;
  *   1  the witness map first with the device to itself, then all five MSMs at once (round 4's A/B knob; slower);
  *   2  the accumulate LANE (round 5): the map first while the MSMs sort beside it, then the MSMs' accumulate kernels one

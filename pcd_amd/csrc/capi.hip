@@ -607,7 +607,7 @@ static int lane_reserve_of(const pcdhip_ctx* ctx) {
 }
 // CU-masked streams are made once per (device, reserve) and NEVER destroyed: on this stack (ROCm 7.2) hipStreamDestroy of a stream created
 // by hipExtStreamCreateWithCUMask stalls for good now and then once such streams have been created and destroyed before in the process
-// (round 5: a soak that toggled the schedule per proof hung in the second round of destructions, profiles/r05_stress_proof.log).  Contexts
+// (round 5: a soak that toggled the schedule per proof hung in the second round of destructions, profiles/r05_stress.log).  Contexts
 // of one device share the lane: stream order only adds dependencies between their accumulations, and the mode is not the default.
 static hipStream_t masked_lane_of(int device, int cus, int reserve, hipError_t* err) {
   static std::mutex mu;
