@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <new>
 
@@ -1760,6 +1761,10 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   EventSet<8> ev;
   TRY(ev.create());
   TRY(hipEventRecord(ev[0], st));
+  static const bool host_time = getenv("PCDHIP_G16_HOSTTIME") != nullptr;  // developer knob: where the HOST is while the proof's launches queue up
+  const auto ht0 = std::chrono::steady_clock::now();
+  double ht[6] = {0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int k) { if (host_time) ht[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ht0).count(); };
   int rc = PCDHIP_OK;
   uint32_t rows = 0;
   if (A && B && C) rows = (uint32_t)A->num_rows;
@@ -1797,7 +1802,9 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   // the mask (a masked queue runs an accumulate kernel 15 .. 45 % slower: one CU less in ONE shader engine per XCD unbalances the dispatch) or,
   // unmasked, for its own serialisation (18.0 / 16.4 .. 18.4 ms).  Mode 0 stays the default; what round 5 gained came from doing less work.
   const bool map_first = ctx->g16_schedule >= 1;
+  stamp(0);
   if (!map_first) { rc = run.launch_assignment(0, m + 4, folded); if (rc) return rc; }
+  stamp(1);
   // ---- K1: h, on the context's stream
   DevCsr mats[3];
   if (A && B && C) { TRY(hipStreamSynchronize(st)); rc = upload_three(ctx, A, B, C, fe, m, mats); if (rc) return rc; }  // (staging slot AUX_SCAL is reused)
@@ -1808,6 +1815,7 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   if (dom_used.n != dom.n) return PCDHIP_E_ARG;
   TRY(fe.convert(st, (const uint32_t*)ctx->aux_ws.buf[AUX_A], run.h_can, (uint32_t)n, 2));
   TRY(hipEventRecord(ev[1], st));
+  stamp(2);
   // (round 5 also tried the map's launches merely ENQUEUED first with the h MSM right behind it and the assignment MSMs after, nothing
   //  gated -- the critical path of a proof over a witness-like assignment is upload -> map -> h MSM: slower everywhere, 11.2 against 8.0 ms
   //  there, 19.0 against 15.8 ms on a uniform assignment, because the G2 MSM and the one-point products then start last; and mode 0 with only
@@ -1816,14 +1824,20 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   if (map_first) { rc = run.launch_assignment_gated(0, m + 4, folded, ev[1]); if (rc) return rc; }  // (lane: no accumulation under the map; the sorts start at once)
   rc = run.launch_h(0, std::min<size_t>(pk->h_query->n, n), ev[1]);
   if (rc) return rc;
+  stamp(3);
   rc = run.join();
   if (rc) return rc;
   TRY(hipEventRecord(ev[6], st));
   // assembly: three additions and three affine conversions (writes the proof in the C-ABI image)
   TRY(curve_entry(cid).assemble(st, run.msm_g1, run.msm_g2, run.proof_dev));
   TRY(hipEventRecord(ev[7], st));
+  stamp(4);
   rc = finish_proof(ctx, cid, run.proof_dev, proof_out, inf_out);
   if (rc) return rc;
+  stamp(5);
+  if (host_time)
+    fprintf(stderr, "pcdhip prove host ms: prepared %.3f, assignment MSMs enqueued %.3f, map enqueued %.3f, h enqueued %.3f, all enqueued %.3f, done %.3f\n",
+            ht[0], ht[1], ht[2], ht[3], ht[4], ht[5]);
   // [witness_map, msm_h, msm_l, msm_a (A and s*A), msm_b_g1 (B_1 and r*B_1), msm_b_g2 (each on its own stream: they
   //  overlap), assembly, total]
   (void)hipEventElapsedTime(&ctx->g16_ms[0], ev[0], ev[1]);

@@ -40,3 +40,6 @@ for item in os.environ.get("AB_SCHEDULES", "0,2:8,0,2:8").split(","):
         t0 = time.perf_counter(); ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True); walls.append((time.perf_counter() - t0) * 1e3)
     tm = {k: round(float(v), 2) for k, v in ctx.groth16_last_timings().items()}
     print(f"lib={os.environ.get('PCDHIP_LIB', 'in-tree')} curve={curve} schedule={item} prove wall ms median {np.median(walls):.3f} min {min(walls):.3f}; device {tm}", flush=True)
+if os.environ.get("AB_MAP_ALONE"):   # the witness map with the device to itself, same matrices and assignment
+    wm = [ctx.witness_map_resident(pk, r, want_h=False)[1] for _ in range(5)][-1]
+    print(f"witness map alone, device ms: { {k: round(float(v), 3) for k, v in wm.items()} }", flush=True)
