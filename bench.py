@@ -322,6 +322,7 @@ def run(args, stdout_fd):
     elapsed_sync, res = timed_msm(bases, sbuf, args.steps, args.warmup)                 # one MSM at a time: the latency view
     elapsed, res = timed_msm(bases, sbuf, args.steps, args.warmup, depth) if depth > 1 else (elapsed_sync, res)
     stages = stage_times(bases, sbuf)
+    mad_peak_live = ctx.mad_rate()   # the v_mad_u64_u32 issue rate of THIS box, right behind the kernels it prices (boxes differ by ~10 % in sustained clock)
     c_bits, W, copies = ctx.bases_info(bases)
 
     # ---- correctness of what was timed (outside the timed region): rank-local partial vs the CPU oracle
@@ -417,6 +418,9 @@ def run(args, stdout_fd):
                                  "not HBM-bound: see roofline_int"},
             "roofline_int": {"bound": "valu_int32_mad", "achieved": round(executed / (acc * 1e-3) / 1e12, 3),
                              "peak": round(MAD_PEAK / 1e12, 2), "unit": "T mad/s", "frac": round(executed / (acc * 1e-3) / MAD_PEAK, 4),
+                             "peak_live": round(mad_peak_live / 1e12, 2), "frac_live": round(executed / (acc * 1e-3) / mad_peak_live, 4),
+                             "peak_live_note": "pcdhip_mad_rate: the same issue-rate microbenchmark as `peak` (four waves per SIMD, eight chains per lane), run on this "
+                                               "box right after the stage timings; `peak` is the round-1 constant every other fraction in this line uses",
                              "executed_mads_per_pair": W * madd_mads(CURVE),
                              "note": f"EXECUTED multiply-adds of the plan that ran: n x W={W} mixed additions (signed digits, c={c_bits}) x "
                                      f"{madd_mads(CURVE)} mads per lazily reduced madd; peak = measured v_mad_u64_u32 issue rate "

@@ -168,6 +168,9 @@ int pcdhip_msm_last_timings(pcdhip_ctx* ctx, float out_ms[8]);
 /* ... and what the device planned for that MSM: out[0] = entries of the sorted (bucket, base) list -- n x windows less the zero digits, the
  * scalars equal to zero or one and the bases at infinity --, out[1] = entries per lane of the accumulate kernel chosen for it. */
 int pcdhip_msm_last_plan(pcdhip_ctx* ctx, uint32_t out[2]);
+/* Measurement aid: the v_mad_u64_u32 issue rate of the context's device in lane-operations per second (four waves per SIMD, eight independent
+ * chains per lane, ~1 ms) -- the roof bench.py prices the integer kernels against (`roofline_int.peak_live`), measured on the box at hand. */
+int pcdhip_mad_rate(pcdhip_ctx* ctx, double* out_lane_mads_per_s);
 /* Sum of n Jacobian points (the multi-GPU combine step after the all-gather of partial results). */
 int pcdhip_points_sum(pcdhip_ctx* ctx, int curve_id, int group_id, const uint64_t* xyz_mont, size_t n,
                       uint64_t* out_xyz_mont);

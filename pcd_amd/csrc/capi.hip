@@ -571,6 +571,53 @@ int pcdhip_msm_last_plan(pcdhip_ctx* ctx, uint32_t out[2]) {
   out[0] = ctx->msm_tm.entries; out[1] = ctx->msm_tm.chunk;
   return PCDHIP_OK;
 }
+// The roof the MSM, FFT and pairing kernels are priced against, measured on the device at hand: v_mad_u64_u32 issue rate with four waves
+// per SIMD, eight independent accumulator chains per lane (tools/microbench/k0_int_rates.hip found 3.42e13 lane-mads/s that way in round 1;
+// boxes of the pool differ by ~10 % in sustained clock, and a fraction against a constant moves with the box).
+namespace {
+__global__ void __launch_bounds__(256) mad_rate_kernel(uint32_t* out, int iters, uint32_t seed) {
+  uint32_t a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9e3779b9u;
+  uint64_t c0 = a, c1 = b, c2 = a + 1, c3 = b + 1, c4 = a + 2, c5 = b + 2, c6 = a + 3, c7 = b + 3;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      asm volatile(
+          "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n"
+          "v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+          "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n"
+          "v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n"
+          : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b) : "vcc");
+  }
+  const uint64_t x = c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)x ^ (uint32_t)(x >> 32);
+}
+}  // namespace
+int pcdhip_mad_rate(pcdhip_ctx* ctx, double* out_lane_mads_per_s) {
+  return guarded([&]() -> int {
+  if (!ctx || !out_lane_mads_per_s) return PCDHIP_E_ARG;
+  BIND();
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
+  const int blocks = cus * 4, iters = 1000;  // one workgroup of four waves per SIMD quartet, four of them per CU: four waves per SIMD
+  TRY(ctx->aux_ws.ensure(AUX_SCAL, (size_t)blocks * 256 * 4));
+  uint32_t* out = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
+  EventSet<2> ev;
+  TRY(ev.create());
+  float best = 0;
+  for (int r = 0; r < 9; r++) {  // (the first pass warms up; the best of eight: the clock needs a few milliseconds of load to settle)
+    TRY(hipEventRecord(ev[0], ctx->stream));
+    hipLaunchKernelGGL(mad_rate_kernel, dim3(blocks), dim3(256), 0, ctx->stream, out, r ? iters : 10, (uint32_t)r);
+    TRY(hipEventRecord(ev[1], ctx->stream));
+    TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    if (r && (best == 0 || ms < best)) best = ms;
+  }
+  TRY(hipGetLastError());
+  *out_lane_mads_per_s = (double)blocks * 256.0 * iters * 64.0 / ((double)best * 1e-3);
+  return PCDHIP_OK;
+  });
+}
 int pcdhip_msm_last_timings(pcdhip_ctx* ctx, float out_ms[8]) {
   if (!ctx || !out_ms) return PCDHIP_E_ARG;
   const MsmTimings& t = ctx->msm_tm;

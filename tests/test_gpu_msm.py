@@ -390,6 +390,14 @@ def test_submit_partial_tickets(co, gpu_ctx):
         p.free()
 
 
+def test_mad_rate_is_a_plausible_roof(gpu_ctx):
+    """pcdhip_mad_rate (the live `roofline_int.peak_live` of bench.py): an MI355X issues a v_mad_u64_u32 per SIMD every ~4.5 cycles -- between
+    2e13 and 4.5e13 lane-operations a second over 1024 SIMDs at 2 .. 2.4 GHz; repeated calls agree within 15 %"""
+    r = [gpu_ctx.mad_rate() for _ in range(3)]
+    assert all(2.0e13 < v < 4.5e13 for v in r), r
+    assert max(r) / min(r) < 1.15, r
+
+
 def test_device_chosen_chunk_and_plan_report(co, gpu_ctx):
     """round 5: the entries per lane of the accumulate kernel are chosen on the device from the REAL list length (msm.hip.h msm_plan_chunk) -- a
     witness-like vector (45 % zeros, 35 % ones) leaves a fifth of the n W entries a uniform one makes, and a short list gets short chunks
