@@ -684,7 +684,10 @@ static int ensure_side_streams(pcdhip_ctx* ctx) {
     // that MSM's wait for its accumulation on the lane -- l' and h started 3 ms late (profiles/r05_pt_lane_aliased.txt: q5 carries s4 AND s5).
     // Lane mode therefore spreads its six side streams two per priority (with the context's own stream: three at the normal one); the other
     // schedules keep round 4's mix (2 high, 1 normal, 3 low).
-    const int prio = lane_mode ? (k < 2 ? greatest : k < 4 ? normal : least) : (k < 2 ? greatest : k == 2 ? normal : least);
+    int prio = lane_mode ? (k < 2 ? greatest : k < 4 ? normal : least) : (k < 2 ? greatest : k == 2 ? normal : least);
+    static const char* side_prio = getenv("PCDHIP_SIDE_PRIO");  // developer knob: "low" = every side stream at the lowest priority, "mid" = none above normal
+    if (side_prio && !strcmp(side_prio, "low")) prio = least;
+    if (side_prio && !strcmp(side_prio, "mid")) prio = k < 3 ? normal : least;
     TRY(hipStreamCreateWithPriority(&ctx->g16_streams[k], hipStreamNonBlocking, prio));
     TRY(hipEventCreate(&ctx->g16_begin[k]));
     TRY(hipEventCreate(&ctx->g16_end[k]));
@@ -1614,7 +1617,12 @@ struct G16Run {
       }
       jobs[nj++] = {&g1, plain(vl), zc, n, slot(1), 2, nullptr, nullptr, (sparse_a && sparse_b) ? NONE : CONSUME};   // l'
     }
-    for (int k = 0; k < nj; k++) { int rc = launch(k, after ? after : ctx->g16_ready); if (rc) return rc; }
+    static const int skip = getenv("PCDHIP_G16_SKIP") ? atoi(getenv("PCDHIP_G16_SKIP")) : 0;  // DIAGNOSIS ONLY (wrong proofs): leave out job k where bit k is set
+    for (int k = 0; k < nj; k++) {
+      if (skip >> k & 1) { BIND(); TRY(hipEventRecord(ctx->g16_begin[k], ctx->g16_streams[k])); TRY(hipEventRecord(ctx->g16_end[k], ctx->g16_streams[k])); continue; }
+      int rc = launch(k, after ? after : ctx->g16_ready);
+      if (rc) return rc;
+    }
     return PCDHIP_OK;
   }
   // ... behind `gate`: with the lane only the accumulations wait for it (the sorts start at once), otherwise the MSMs as a whole
