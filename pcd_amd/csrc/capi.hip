@@ -1523,12 +1523,12 @@ struct G16Run {
     j1 = (size_t)g1.point_words / 2 * 3 * 4;
     j2 = (size_t)g2.point_words / 2 * 3 * 4;
     const CurveEntry& ce = curve_entry(cid);
-    TRY(ctx->aux_ws.ensure(AUX_G16, 6 * j1 + j2 + 6 * 320 * j1 + ce.proof_abi_bytes + 256));  // (320 Jacobian slots per one-point product: inst_g16.hip)
+    TRY(ctx->aux_ws.ensure(AUX_G16, 6 * j1 + j2 + 6 * 400 * j1 + ce.proof_abi_bytes + 256));  // (400 Jacobian slots per one-point product: inst_g16.hip)
     char* gbase = (char*)ctx->aux_ws.buf[AUX_G16];
     msm_g1 = (uint32_t*)gbase;  // h, l', A, s*A, r*B_1, B_1
     msm_g2 = (uint32_t*)(gbase + 6 * j1);
     mul_scratch = (uint32_t*)(gbase + 6 * j1 + j2);
-    proof_dev = (uint32_t*)(gbase + 6 * j1 + j2 + 6 * 320 * j1);
+    proof_dev = (uint32_t*)(gbase + 6 * j1 + j2 + 6 * 400 * j1);
     t1 = z_can + m * sw;  // [r, s, -rs, 1] canonical
     TRY(ce.prepare_scalars(st, rs_dev, t1, sz_can + m * sw, rz_can + m * sw));
     { int rc = ensure_side_streams(ctx); if (rc) return rc; }
@@ -1554,7 +1554,7 @@ struct G16Run {
                         (jobs[k].share & 3) ? ((jobs[k].share & SHARE_B) ? &ctx->g16_share_b : &ctx->g16_share) : nullptr, jobs[k].share & 3);
     ctx->g16_ws[k].lane = nullptr;
     TRY(me);
-    if (jobs[k].k) TRY(ce.scale_g1(sk, jobs[k].out, jobs[k].k, mul_scratch + (size_t)k * 320 * (j1 / 4), jobs[k].kout));
+    if (jobs[k].k) TRY(ce.scale_g1(sk, jobs[k].out, jobs[k].k, mul_scratch + (size_t)k * 400 * (j1 / 4), jobs[k].kout));
     TRY(hipEventRecord(ctx->g16_end[k], sk));
     static const bool serial = getenv("PCDHIP_G16_SERIAL") != nullptr;  // developer knob: every MSM of a proof with the device to itself (kernel traces)
     if (serial) TRY(hipDeviceSynchronize());

@@ -70,30 +70,72 @@ __global__ void __launch_bounds__(64) g16_finish(const uint32_t* __restrict__ ms
 // out = k * in (k: canonical words).  Round 4's form was ONE lane (4-bit window: ~300 / 750 doublings and ~75 / 190 additions of 9 .. 16
 // dependent products each: 4.6 ms over the 298-bit fields, ~60 ms over the 753-bit ones -- the longest kernel of a proof, harmless only
 // while it hid under three other accumulations).  Now one workgroup of four waves:
-//   1. lanes 0 / 1 run the doubling chain with two lanes per doubling (EC2::dbl2: 5 product slots instead of 9 products) and leave
-//      T_j = 16^j P behind for every 4-bit window j;
+//   1. lanes 0 .. 3 run the doubling chain, FOUR lanes per doubling in XYZZ coordinates (dbl-2008-s-1: its ten products are three levels deep --
+//      V = (2Y)^2, X^2, ZZ^2 | W = 2Y V, S = X V, M^2, ZZ' = V ZZ | M (S - X'), W Y, ZZZ' = W ZZZ -- so three product slots a doubling where
+//      the two-lane Jacobian form (EC2::dbl2) has five: the chain is the kernel's critical path, bits of the scalar field many) and leave
+//      T_j = 16^j P behind for every 4-bit window j (four coordinates; the readers convert);
 //   2. every lane PAIR takes windows j, j + 128, ..: d_j T_j by double-and-add over the digit's four bits (the pairs of a wave run in
 //      lockstep, so a pair pays the four doublings and four additions whatever its digit), summed per pair;
 //   3. a tree over the 128 pairs through `scratch`.
-// The doublings that remain are the chain itself (bits of the scalar field many); everything else is ~20 group operations deep.
-// scratch: SCALE_SLOTS Jacobian slots (window table, then one partial per pair).
-constexpr int SCALE_W = 4, SCALE_NW = (GA::FR::BITS + SCALE_W - 1) / SCALE_W, SCALE_PAIRS = 128, SCALE_SLOTS = SCALE_NW + SCALE_PAIRS;
-static_assert(SCALE_SLOTS <= 320, "G16Run::prepare reserves 320 Jacobian slots per product");
+// A witness-like proof waits for exactly this kernel behind its sparse A / B_1 MSMs (profiles/r05_witness_like_critical_path.txt).
+// scratch: SCALE_SLOTS Jacobian slots (window table of four-coordinate records, then one partial per pair).
+constexpr int SCALE_W = 4, SCALE_NW = (GA::FR::BITS + SCALE_W - 1) / SCALE_W, SCALE_PAIRS = 128;
+constexpr int SCALE_TABLE_SLOTS = (SCALE_NW * 4 + 2) / 3, SCALE_SLOTS = SCALE_TABLE_SLOTS + SCALE_PAIRS;
+static_assert(SCALE_SLOTS <= 400, "G16Run::prepare reserves 400 Jacobian slots per product");
+struct ScaleQuad {  // four lanes per doubling
+  typedef F1 F;
+  struct P4 { F X, Y, ZZ, ZZZ; };
+  template <int K> PCD_DEV static F bc(const F& a) { F r;   // lane K of every quad to all four of its lanes
+#pragma unroll
+    for (int i = 0; i < F::N; i++) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], K * 0x55, 0xF, 0xF, false);
+    return r; }
+  PCD_DEV static F sel4(uint32_t l, const F& a0, const F& a1, const F& a2, const F& a3) { F r;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) { const uint32_t lo = (l & 1u) ? a1.v[i] : a0.v[i], hi = (l & 1u) ? a3.v[i] : a2.v[i]; r.v[i] = (l & 2u) ? hi : lo; }
+    return r; }
+  PCD_DEV static P4 dbl4(const P4& p) {  // (a finite point of odd prime order: no doubling of this chain meets the identity)
+    const uint32_t l = threadIdx.x & 3u;
+    const F U = p.Y.dbl();
+    const F a1 = sel4(l, U, p.X, p.ZZ, U);
+    const F s1 = a1 * a1;                                   // lane 0: V = U^2      1: X^2      2: ZZ^2     (3: idle)
+    const F V = bc<0>(s1), XX = bc<1>(s1), Z4 = bc<2>(s1);
+    const F M = XX.dbl() + XX + GA::mul_by_a(Z4);
+    const F a2 = sel4(l, U, p.X, M, V), b2 = sel4(l, V, V, M, p.ZZ);
+    const F s2 = a2 * b2;                                   // lane 0: W = U V      1: S = X V  2: M^2      3: ZZ' = V ZZ
+    const F W = bc<0>(s2), S = bc<1>(s2), MM = bc<2>(s2);
+    P4 r;
+    r.ZZ = bc<3>(s2);
+    r.X = MM - S.dbl();
+    const F smx = S - r.X;
+    const F a3 = sel4(l, M, W, W, M), b3 = sel4(l, smx, p.Y, p.ZZZ, smx);
+    const F s3 = a3 * b3;                                   // lane 0: M (S - X')   1: W Y      2: ZZZ' = W ZZZ     (3: idle)
+    r.Y = bc<0>(s3) - bc<1>(s3);
+    r.ZZZ = bc<2>(s3);
+    return r;
+  }
+};
 __global__ void __launch_bounds__(2 * SCALE_PAIRS) g16_scale_point(const uint32_t* __restrict__ in, const uint32_t* __restrict__ k,
                                                                   uint32_t* __restrict__ scratch, uint32_t* __restrict__ out) {
   if (blockIdx.x != 0) return;
   typedef EC2<GA> E2;
   typedef Jac<F1> J;
+  constexpr int FW = F1::WORDS;
   const uint32_t pair = threadIdx.x >> 1;
   const bool writer = (threadIdx.x & 1u) == 0;
   uint32_t* table = scratch;
-  uint32_t* partial = scratch + (size_t)SCALE_NW * J1;
-  if (pair == 0) {
-    J t = J::load(in);
+  uint32_t* partial = scratch + (size_t)SCALE_TABLE_SLOTS * J1;
+  const J p_in = J::load(in);
+  if (p_in.is_inf()) {  // (uniform: every lane reads the same point)
+    if (threadIdx.x == 0) J::infinity().store(out);
+    return;
+  }
+  if (threadIdx.x < 4) {
+    const F1 zz = p_in.Z.sqr();
+    ScaleQuad::P4 t = {p_in.X, p_in.Y, zz, zz * p_in.Z};
     for (int j = 0; j < SCALE_NW; j++) {
-      if (writer) t.store(table + (size_t)j * J1);
+      if (threadIdx.x == 0) { t.X.store(table + (size_t)j * 4 * FW); t.Y.store(table + ((size_t)j * 4 + 1) * FW); t.ZZ.store(table + ((size_t)j * 4 + 2) * FW); t.ZZZ.store(table + ((size_t)j * 4 + 3) * FW); }
       if (j + 1 < SCALE_NW)
-        for (int d = 0; d < SCALE_W; d++) t = E2::dbl2(t);
+        for (int d = 0; d < SCALE_W; d++) t = ScaleQuad::dbl4(t);
     }
   }
   __syncthreads();
@@ -101,7 +143,12 @@ __global__ void __launch_bounds__(2 * SCALE_PAIRS) g16_scale_point(const uint32_
   for (uint32_t j = pair; j < (uint32_t)SCALE_NW; j += SCALE_PAIRS) {
     const uint32_t bit0 = j * SCALE_W;
     const uint32_t dgt = bit0 / 32 < (uint32_t)SWA ? (k[bit0 / 32] >> (bit0 % 32)) & 15u : 0u;  // (4 divides 32: a digit never straddles words)
-    const J t = J::load(table + (size_t)j * J1);
+    // the Jacobian point (X ZZ : Y ZZZ : ZZ) of the record: one product slot of the pair
+    const uint32_t* rec = table + (size_t)j * 4 * FW;
+    const F1 zz = F1::load(rec + 2 * FW);
+    const F1 pr = E2::slot(F1::load(rec), zz, F1::load(rec + FW), F1::load(rec + 3 * FW));
+    const F1 prx = E2::xch(pr);
+    const J t = {E2::sel(E2::odd(), prx, pr), E2::sel(E2::odd(), pr, prx), zz};
     J r = J::infinity();
     for (int b = SCALE_W - 1; b >= 0; b--) {
       r = E2::dbl2(r);
