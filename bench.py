@@ -795,6 +795,7 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None, variants=True):
         r.z = capi.pinned_like(r.z)
         ctx.groth16_prove(vpk, r, rs[0], rs[1], resident_r1cs=True)
         wall, proof, tm, walls = median_prove(ctx, vpk, r, rs)
+        sparse_used, general = ctx.groth16_last_plan()   # (pcdhip_groth16_set_sparse_window: the copies for a shorter window, taken when <= 1/8 of z is general)
         ctx.groth16_set_assembly(2)
         p_chained = ctx.groth16_prove(vpk, r, rs[0], rs[1], resident_r1cs=True)[0]
         ctx.groth16_set_assembly(1)
@@ -805,7 +806,8 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None, variants=True):
             raise SystemExit("the two assembly forms of a Groth16 proof differ")
         res = {"gpu_wall_ms": round(wall, 2), "gpu_wall_ms_min_max": [round(min(walls), 2), round(max(walls), 2)],
                "gpu_device_ms": {k: round(float(v), 3) for k, v in tm.items()},
-               "query_infinity_frac": {"a": round(float(np.mean(keys.a_inf)), 4), "b": round(float(np.mean(keys.b_g2_inf)), 4)}}
+               "query_infinity_frac": {"a": round(float(np.mean(keys.a_inf)), 4), "b": round(float(np.mean(keys.b_g2_inf)), 4)},
+               "sparse_window_plan": {"used": bool(sparse_used), "general_scalars": int(general)}}
         if cpu:
             t0 = time.perf_counter()
             want, _ = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=threads)

@@ -264,6 +264,16 @@ int pcdhip_groth16_last_timings(pcdhip_ctx* ctx, float out_ms[8]);
  *   1  folded into two more MSMs over the a / b_g1 bases with every scalar multiplied by s / r;
  *   0  (default) automatic: 2 for large proofs, 1 for small ones (<= 2^17 variables, 2^18 over the 753-bit fields). */
 int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode);
+/* A window per PROOF for the four MSMs over the assignment (round 5).  The window of an MSM over a resident key is fixed by the key's
+ * window-shifted copies and chosen for a dense scalar vector; the assignment of a verifier circuit (reference src/ec_cycle_pcd/data_structures.rs:269-304:
+ * bit decompositions) is zeros and ones with a few per cent general scalars, and the bucket reduction of the dense window then costs more than the
+ * additions.  bits: -1 (default) pcdhip_g16_pk_upload also lays the a / b_g1 / b_g2 / l queries out for a window four bits shorter when the key is a
+ * whole key of at least 2^18 entries on an ordinary context and the extra copies fit 12 GB; 0 never; 6 .. 22: always, with that window.  Takes effect
+ * at the next key upload.  pcdhip_groth16_prove counts the general scalars (neither 0 nor 1) of the assignment on the device and runs the four MSMs
+ * on the shorter-window copies when they are at most an eighth of it (chained assembly only); the proof is the same either way.
+ * pcdhip_groth16_last_plan: out[0] = 1 when the last proof took them, out[1] = its count of general scalars (0 when not counted). */
+int pcdhip_groth16_set_sparse_window(pcdhip_ctx* ctx, int bits);
+int pcdhip_groth16_last_plan(pcdhip_ctx* ctx, uint32_t out[2]);
 /* Multi-device contexts with at least three devices: where the three independent chains of the witness map (a = A z, b = B z, c = C z:
  * mat-vec, ifft, coset fft each -- ark-groth16 `R1CSToQAP::witness_map`, SURVEY.md 8e "a || b || c on 3 GPUs") run.  1 (default): chain a on
  * device 0, b on device 1, c on device 2 (the matrices are resident on all three, pcdhip_g16_pk_set_r1cs), the two vectors come back

@@ -530,6 +530,16 @@ int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode) {
   ctx->g16_assembly = mode;
   return PCDHIP_OK;
 }
+int pcdhip_groth16_set_sparse_window(pcdhip_ctx* ctx, int bits) {
+  if (!ctx || bits < -1 || (bits > 0 && (bits < 6 || bits > 22))) return PCDHIP_E_ARG;
+  ctx->g16_sparse_window = bits;
+  return PCDHIP_OK;
+}
+int pcdhip_groth16_last_plan(pcdhip_ctx* ctx, uint32_t out[2]) {
+  if (!ctx || !out) return PCDHIP_E_ARG;
+  out[0] = (uint32_t)ctx->g16_last_sparse; out[1] = ctx->g16_last_general;
+  return PCDHIP_OK;
+}
 static int drop_side_streams(pcdhip_ctx* ctx);
 static bool pipe_pending(const pcdhip_ctx* ctx);
 int pcdhip_groth16_set_schedule(pcdhip_ctx* ctx, int mode) {
@@ -1405,6 +1415,34 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
     const size_t pl1 = (size_t)pcdhip_point_limbs(cid, 1);
     rc = rc ? rc : bases_upload_single(C, cid, 1, h->h_query ? h->h_query + hlo * pl1 : nullptr, h->h_inf ? h->h_inf + hlo : nullptr, hhi - hlo, &pk->h_query);
     if (rc) { pcdhip_g16_pk_free(C, pk); return rc; }
+    // A second layout of the four queries over the assignment, for a smaller window (round 5).  The window of a key is fixed by its window-shifted
+    // copies, and it is chosen for a DENSE scalar vector: c = 19 / 20 at 2^20 entries, one bucket window of 2^18 / 2^19.  A witness-like
+    // assignment leaves a few per cent general scalars, but the fix-up, the first reduction level (two additions per bucket) and the 19 levels
+    // over that bucket window cost every one of its four MSMs the same as a dense list: ~1.7 ms of device-filling work per G1 MSM of a proof
+    // that takes 8.3 (profiles/r05_witness_like_critical_path.txt).  With copies for a window four bits shorter as well -- what the picker
+    // chooses for a sixteenth of the entries -- pcdhip_groth16_prove counts the general scalars and takes the copies that fit the list.
+    // Whole keys on an ordinary context only; automatic mode builds them for large keys whose extra copies fit 12 GB (9.2 GB for a 298-bit key of 2^20 entries).
+    if (C == ctx && ctx->peers.size() <= 1 && ctx->g16_sparse_window != 0 && pk->a_query && pk->a_query->groups > 1 &&
+        (ctx->g16_sparse_window > 0 || hi - lo >= ((size_t)1 << 18))) {
+      const int cs = ctx->g16_sparse_window > 0 ? ctx->g16_sparse_window : std::max(8, pk->a_query->c - 4);
+      const int Ws = (group_entry(cid, 1).scalar_bits + 1 + cs - 1) / cs;
+      const size_t extra = (size_t)Ws * (hi - lo) * (3 * (size_t)group_entry(cid, 1).point_words + (size_t)group_entry(cid, 2).point_words) * 4;
+      if (cs != pk->a_query->c && (ctx->g16_sparse_window > 0 || extra <= ((size_t)12 << 30))) {
+        const int saved_c = C->msm_c, saved_pre = C->precompute;
+        C->msm_c = cs; C->msm_c_bias = 0; C->precompute = -1;
+        int rs = up(qa, &pk->a_sparse);
+        rs = rs ? rs : up(qb1, &pk->b_g1_sparse);
+        rs = rs ? rs : up(qb2, &pk->b_g2_sparse);
+        rs = rs ? rs : up(ql, &pk->l_sparse);
+        C->msm_c = saved_c; C->precompute = saved_pre;
+        const bool whole = !rs && pk->a_sparse->c == cs && pk->b_g1_sparse->c == cs && pk->b_g2_sparse->c == cs && pk->l_sparse->c == cs &&
+                           pk->a_sparse->groups == pk->b_g1_sparse->groups && pk->a_sparse->groups == pk->b_g2_sparse->groups && pk->a_sparse->groups == pk->l_sparse->groups;
+        if (!whole) {  // (not enough memory for all four, or fewer groups than windows somewhere: the key works without them)
+          pcdhip_bases_free(C, pk->a_sparse); pcdhip_bases_free(C, pk->b_g1_sparse); pcdhip_bases_free(C, pk->b_g2_sparse); pcdhip_bases_free(C, pk->l_sparse);
+          pk->a_sparse = pk->b_g1_sparse = pk->b_g2_sparse = pk->l_sparse = nullptr;
+        }
+      }
+    }
     *res = pk;
     return PCDHIP_OK;
   };
@@ -1466,10 +1504,24 @@ void pcdhip_g16_pk_free(pcdhip_ctx* ctx, pcdhip_g16_pk* pk) {
   if (pk->r1cs_dev) (void)hipFree(pk->r1cs_dev);
   pcdhip_bases_free(ctx, pk->a_query); pcdhip_bases_free(ctx, pk->b_g1_query); pcdhip_bases_free(ctx, pk->b_g2_query);
   pcdhip_bases_free(ctx, pk->h_query); pcdhip_bases_free(ctx, pk->l_query);
+  pcdhip_bases_free(ctx, pk->a_sparse); pcdhip_bases_free(ctx, pk->b_g1_sparse); pcdhip_bases_free(ctx, pk->b_g2_sparse); pcdhip_bases_free(ctx, pk->l_sparse);
   delete pk;
 }
 
 namespace {
+// scalars of `can` (n canonical values of sw words) that are neither 0 nor 1
+__global__ void __launch_bounds__(256) count_general_kernel(const uint32_t* __restrict__ can, uint32_t n, int sw, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool g = false;
+  if (i < n) {
+    const uint32_t* p = can + (size_t)i * sw;
+    uint32_t hi = 0;
+    for (int k = 1; k < sw; k++) hi |= p[k];
+    g = hi != 0 || p[0] > 1u;
+  }
+  const unsigned long long b = __ballot(g);
+  if ((threadIdx.x & 63u) == 0 && b) atomicAdd(out, (uint32_t)__popcll(b));
+}
 // One device's share of a Groth16 proof: the scalar vectors (assignment z followed by the tail [r, s, -rs, 1], canonical words,
 // and their s / r multiples), the MSMs over an entry range of the device's queries, their results.  An ordinary context runs one
 // of these over the whole key; a multi-device context one per device over that device's ranges.
@@ -1485,6 +1537,8 @@ struct G16Run {
   Job jobs[6];
   int nj = 0;
   bool use_lane = false;      // the jobs' accumulate kernels run one after the other on the context's lane (pcdhip_groth16_set_schedule 2)
+  bool sparse = false;        // the assignment MSMs take the key's sparse-window copies (decide_sparse)
+  uint32_t* general_dev = nullptr;
   uint32_t* slot(int i) const { return (uint32_t*)((char*)msm_g1 + (size_t)i * j1); }
   size_t partial_bytes() const { return 6 * j1 + j2; }  // msm_g1 (six slots) and msm_g2 are contiguous
 
@@ -1500,7 +1554,7 @@ struct G16Run {
     hipStream_t st = ctx->stream;
     TRY(ctx->aux_ws.ensure(AUX_Z, m * fe.words * 4));
     TRY(ctx->aux_ws.ensure(AUX_SCAL, m * sb));
-    TRY(ctx->aux_ws.ensure(AUX_Z_CANON, 3 * (m + 4) * sb + 2 * sb));
+    TRY(ctx->aux_ws.ensure(AUX_Z_CANON, 3 * (m + 4) * sb + 2 * sb + 64));
     TRY(ctx->aux_ws.ensure(AUX_H_CANON, n_dom * sb));
     z_dev = (uint32_t*)ctx->aux_ws.buf[AUX_Z];
     uint32_t* z_abi = (uint32_t*)ctx->aux_ws.buf[AUX_SCAL];
@@ -1508,6 +1562,7 @@ struct G16Run {
     sz_can = z_can + (m + 4) * sw;
     rz_can = sz_can + (m + 4) * sw;
     rs_dev = rz_can + (m + 4) * sw;  // r, s (C-ABI Montgomery)
+    general_dev = rs_dev + 2 * sw;   // one word: the count of general scalars (decide_sparse)
     h_can = (uint32_t*)ctx->aux_ws.buf[AUX_H_CANON];
     TRY(hipMemcpyAsync(z_abi, z, m * sb, hipMemcpyHostToDevice, st));
     TRY(hipMemcpyAsync(rs_dev, r_mont, sb, hipMemcpyHostToDevice, st));
@@ -1540,6 +1595,25 @@ struct G16Run {
     ctx->g16_share_b.valid = false;
     nj = 0;
     use_lane = ctx->g16_schedule == 2 && ctx->lane.stream;
+    return PCDHIP_OK;
+  }
+  // Which copies the four assignment MSMs run on: the sparse-window ones when at most an eighth of the assignment is general (neither 0 nor 1).
+  // One small kernel over the canonical scalars and a 4-byte read-back: the only point where pcdhip_groth16_prove waits for the device before
+  // its last launch (the upload is done by then; everything behind it is queued within 0.4 ms, profiles/r05_prove_host_enqueue.txt).
+  int decide_sparse(bool folded) {
+    sparse = false;
+    ctx->g16_last_sparse = 0; ctx->g16_last_general = 0;
+    if (folded || !pk->a_sparse) return PCDHIP_OK;   // (the folded form multiplies every scalar by s / r: nothing stays 0 / 1 but the zeros)
+    BIND();
+    hipStream_t st = ctx->stream;
+    TRY(hipMemsetAsync(general_dev, 0, 4, st));
+    hipLaunchKernelGGL(count_general_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, z_can, (uint32_t)m, (int)sw, general_dev);
+    uint32_t general = 0;
+    TRY(hipMemcpyAsync(&general, general_dev, 4, hipMemcpyDeviceToHost, st));
+    TRY(hipStreamSynchronize(st));
+    ctx->g16_last_general = general;
+    sparse = (uint64_t)general * 8 <= m;
+    ctx->g16_last_sparse = sparse ? 1 : 0;
     return PCDHIP_OK;
   }
   int launch(int k, hipEvent_t after) {
@@ -1577,7 +1651,8 @@ struct G16Run {
     // the same entries, get a sort of their own when enough of them are infinite to pay for it (a sort is ~15 % of a G1 MSM, ~5 % of a G2
     // one; the accumulations shrink by the infinite fraction).
     auto plain = [](MsmBasesView v) { v.inf_bits = nullptr; return v; };
-    const MsmBasesView va = pk->a_query->view(0), vb1 = pk->b_g1_query->view(0), vb2 = pk->b_g2_query->view(0), vl = pk->l_query->view(0);
+    const MsmBasesView va = (sparse ? pk->a_sparse : pk->a_query)->view(0), vb1 = (sparse ? pk->b_g1_sparse : pk->b_g1_query)->view(0),
+                       vb2 = (sparse ? pk->b_g2_sparse : pk->b_g2_query)->view(0), vl = (sparse ? pk->l_sparse : pk->l_query)->view(0);
     const bool sparse_b = pk->b_inf_count * 16 > cnt;
     if (folded) {
       // (A leaves the shared list for a sort of its own when enough of its entries are infinite AND the MSM is large: at 2^16 the sort costs
@@ -1841,6 +1916,8 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   const size_t fold_below = fe.abi_words > 12 ? (1u << 18) : (1u << 17);
   const bool folded = ctx->g16_assembly == 1 || (ctx->g16_assembly == 0 && m + 4 <= fold_below);
   rc = run.prepare(z, r_mont, s_mont, n, folded);
+  if (rc) return rc;
+  rc = run.decide_sparse(folded);
   if (rc) return rc;
   // Schedule (pcdhip_groth16_set_schedule).  Default 0: the four assignment MSMs are launched BEFORE the witness map and run concurrently
   // with it; the h MSM follows the map.  Inside a proof the map's ~30 short dependent kernels wait behind the MSMs' accumulate grids (the 8 ms

@@ -63,6 +63,9 @@ struct pcdhip_g16_pk {
   uint64_t num_vars = 0, num_inputs = 0, domain_size = 0;
   // a / b / l queries carry four trailing slots [delta_r, delta_s, delta_rs, vk point] (see inst_g16.hip)
   pcdhip_bases *a_query = nullptr, *b_g1_query = nullptr, *b_g2_query = nullptr, *h_query = nullptr, *l_query = nullptr;
+  // the same a' / b' / l' queries laid out for a SMALLER window (round 5, pcdhip_groth16_set_sparse_window): what a proof over a witness-like
+  // assignment -- a few per cent general scalars, the rest zero or one -- runs its four assignment MSMs on; null when not built
+  pcdhip_bases *a_sparse = nullptr, *b_g1_sparse = nullptr, *b_g2_sparse = nullptr, *l_sparse = nullptr;
   // multi-device key: shard g holds the entry range [lo[g], lo[g + 1]) of the a' / b' / l' queries (num_vars + 4 entries) and the
   // range [hlo[g], hlo[g + 1]) of the h query on the context's device g; the parent's own query handles are null
   std::vector<pcdhip_g16_pk*> shards;
@@ -104,6 +107,9 @@ struct pcdhip_ctx {
   int fft_passes = 0;
   float g16_ms[8] = {0};
   int g16_assembly = 0;  // s*A and r*B_1: 0 automatic, 1 folded into two extra MSMs, 2 chained one-lane products
+  int g16_sparse_window = -1;            // pcdhip_groth16_set_sparse_window: -1 automatic (large whole keys, when the copies fit), 0 off, > 0 that many window bits
+  uint32_t g16_last_general = 0;         // general scalars (neither 0 nor 1) of the last proof's assignment, when counted
+  int g16_last_sparse = 0;               // 1: the last proof ran its assignment MSMs on the sparse-window copies
   hipEvent_t t0 = nullptr, t1 = nullptr;
   // pcdhip_msm_submit / collect: up to PIPE_SLOTS independent MSMs in flight, each on one of the side streams (g16_streams[2 + slot],
   // with that stream's workspace); results land in page-locked host memory

@@ -123,3 +123,52 @@ def test_key_plan_report_and_lane_reserve(co, gpu_ctx):
         gpu_ctx.groth16_set_schedule(0)
         gpu_ctx.set_lane_reserve(-1)
         pk.free()
+
+
+@pytest.mark.parametrize("cid,nc,bits", [(0, 40000, 12), (1, 9000, 10), (3, 4000, 9)])
+def test_sparse_window_plan(co, gpu_ctx, cid, nc, bits):
+    """pcdhip_groth16_set_sparse_window (round 5): a key that also carries its a / b / l queries laid out for a shorter window; the prover counts the
+    general scalars of the assignment on the device and takes those copies for a witness-like assignment, the ordinary ones for a dense one --
+    the proof equals the oracle's either way, in both assembly forms (the folded one never takes them), and a key uploaded with the plan switched
+    off behaves as before."""
+    fr = co.CURVE_FR[cid]
+    r = co.witness_r1cs(fr, nc, 2, seed=4800 + cid)
+    rs = co.gen_field(fr, 2, seed=4810 + cid)
+    keys = co.synthetic_keys(cid, r, seed=4820 + cid)
+    want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)
+    z = co.fp_op(fr, "to_canonical", np.ascontiguousarray(r.z))
+    general = int(((z[:, 0] > 1) | z[:, 1:].any(axis=1)).sum())
+    # the same system with a dense assignment: the matrices stay, z is replaced by what satisfies nothing in particular -- a proof is a function of
+    # (key, matrices, z) whether or not z satisfies the system, and the oracle computes the same function
+    import copy
+    rd = copy.copy(r)
+    rd.z = co.gen_field(fr, r.z.shape[0], seed=4830 + cid)
+    want_d, winf_d = co.groth16_prove(keys, rd, rs[0], rs[1], nthreads=THREADS)
+    try:
+        gpu_ctx.groth16_set_sparse_window(bits)
+        pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
+        try:
+            for mode, expect_sparse in ((2, True), (1, False)):
+                gpu_ctx.groth16_set_assembly(mode)
+                got, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
+                assert np.array_equal(got, want) and np.array_equal(inf, winf), (cid, mode)
+                used, counted = gpu_ctx.groth16_last_plan()
+                assert used == expect_sparse and (counted == general if mode == 2 else counted == 0), (cid, mode, used, counted, general)
+            gpu_ctx.groth16_set_assembly(2)
+            got, inf = gpu_ctx.groth16_prove(pk, rd, rs[0], rs[1])
+            assert np.array_equal(got, want_d) and np.array_equal(inf, winf_d)
+            used, counted = gpu_ctx.groth16_last_plan()
+            assert not used and counted * 8 > rd.z.shape[0]
+        finally:
+            pk.free()
+        gpu_ctx.groth16_set_sparse_window(0)
+        pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
+        try:
+            got, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
+            assert np.array_equal(got, want) and np.array_equal(inf, winf)
+            assert gpu_ctx.groth16_last_plan() == (False, 0)
+        finally:
+            pk.free()
+    finally:
+        gpu_ctx.groth16_set_sparse_window(-1)
+        gpu_ctx.groth16_set_assembly(0)

@@ -20,6 +20,8 @@ if os.environ.get("AB_BENCH_INPUTS"):   # exactly what bench.py's pcd_step prove
 else:
     keys = co.synthetic_keys(curve, r, seed=78, mt=True, consistent=os.environ.get("AB_DENSE", "0") != "1")
 rs = co.gen_field(fr, 2, seed=79)
+if os.environ.get("AB_SPARSE_WINDOW"):   # pcdhip_groth16_set_sparse_window: -1 automatic, 0 off, 6..22 forced bits
+    ctx.groth16_set_sparse_window(int(os.environ["AB_SPARSE_WINDOW"]))
 pk = ctx.g16_pk_upload(keys.host_struct(), curve)
 ctx.g16_pk_set_r1cs(pk, r)
 r.z = capi.pinned_like(r.z)
@@ -41,7 +43,8 @@ for item in os.environ.get("AB_SCHEDULES", "0,2:8,0,2:8").split(","):
     for _ in range(7):
         t0 = time.perf_counter(); ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True); walls.append((time.perf_counter() - t0) * 1e3)
     tm = {k: round(float(v), 2) for k, v in ctx.groth16_last_timings().items()}
-    print(f"lib={os.environ.get('PCDHIP_LIB', 'in-tree')} curve={curve} schedule={item} prove wall ms median {np.median(walls):.3f} min {min(walls):.3f}; device {tm}", flush=True)
+    plan = ctx.groth16_last_plan() if hasattr(ctx, "groth16_last_plan") else None
+    print(f"lib={os.environ.get('PCDHIP_LIB', 'in-tree')} curve={curve} schedule={item} prove wall ms median {np.median(walls):.3f} min {min(walls):.3f}; device {tm}; sparse plan {plan}", flush=True)
 if os.environ.get("AB_MAP_ALONE"):   # the witness map with the device to itself, same matrices and assignment
     wm = [ctx.witness_map_resident(pk, r, want_h=False)[1] for _ in range(5)][-1]
     print(f"witness map alone, device ms: { {k: round(float(v), 3) for k, v in wm.items()} }", flush=True)
