@@ -1421,13 +1421,16 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
     // over that bucket window cost every one of its four MSMs the same as a dense list: ~1.7 ms of device-filling work per G1 MSM of a proof
     // that takes 8.3 (profiles/r05_witness_like_critical_path.txt).  With copies for a window four bits shorter as well -- what the picker
     // chooses for a sixteenth of the entries -- pcdhip_groth16_prove counts the general scalars and takes the copies that fit the list.
-    // Whole keys on an ordinary context only; automatic mode builds them for large keys whose extra copies fit 12 GB (9.2 GB for a 298-bit key of 2^20 entries).
+    // Whole keys on an ordinary context only; automatic mode builds them for large keys whose extra copies take at most a quarter of the memory that
+    // is free at upload (9.2 GB for a 298-bit key of 2^20 entries, 54 GB for a 753-bit one; pcdhip_set_precompute_budget applies to them as to any vector).
     if (C == ctx && ctx->peers.size() <= 1 && ctx->g16_sparse_window != 0 && pk->a_query && pk->a_query->groups > 1 &&
         (ctx->g16_sparse_window > 0 || hi - lo >= ((size_t)1 << 18))) {
       const int cs = ctx->g16_sparse_window > 0 ? ctx->g16_sparse_window : std::max(8, pk->a_query->c - 4);
       const int Ws = (group_entry(cid, 1).scalar_bits + 1 + cs - 1) / cs;
       const size_t extra = (size_t)Ws * (hi - lo) * (3 * (size_t)group_entry(cid, 1).point_words + (size_t)group_entry(cid, 2).point_words) * 4;
-      if (cs != pk->a_query->c && (ctx->g16_sparse_window > 0 || extra <= ((size_t)12 << 30))) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+      if (cs != pk->a_query->c && (ctx->g16_sparse_window > 0 || extra <= free_b / 4)) {
         const int saved_c = C->msm_c, saved_pre = C->precompute;
         C->msm_c = cs; C->msm_c_bias = 0; C->precompute = -1;
         int rs = up(qa, &pk->a_sparse);
