@@ -1512,18 +1512,22 @@ void pcdhip_g16_pk_free(pcdhip_ctx* ctx, pcdhip_g16_pk* pk) {
 }
 
 namespace {
-// scalars of `can` (n canonical values of sw words) that are neither 0 nor 1
+// scalars of `can` (n canonical values of sw words) that are neither 0 nor 1 (grid-stride, one atomic per workgroup: the count is read back by the
+// host before the proof's MSMs are launched, so its latency is on the proof's path -- one atomic per wave on one address took 110 us at 2^20)
 __global__ void __launch_bounds__(256) count_general_kernel(const uint32_t* __restrict__ can, uint32_t n, int sw, uint32_t* __restrict__ out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool g = false;
-  if (i < n) {
+  __shared__ uint32_t block_count;
+  if (threadIdx.x == 0) block_count = 0;
+  __syncthreads();
+  uint32_t mine = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint32_t* p = can + (size_t)i * sw;
     uint32_t hi = 0;
     for (int k = 1; k < sw; k++) hi |= p[k];
-    g = hi != 0 || p[0] > 1u;
+    mine += (hi != 0 || p[0] > 1u) ? 1u : 0u;
   }
-  const unsigned long long b = __ballot(g);
-  if ((threadIdx.x & 63u) == 0 && b) atomicAdd(out, (uint32_t)__popcll(b));
+  if (mine) atomicAdd(&block_count, mine);
+  __syncthreads();
+  if (threadIdx.x == 0 && block_count) atomicAdd(out, block_count);
 }
 // One device's share of a Groth16 proof: the scalar vectors (assignment z followed by the tail [r, s, -rs, 1], canonical words,
 // and their s / r multiples), the MSMs over an entry range of the device's queries, their results.  An ordinary context runs one
@@ -1610,7 +1614,7 @@ struct G16Run {
     BIND();
     hipStream_t st = ctx->stream;
     TRY(hipMemsetAsync(general_dev, 0, 4, st));
-    hipLaunchKernelGGL(count_general_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, z_can, (uint32_t)m, (int)sw, general_dev);
+    hipLaunchKernelGGL(count_general_kernel, dim3((unsigned)std::min<size_t>((m + 255) / 256, 1024)), dim3(256), 0, st, z_can, (uint32_t)m, (int)sw, general_dev);
     uint32_t general = 0;
     TRY(hipMemcpyAsync(&general, general_dev, 4, hipMemcpyDeviceToHost, st));
     TRY(hipStreamSynchronize(st));
