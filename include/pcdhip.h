@@ -268,10 +268,11 @@ int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode);
  * window-shifted copies and chosen for a dense scalar vector; the assignment of a verifier circuit (reference src/ec_cycle_pcd/data_structures.rs:269-304:
  * bit decompositions) is zeros and ones with a few per cent general scalars, and the bucket reduction of the dense window then costs more than the
  * additions.  bits: -1 (default) pcdhip_g16_pk_upload also lays the a / b_g1 / b_g2 / l queries out for a window four bits shorter when the key is a
- * whole key of at least 2^18 entries on an ordinary context and the extra copies take at most a quarter of the device memory free at that moment
+ * whole key of at least 2^18 entries (2^14 over the 298-bit fields) on an ordinary context and the extra copies take at most a quarter of the device memory free at that moment
  * (9.2 GB for a 298-bit key of 2^20 entries, 54 GB for a 753-bit one); 0 never; 6 .. 22: always, with that window.  Takes effect
  * at the next key upload.  pcdhip_groth16_prove counts the general scalars (neither 0 nor 1) of the assignment on the device and runs the four MSMs
- * on the shorter-window copies when they are at most an eighth of it (chained assembly only); the proof is the same either way.
+ * on the shorter-window copies when they are at most an eighth of it (chained assembly only -- which a small 298-bit proof with such an assignment
+ * then takes instead of the folded form its size would choose); the proof is the same either way.
  * pcdhip_groth16_last_plan: out[0] = 1 when the last proof took them, out[1] = its count of general scalars (0 when not counted). */
 int pcdhip_groth16_set_sparse_window(pcdhip_ctx* ctx, int bits);
 int pcdhip_groth16_last_plan(pcdhip_ctx* ctx, uint32_t out[2]);

@@ -1424,7 +1424,7 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
     // Whole keys on an ordinary context only; automatic mode builds them for large keys whose extra copies take at most a quarter of the memory that
     // is free at upload (9.2 GB for a 298-bit key of 2^20 entries, 54 GB for a 753-bit one; pcdhip_set_precompute_budget applies to them as to any vector).
     if (C == ctx && ctx->peers.size() <= 1 && ctx->g16_sparse_window != 0 && pk->a_query && pk->a_query->groups > 1 &&
-        (ctx->g16_sparse_window > 0 || hi - lo >= ((size_t)1 << 18))) {
+        (ctx->g16_sparse_window > 0 || hi - lo >= ((size_t)1 << 18) || (field_entry(kCurveFr[cid]).abi_words <= 12 && hi - lo >= ((size_t)1 << 14)))) {
       const int cs = ctx->g16_sparse_window > 0 ? ctx->g16_sparse_window : std::max(8, pk->a_query->c - 4);
       const int Ws = (group_entry(cid, 1).scalar_bits + 1 + cs - 1) / cs;
       const size_t extra = (size_t)Ws * (hi - lo) * (3 * (size_t)group_entry(cid, 1).point_words + (size_t)group_entry(cid, 2).point_words) * 4;
@@ -1621,6 +1621,16 @@ struct G16Run {
     ctx->g16_last_general = general;
     sparse = (uint64_t)general * 8 <= m;
     ctx->g16_last_sparse = sparse ? 1 : 0;
+    return PCDHIP_OK;
+  }
+  // the s z / r z copies of the folded form, when prepare() was told to leave them out (the form is chosen after the count)
+  int scale_for_fold() {
+    BIND();
+    const FieldEntry& fe = field_entry(kCurveFr[cid]);
+    hipStream_t st = ctx->stream;
+    TRY(fe.scale_canon(st, z_dev, rs_dev + sw, sz_can, (uint32_t)m, 1));
+    TRY(fe.scale_canon(st, z_dev, rs_dev, rz_can, (uint32_t)m, 1));
+    TRY(hipEventRecord(ctx->g16_ready, st));
     return PCDHIP_OK;
   }
   int launch(int k, hipEvent_t after) {
@@ -1921,11 +1931,19 @@ int pcdhip_groth16_prove(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_
   // (753-bit, 2^16) of throughput.  Measured (folded vs chained, round 5): 17.6 vs 16.2 ms (298-bit, 2^20), 3.8 vs 5.0 ms (298-bit, 2^16),
   // 202 vs 180 ms (753-bit, 2^20), 29.7 vs 42.0 ms (753-bit, 5 * 2^14).
   const size_t fold_below = fe.abi_words > 12 ? (1u << 18) : (1u << 17);
-  const bool folded = ctx->g16_assembly == 1 || (ctx->g16_assembly == 0 && m + 4 <= fold_below);
-  rc = run.prepare(z, r_mont, s_mont, n, folded);
+  bool folded = ctx->g16_assembly == 1 || (ctx->g16_assembly == 0 && m + 4 <= fold_below);
+  // (a SMALL proof over the 298-bit fields whose assignment turns out sparse takes the chained form after all: the shorter-window copies make its
+  //  four MSMs cheap, and the folded form -- every scalar times s / r -- cannot use them: MNT6-298 at 2^16, witness-like: 3.36 ms folded,
+  //  3.08 chained on 12-bit copies; over the 753-bit fields the one-point products (~9 ms) lose: 18.4 against 18.0)
+  const bool may_unfold = ctx->g16_assembly == 0 && folded && pk->a_sparse && fe.abi_words <= 12;
+  rc = run.prepare(z, r_mont, s_mont, n, folded && !may_unfold);
   if (rc) return rc;
-  rc = run.decide_sparse(folded);
+  rc = run.decide_sparse(folded && !may_unfold);
   if (rc) return rc;
+  if (may_unfold) {
+    if (run.sparse) folded = false;
+    else { rc = run.scale_for_fold(); if (rc) return rc; }
+  }
   // Schedule (pcdhip_groth16_set_schedule).  Default 0: the four assignment MSMs are launched BEFORE the witness map and run concurrently
   // with it; the h MSM follows the map.  Inside a proof the map's ~30 short dependent kernels wait behind the MSMs' accumulate grids (the 8 ms
   // map of a 753-bit proof ends at 160 ms) and the h MSM runs last -- which LOOKS like a serialised tail, so round 4 built mode 1: the map
