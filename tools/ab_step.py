@@ -38,7 +38,7 @@ for item in os.environ.get("AB_SCHEDULES", "0,2:8,0,2:8").split(","):
     for _ in range(3):
         proof, _ = ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
     first = proof if first is None else first
-    assert os.environ.get("PCDHIP_G16_SKIP") or np.array_equal(proof, first)
+    assert np.array_equal(proof, first)
     walls = []
     for _ in range(7):
         t0 = time.perf_counter(); ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True); walls.append((time.perf_counter() - t0) * 1e3)
