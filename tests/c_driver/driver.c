@@ -133,6 +133,27 @@ int main(int argc, char** argv) {
   if (!rc) rc = pcdhip_groth16_prove(ctx, pk, NULL, NULL, NULL, z, r, s, proof, inf);
   if (rc) { fprintf(stderr, "prove: %s (%s)\n", pcdhip_strerror(rc), pcdhip_last_hip_error(ctx)); return 4; }
   int bad = memcmp(proof, want, pw * 8) != 0 || memcmp(inf, want_inf, 3) != 0;
+  /* the same proof from a key that also carries its assignment queries for a shorter window (pcdhip_groth16_set_sparse_window): the prover
+   * counts the general scalars of z and picks -- the bytes do not depend on which copies it took */
+  {
+    pcdhip_g16_pk* pk2 = NULL;
+    uint32_t plan[2] = {7, 7};
+    uint64_t* proof2 = (uint64_t*)calloc(pw, 8);
+    uint8_t inf2[3] = {0, 0, 0};
+    rc = pcdhip_groth16_set_sparse_window(ctx, 8);
+    if (!rc) rc = pcdhip_g16_pk_upload(ctx, &k, &pk2);
+    if (!rc) rc = pcdhip_g16_pk_set_r1cs(ctx, pk2, &A, &B, &C);
+    if (!rc) rc = pcdhip_groth16_set_assembly(ctx, 2);
+    if (!rc) rc = pcdhip_groth16_prove(ctx, pk2, NULL, NULL, NULL, z, r, s, proof2, inf2);
+    if (!rc) rc = pcdhip_groth16_last_plan(ctx, plan);
+    if (rc) { fprintf(stderr, "prove (sparse-window key): %s (%s)\n", pcdhip_strerror(rc), pcdhip_last_hip_error(ctx)); return 6; }
+    bad |= memcmp(proof2, want, pw * 8) != 0 || memcmp(inf2, want_inf, 3) != 0 || plan[0] > 1 || plan[1] > m;
+    bad |= pcdhip_groth16_set_sparse_window(ctx, 3) != PCDHIP_E_ARG || pcdhip_groth16_last_plan(ctx, NULL) != PCDHIP_E_ARG;
+    (void)pcdhip_groth16_set_sparse_window(ctx, -1);
+    (void)pcdhip_groth16_set_assembly(ctx, 0);
+    pcdhip_g16_pk_free(ctx, pk2);
+    free(proof2);
+  }
   /* the same key material through the MSM entry point */
   pcdhip_bases* bases = NULL;
   uint64_t* xyz = (uint64_t*)calloc(l1 / 2 * 3, 8);
