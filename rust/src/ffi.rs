@@ -50,6 +50,8 @@ extern "C" {
     pub fn pcdhip_g16_pk_free(ctx: *mut pcdhip_ctx, pk: *mut pcdhip_g16_pk);
     pub fn pcdhip_groth16_prove(ctx: *mut pcdhip_ctx, pk: *const pcdhip_g16_pk, a: *const pcdhip_csr, b: *const pcdhip_csr, c: *const pcdhip_csr,
                                 z: *const u64, r: *const u64, s: *const u64, proof: *mut u64, inf: *mut u8) -> c_int;
+    // key memory: the second layout of a key's assignment queries (a window per proof; INTEGRATION.md "Key memory"): -1 automatic, 0 never, 6..22 bits
+    pub fn pcdhip_groth16_set_sparse_window(ctx: *mut pcdhip_ctx, bits: c_int) -> c_int;
     // 8f rank 2: generate_parameters after synthesis
     pub fn pcdhip_groth16_setup(ctx: *mut pcdhip_ctx, curve: c_int, a: *const pcdhip_csr, b: *const pcdhip_csr, c: *const pcdhip_csr,
                                 num_vars: usize, num_inputs: usize, g1_xy: *const u64, g2_xy: *const u64, toxic: *const u64,

@@ -41,6 +41,11 @@ pub(crate) fn with_device<T>(f: impl FnOnce(&mut Device) -> Result<T, Error>) ->
             .split(',').filter_map(|t| t.trim().parse().ok()).collect();
         let mut ctx = core::ptr::null_mut();
         ffi::check(unsafe { ffi::pcdhip_init_devices(ids.as_ptr(), ids.len() as c_int, &mut ctx) })?;
+        // the second layout of a key's assignment queries (a window per proof: the assignment of the reference's circuits is bit decompositions,
+        // data_structures.rs:269-304): automatic unless the host says otherwise -- it caches up to MAX_CACHED_KEYS keys on one device
+        if let Some(bits) = std::env::var("PCDHIP_SPARSE_WINDOW").ok().and_then(|v| v.trim().parse::<c_int>().ok()) {
+            ffi::check(unsafe { ffi::pcdhip_groth16_set_sparse_window(ctx, bits) })?;
+        }
         *guard = Some(Device { ctx, keys: Vec::new(), vks: Vec::new(), clock: 0, #[cfg(feature = "s2")] bases: Vec::new() });
     }
     f(guard.as_mut().unwrap())
