@@ -31,7 +31,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # (ORACLE_LIB: the sanitizer build, tests/test_sanitizers.py)
+        so = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # (ORACLE_LIB: the sanitizer build, tools/san/test_sanitizers.py)
         if not os.path.exists(so):
             build()
         _LIB = C.CDLL(so)

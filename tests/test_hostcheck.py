@@ -34,19 +34,21 @@ def hc():
     csrc = os.path.join(ROOT, "pcd_amd", "csrc")
     hdrs = [os.path.join(csrc, f) for f in ("fp.hip.h", "ec.hip.h", "pairing.hip.h", "pairing_vm.hip.h", "pairing_vm_gen.h", "vm_tables.h",
                                             "params_gen.h", "params28_gen.h")]
-    jobs = []
-    # HOSTCHECK_SAN=1 (tests/test_sanitizers.py, opt-in leg): the same harness compiled host-only under AddressSanitizer into build/san
-    san = os.environ.get("HOSTCHECK_SAN") == "1"
-    out_dir = os.path.join(ROOT, "build", "san") if san else HC
-    os.makedirs(out_dir, exist_ok=True)
-    flags = ["--cuda-host-only", "-fsanitize=address", "-shared-libsan", "-g"] if san else ["--offload-arch=gfx950"]
-    for stem in ("hostcheck", "hostcheck_pairing"):
-        so, src = os.path.join(out_dir, f"lib{stem}.so"), os.path.join(HC, f"{stem}.hip")
-        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in [src] + hdrs):
-            jobs.append(subprocess.Popen(["hipcc"] + flags + ["-O1", "-std=c++17", "-fPIC", "-shared", "-DPCD_LZ_CHECK", src, "-o", so],
-                                         stderr=subprocess.DEVNULL))
-    for j in jobs:
-        assert j.wait() == 0
+    # HOSTCHECK_SAN=1 (tools/san/test_sanitizers.py, opt-in leg): load the harness the sanitizer recipes of tools/san built into build/san
+    # (this file only picks the directory; every compiler flag of that build lives in tools/san/Makefile, which does not ship to the GPU box)
+    if os.environ.get("HOSTCHECK_SAN") == "1":
+        out_dir = os.path.join(ROOT, "build", "san")
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools", "san"), "hostcheck"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    else:
+        out_dir = HC
+        jobs = []
+        for stem in ("hostcheck", "hostcheck_pairing"):
+            so, src = os.path.join(out_dir, f"lib{stem}.so"), os.path.join(HC, f"{stem}.hip")
+            if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in [src] + hdrs):
+                jobs.append(subprocess.Popen(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared", "-DPCD_LZ_CHECK", src, "-o", so],
+                                             stderr=subprocess.DEVNULL))
+        for j in jobs:
+            assert j.wait() == 0
     return _Libs([C.CDLL(os.path.join(out_dir, "libhostcheck.so")), C.CDLL(os.path.join(out_dir, "libhostcheck_pairing.so"))])
 
 

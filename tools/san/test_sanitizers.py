@@ -1,11 +1,11 @@
 """Sanitizers on the CPU side (SURVEY.md section 5 "race detection / sanitizers").  GPU AddressSanitizer is not available
 on this pool, so what can be instrumented is what runs on the host:
 
-  * the C++ oracle (`make -C oracle asan`: AddressSanitizer + UndefinedBehaviorSanitizer, -fno-sanitize-recover) -- the golden-vector and
+  * the C++ oracle (`make -C tools/san oracle`: AddressSanitizer + UndefinedBehaviorSanitizer, -fno-sanitize-recover) -- the golden-vector and
     property tests of the oracle run again in a child python with the sanitizer runtimes preloaded and ORACLE_LIB pointing at that build;
     its MSM and FFT are multi-threaded, so this also walks the thread joins;
   * the library's HOST paths that need no GPU -- the wire format (pcd_amd/csrc/wire.hip: parsing of untrusted bytes, Tonelli-Shanks, subgroup
-    checks), argument checking, the no-device error paths -- from `make -C pcd_amd/csrc san` (host-only compile of the same sources under
+    checks), argument checking, the no-device error paths -- from `make -C tools/san lib` (host-only compile of the same sources under
     AddressSanitizer), again in a child python.
 
 A report from either runtime fails the test (non-zero exit of the child or a sanitizer banner in its output)."""
@@ -15,7 +15,7 @@ import sys
 
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 BANNERS = ("ERROR: AddressSanitizer", "runtime error:", "ERROR: LeakSanitizer", "SUMMARY: UndefinedBehaviorSanitizer")
 
 
@@ -32,7 +32,7 @@ def _run(env_extra, args, timeout):
 
 
 def test_oracle_under_asan_ubsan():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools", "san"), "oracle"], stdout=subprocess.DEVNULL)
     so = os.path.join(ROOT, "oracle", "_san", "liboracle_san.so")
     pre = [subprocess.check_output(["gcc", f"-print-file-name={n}"], text=True).strip() for n in ("libasan.so", "libubsan.so")]
     assert all(os.path.isabs(x) and os.path.exists(x) for x in pre), pre
@@ -43,7 +43,7 @@ def test_oracle_under_asan_ubsan():
 
 def test_library_host_paths_under_asan():
     san = os.path.join(ROOT, "build", "san", "libpcdhip_san.so")
-    r = subprocess.run(["make", "-C", os.path.join(ROOT, "pcd_amd", "csrc"), "san"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-j4", "-C", os.path.join(ROOT, "tools", "san"), "lib"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     rt = subprocess.check_output(["hipcc", "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
     if not (os.path.isabs(rt) and os.path.exists(rt)):
