@@ -118,7 +118,9 @@ int pcdhip_msm_collect(pcdhip_ctx* ctx, int ticket, uint64_t* out_xyz_mont);
  * An unreduced scalar (PCDHIP_E_ARG from pcdhip_msm_dev) is reported on this path by the NEXT submission that reuses the ticket's slot, as
  * PCDHIP_E_PREV_TICKET: a code of its own, so that a pipelined caller can tell "an earlier MSM of this slot was wrong" from "this submission
  * was refused" -- the new submission IS enqueued and *ticket valid in that case.  pcdhip_msm_ticket_status polls a released ticket's word
- * without submitting (e.g. after the last step of a loop). */
+ * without submitting (e.g. after the last step of a loop).  pcdhip_msm_submit never returns PCDHIP_E_PREV_TICKET: when it reuses a slot
+ * whose last user was released by pcdhip_msm_ticket_wait it clears that slot's deferred word unreported (poll pcdhip_msm_ticket_status
+ * first when mixing the two forms). */
 int pcdhip_msm_submit_partial(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset,
                               size_t n, uint64_t* out_xyz_device_slots, size_t slot_stride_bytes, int* ticket);
 int pcdhip_msm_ticket_wait(pcdhip_ctx* ctx, int ticket, void* other_stream);
@@ -138,6 +140,8 @@ int pcdhip_set_precompute(pcdhip_ctx* ctx, int mode);
  * hipMalloc had failed (halving until it fits; at worst the plain vector, which is always accepted).  For hosts that keep several
  * proving keys resident: the full set of copies of ONE MNT4-753 key at 2^22 constraints is ~195 GB (BASELINE configs[4]). */
 int pcdhip_set_precompute_budget(pcdhip_ctx* ctx, size_t bytes_per_vector);
+/* The bound currently set (a layer that changes it for one upload puts the host's own setting back afterwards: rust/src/s2.rs). */
+int pcdhip_get_precompute_budget(pcdhip_ctx* ctx, size_t* bytes_per_vector);
 /* The plan an MSM of n pairs over these bases runs with (n = 0: the whole vector): signed-digit window bits c, scalar
  * windows W = ceil((bits + 1) / c), and how many window-shifted copies of the vector are resident (1 = none).  bench.py
  * prices the accumulate kernel's executed multiply-adds from it. */
@@ -267,9 +271,10 @@ int pcdhip_groth16_set_assembly(pcdhip_ctx* ctx, int mode);
 /* A window per PROOF for the four MSMs over the assignment (round 5).  The window of an MSM over a resident key is fixed by the key's
  * window-shifted copies and chosen for a dense scalar vector; the assignment of a verifier circuit (reference src/ec_cycle_pcd/data_structures.rs:269-304:
  * bit decompositions) is zeros and ones with a few per cent general scalars, and the bucket reduction of the dense window then costs more than the
- * additions.  bits: -1 (default) pcdhip_g16_pk_upload also lays the a / b_g1 / b_g2 / l queries out for a window four bits shorter when the key is a
+ * additions.  OPT-IN (the second layout more than doubles a key's memory, upload and precompute time, and a host may keep several keys resident):
+ * bits: 0 (default) never; -1 automatic: pcdhip_g16_pk_upload also lays the a / b_g1 / b_g2 / l queries out for a window four bits shorter when the key is a
  * whole key of at least 2^18 entries (2^14 over the 298-bit fields) on an ordinary context and the extra copies take at most a quarter of the device memory free at that moment
- * (9.2 GB for a 298-bit key of 2^20 entries, 54 GB for a 753-bit one); 0 never; 6 .. 22: always, with that window.  Takes effect
+ * (9.2 GB for a 298-bit key of 2^20 entries, 54 GB for a 753-bit one); 6 .. 22: always, with that window.  Takes effect
  * at the next key upload.  pcdhip_groth16_prove counts the general scalars (neither 0 nor 1) of the assignment on the device and runs the four MSMs
  * on the shorter-window copies when they are at most an eighth of it (chained assembly only -- which a small 298-bit proof with such an assignment
  * then takes instead of the folded form its size would choose); the proof is the same either way.

@@ -54,7 +54,7 @@ EXPORTS = [
     "pcdhip_field_limbs", "pcdhip_curve_base_field", "pcdhip_curve_scalar_field", "pcdhip_point_limbs",
     "pcdhip_buf_upload", "pcdhip_buf_alloc", "pcdhip_buf_download", "pcdhip_buf_free",
     "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config", "pcdhip_msm_submit", "pcdhip_msm_collect", "pcdhip_msm_submit_partial", "pcdhip_msm_ticket_wait", "pcdhip_msm_ticket_status", "pcdhip_bases_info", "pcdhip_stream_wait",
-    "pcdhip_set_precompute", "pcdhip_set_precompute_budget", "pcdhip_msm_set_sort", "pcdhip_msm_set_accumulate", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_msm_last_plan", "pcdhip_mad_rate", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
+    "pcdhip_set_precompute", "pcdhip_set_precompute_budget", "pcdhip_get_precompute_budget", "pcdhip_msm_set_sort", "pcdhip_msm_set_accumulate", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_msm_last_plan", "pcdhip_mad_rate", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_fft_seq", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
     "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_g16_pk_info", "pcdhip_g16_witness_map_resident", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_groth16_set_sparse_window", "pcdhip_groth16_last_plan", "pcdhip_groth16_set_witness_split", "pcdhip_groth16_set_schedule", "pcdhip_set_lane_reserve", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
     "pcdhip_serialized_size", "pcdhip_serialize_points", "pcdhip_deserialize_points", "pcdhip_deserialize_points_unchecked", "pcdhip_proof_serialized_size", "pcdhip_proof_serialize",
@@ -231,6 +231,11 @@ class Context:
     def set_precompute_budget(self, bytes_per_vector):
         """bytes one base vector uploaded afterwards may occupy with its window-shifted copies (0: no bound); fewer copies otherwise."""
         self._check(lib().pcdhip_set_precompute_budget(self._ctx, C.c_size_t(int(bytes_per_vector))))
+
+    def get_precompute_budget(self):
+        v = C.c_size_t(0)
+        self._check(lib().pcdhip_get_precompute_budget(self._ctx, C.byref(v)))
+        return v.value
 
     def msm_set_sort(self, mode):
         """0: LDS partition sort (default); 1: single-pass binning with on-device fallback; 2: two-pass counting sort."""

@@ -430,7 +430,7 @@ static int bases_upload_single(pcdhip_ctx* ctx, int curve_id, int group_id, cons
     (void)hipGetLastError();
     b->groups = (b->groups + 1) / 2;  // not enough HBM for this many copies: fewer groups, more bucket windows
   }
-  if (e != hipSuccess) { delete b; return fail(ctx, e); }
+  if (e != hipSuccess) { (void)hipGetLastError(); delete b; return fail(ctx, e); }   // (the sticky error must not surface at a later launch's hipGetLastError)
   if (b->groups == 1) b->c = 0;
   // stage the C-ABI image, rewrite flagged points to (0, 0) (not on any of the curves: b != 0), convert
   e = ctx->aux_ws.ensure(AUX_MISC, std::max<size_t>(n, 1) * (abi_b + 1) + 64);
@@ -467,6 +467,11 @@ int pcdhip_set_precompute(pcdhip_ctx* ctx, int mode) {
 int pcdhip_set_precompute_budget(pcdhip_ctx* ctx, size_t bytes_per_vector) {
   if (!ctx) return PCDHIP_E_ARG;
   ctx->precompute_budget = bytes_per_vector;
+  return PCDHIP_OK;
+}
+int pcdhip_get_precompute_budget(pcdhip_ctx* ctx, size_t* bytes_per_vector) {
+  if (!ctx || !bytes_per_vector) return PCDHIP_E_ARG;
+  *bytes_per_vector = ctx->precompute_budget;
   return PCDHIP_OK;
 }
 void pcdhip_bases_free(pcdhip_ctx* ctx, pcdhip_bases* bases) {
@@ -540,31 +545,33 @@ int pcdhip_groth16_last_plan(pcdhip_ctx* ctx, uint32_t out[2]) {
   out[0] = (uint32_t)ctx->g16_last_sparse; out[1] = ctx->g16_last_general;
   return PCDHIP_OK;
 }
-static int drop_side_streams(pcdhip_ctx* ctx);
+static int drop_side_streams(pcdhip_ctx* ctx, bool partial);
 static bool pipe_pending(const pcdhip_ctx* ctx);
 int pcdhip_groth16_set_schedule(pcdhip_ctx* ctx, int mode) {
   if (!ctx || mode < 0 || mode > 2) return PCDHIP_E_ARG;
   if (pipe_pending(ctx)) return PCDHIP_E_ARG;
   std::vector<pcdhip_ctx*> all = ctx->peers.empty() ? std::vector<pcdhip_ctx*>{ctx} : ctx->peers;
+  int first = PCDHIP_OK;
   for (pcdhip_ctx* p : all) {
     if (p->g16_schedule == mode) continue;
     p->g16_schedule = mode;
-    int rc = drop_side_streams(p);  // (their priorities depend on the schedule)
-    if (rc) return rc;
+    const int rc = drop_side_streams(p, false);  // (their priorities depend on the schedule)
+    if (rc && !first) first = rc;                // (every peer gets the new schedule before the first failure is reported: ADVICE r05)
   }
-  return PCDHIP_OK;
+  return first;
 }
 int pcdhip_set_lane_reserve(pcdhip_ctx* ctx, int cus) {
   if (!ctx || cus < -1 || cus > 128) return PCDHIP_E_ARG;
   if (pipe_pending(ctx)) return PCDHIP_E_ARG;
   std::vector<pcdhip_ctx*> all = ctx->peers.empty() ? std::vector<pcdhip_ctx*>{ctx} : ctx->peers;
+  int first = PCDHIP_OK;
   for (pcdhip_ctx* p : all) {
     if (p->lane_reserve == cus) continue;
     p->lane_reserve = cus;
-    int rc = drop_side_streams(p);
-    if (rc) return rc;
+    const int rc = drop_side_streams(p, false);
+    if (rc && !first) first = rc;
   }
-  return PCDHIP_OK;
+  return first;
 }
 int pcdhip_groth16_set_witness_split(pcdhip_ctx* ctx, int on) {
   if (!ctx) return PCDHIP_E_ARG;
@@ -680,8 +687,17 @@ static hipStream_t masked_lane_of(int device, int cus, int reserve, hipError_t* 
   if (*err == hipSuccess) pool[{device, reserve}] = s;
   return s;
 }
+static int drop_side_streams(pcdhip_ctx* ctx, bool partial);
+static int make_side_streams(pcdhip_ctx* ctx);
 static int ensure_side_streams(pcdhip_ctx* ctx) {
   if (ctx->g16_ready) return PCDHIP_OK;
+  const int rc = make_side_streams(ctx);
+  // (g16_ready is set last, so a failure partway -- a CU-masked stream the runtime refuses, the sixth stream -- used to leave
+  //  the streams and events made so far in the context, to be overwritten and leaked by the next call: destroy them here instead)
+  if (rc) (void)drop_side_streams(ctx, true);
+  return rc;
+}
+static int make_side_streams(pcdhip_ctx* ctx) {
   int least = 0, greatest = 0;
   TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
   const bool lane_mode = ctx->g16_schedule == 2;
@@ -719,10 +735,10 @@ static int ensure_side_streams(pcdhip_ctx* ctx) {
   return PCDHIP_OK;
 }
 // (a change of schedule or of the lane's reserve takes effect on streams made afresh)
-static int drop_side_streams(pcdhip_ctx* ctx) {
-  if (!ctx->g16_ready) return PCDHIP_OK;
+static int drop_side_streams(pcdhip_ctx* ctx, bool partial) {
+  if (!ctx->g16_ready && !partial) return PCDHIP_OK;
   BIND();
-  TRY(hipDeviceSynchronize());
+  if (!partial) TRY(hipDeviceSynchronize());   // (partial: nothing has been enqueued on streams that were never handed out)
   for (int k = 0; k < 6; k++) {
     if (ctx->g16_streams[k]) { (void)hipStreamDestroy(ctx->g16_streams[k]); ctx->g16_streams[k] = nullptr; }
     if (ctx->g16_begin[k]) { (void)hipEventDestroy(ctx->g16_begin[k]); ctx->g16_begin[k] = nullptr; }
@@ -730,7 +746,7 @@ static int drop_side_streams(pcdhip_ctx* ctx) {
   }
   if (ctx->lane_stream) { (void)hipStreamDestroy(ctx->lane_stream); ctx->lane_stream = nullptr; }   // (only the unmasked lane is owned)
   ctx->lane = MsmLane();
-  (void)hipEventDestroy(ctx->g16_ready);
+  if (ctx->g16_ready) (void)hipEventDestroy(ctx->g16_ready);
   ctx->g16_ready = nullptr;
   return PCDHIP_OK;
 }
@@ -805,7 +821,12 @@ int pcdhip_msm_ticket_status(pcdhip_ctx* ctx, int slot) {
 }
 int pcdhip_msm_submit(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset, size_t n,
                       int* ticket) {
-  return msm_submit_common(ctx, bases, offset, scalars, scalar_offset, n, nullptr, 0, ticket);
+  // (PCDHIP_E_PREV_TICKET belongs to the released-ticket form alone.  A plain submission that lands on a slot whose last
+  //  user was released by pcdhip_msm_ticket_wait clears that slot's deferred word without reporting it -- callers of this entry point
+  //  treat any non-zero code as a refusal and would drop a ticket that IS in flight, leaving the slot busy for good.  A caller that
+  //  mixes both forms polls pcdhip_msm_ticket_status before it switches.)
+  const int rc = msm_submit_common(ctx, bases, offset, scalars, scalar_offset, n, nullptr, 0, ticket);
+  return rc == PCDHIP_E_PREV_TICKET ? PCDHIP_OK : rc;
 }
 int pcdhip_msm_submit_partial(pcdhip_ctx* ctx, const pcdhip_bases* bases, size_t offset, const pcdhip_buf* scalars, size_t scalar_offset, size_t n,
                               uint64_t* out_xyz_device_slots, size_t slot_stride_bytes, int* ticket) {

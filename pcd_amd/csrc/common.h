@@ -107,7 +107,7 @@ struct pcdhip_ctx {
   int fft_passes = 0;
   float g16_ms[8] = {0};
   int g16_assembly = 0;  // s*A and r*B_1: 0 automatic, 1 folded into two extra MSMs, 2 chained one-lane products
-  int g16_sparse_window = -1;            // pcdhip_groth16_set_sparse_window: -1 automatic (large whole keys, when the copies fit), 0 off, > 0 that many window bits
+  int g16_sparse_window = 0;             // pcdhip_groth16_set_sparse_window: 0 off (default: opt-in), -1 automatic (large whole keys, when the copies fit), > 0 that many window bits
   uint32_t g16_last_general = 0;         // general scalars (neither 0 nor 1) of the last proof's assignment, when counted
   int g16_last_sparse = 0;               // 1: the last proof ran its assignment MSMs on the sparse-window copies
   hipEvent_t t0 = nullptr, t1 = nullptr;

@@ -38,6 +38,7 @@ extern "C" {
     pub fn pcdhip_bases_upload(ctx: *mut pcdhip_ctx, curve: c_int, group: c_int, xy: *const u64, inf: *const u8, n: usize, out: *mut *mut pcdhip_bases) -> c_int;
     pub fn pcdhip_bases_free(ctx: *mut pcdhip_ctx, b: *mut pcdhip_bases);
     pub fn pcdhip_set_precompute_budget(ctx: *mut pcdhip_ctx, bytes: usize) -> c_int;
+    pub fn pcdhip_get_precompute_budget(ctx: *mut pcdhip_ctx, bytes: *mut usize) -> c_int;
     pub fn pcdhip_msm(ctx: *mut pcdhip_ctx, bases: *const pcdhip_bases, offset: usize, scalars: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn pcdhip_to_affine(ctx: *mut pcdhip_ctx, curve: c_int, group: c_int, xyz: *const u64, n: usize, out_xy: *mut u64, out_inf: *mut u8) -> c_int;
     // K2: Radix2EvaluationDomain / GeneralEvaluationDomain transforms

@@ -27,6 +27,8 @@ pub(crate) struct DeviceVk { digest: [u8; 32], ident: Vec<u8>, curve: u32, handl
 pub(crate) struct Device {
     pub(crate) ctx: *mut ffi::pcdhip_ctx, keys: Vec<DeviceKey>, vks: Vec<DeviceVk>, pub(crate) clock: u64,
     #[cfg(feature = "s2")] pub(crate) bases: Vec<crate::s2::Resident>,
+    /// keys of the resident vectors' running digests (rust/src/s2.rs `running_digest`): drawn once per process
+    #[cfg(feature = "s2")] pub(crate) digest_keys: [std::collections::hash_map::RandomState; 2],
 }
 unsafe impl Send for Device {}
 static DEVICE: Mutex<Option<Device>> = Mutex::new(None);
@@ -42,11 +44,13 @@ pub(crate) fn with_device<T>(f: impl FnOnce(&mut Device) -> Result<T, Error>) ->
         let mut ctx = core::ptr::null_mut();
         ffi::check(unsafe { ffi::pcdhip_init_devices(ids.as_ptr(), ids.len() as c_int, &mut ctx) })?;
         // the second layout of a key's assignment queries (a window per proof: the assignment of the reference's circuits is bit decompositions,
-        // data_structures.rs:269-304): automatic unless the host says otherwise -- it caches up to MAX_CACHED_KEYS keys on one device
+        // data_structures.rs:269-304): opt-in (PCDHIP_SPARSE_WINDOW=-1 for the automatic rule, 6..22 for a window outright) -- this host caches up to
+        // MAX_CACHED_KEYS keys on one device and the second layout more than doubles a key's memory, so the library leaves it off by default
         if let Some(bits) = std::env::var("PCDHIP_SPARSE_WINDOW").ok().and_then(|v| v.trim().parse::<c_int>().ok()) {
             ffi::check(unsafe { ffi::pcdhip_groth16_set_sparse_window(ctx, bits) })?;
         }
-        *guard = Some(Device { ctx, keys: Vec::new(), vks: Vec::new(), clock: 0, #[cfg(feature = "s2")] bases: Vec::new() });
+        *guard = Some(Device { ctx, keys: Vec::new(), vks: Vec::new(), clock: 0, #[cfg(feature = "s2")] bases: Vec::new(),
+                               #[cfg(feature = "s2")] digest_keys: [std::collections::hash_map::RandomState::new(), std::collections::hash_map::RandomState::new()] });
     }
     f(guard.as_mut().unwrap())
 }

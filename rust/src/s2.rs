@@ -35,8 +35,9 @@ const SAMPLE_HEAD: usize = 64;
 const SAMPLE_STRIDED: usize = 192;
 
 /// A base vector resident on the device.  `running[i]` = digest of the points 0 ..= i, so a call on a PREFIX of a resident vector
-/// (KZG: `powers_of_g[..deg + 1]`) is recognised by content and served as `pcdhip_msm(handle, 0, .., n)`.  The digest (two 64-bit
-/// FNV-1a lanes over every limb) NOMINATES a candidate; a hit is confirmed on a SAMPLE of the points -- the first 64 and 192 spread over
+/// (KZG: `powers_of_g[..deg + 1]`) is recognised by content and served as `pcdhip_msm(handle, 0, .., n)`.  The digest (two SipHash lanes
+/// over every limb and flag, keyed with per-process random keys: `Device::digest_keys` -- ADVICE r05: the unkeyed FNV-1a of round 5 is not
+/// collision resistant, and a false hit runs the MSM over the wrong bases) NOMINATES a candidate; a hit is confirmed on a SAMPLE of the points -- the first 64 and 192 spread over
 /// the vector, their packed limbs kept here -- instead of a second full copy on the host (round 4 kept up to sixteen of them, 0.6 GB
 /// each for a 2^20-point G2 vector, and compared all n points on every call: ADVICE r04).  Two different vectors that agree on both
 /// digest lanes at the call's length AND on every sampled point do not occur by accident; an adversary who controls the bases controls
@@ -66,19 +67,21 @@ fn log_fallback(cause: &'static str) {
     }
 }
 
-/// two FNV-1a lanes over every limb and flag, point after point
-fn running_digest(xy: &[u64], inf: &[u8], words: usize) -> Vec<[u64; 2]> {
-    let mut h = [0xcbf29ce484222325u64, 0x84222325cbf29ce4u64];
+/// two keyed SipHash lanes (std's `RandomState`: random 128-bit keys drawn once per process and unknown to whoever supplies the bases) over
+/// EVERY limb and flag, point after point; `finish()` does not consume the state, so entry i is the digest of the points 0 ..= i.
+/// Both lanes see the whole stream (independent keys), so a false hit needs a simultaneous collision of two keyed 64-bit PRFs.
+fn running_digest(keys: &[std::collections::hash_map::RandomState; 2], xy: &[u64], inf: &[u8], words: usize) -> Vec<[u64; 2]> {
+    use std::hash::{BuildHasher, Hasher};
+    let mut h = [keys[0].build_hasher(), keys[1].build_hasher()];
     let mut out = Vec::with_capacity(inf.len());
     for (i, flag) in inf.iter().enumerate() {
-        for (j, w) in xy[i * words..(i + 1) * words].iter().enumerate() {
-            let k = j & 1;
-            h[k] ^= *w;
-            h[k] = h[k].wrapping_mul(0x100000001b3);
+        for w in &xy[i * words..(i + 1) * words] {
+            h[0].write_u64(*w);
+            h[1].write_u64(*w);
         }
-        h[0] ^= *flag as u64;
-        h[0] = h[0].wrapping_mul(0x100000001b3);
-        out.push(h);
+        h[0].write_u8(*flag);
+        h[1].write_u8(*flag);
+        out.push([h[0].finish(), h[1].finish()]);
     }
     out
 }
@@ -86,7 +89,7 @@ fn running_digest(xy: &[u64], inf: &[u8], words: usize) -> Vec<[u64; 2]> {
 /// `pcdhip_msm` over (a prefix of) a resident vector; uploads the vector on first sight.  `None` = let upstream run.
 fn msm_packed(dev: &mut Device, curve: u32, group: c_int, words: usize, xy: Vec<u64>, inf: Vec<u8>, scalars: &[u64], out_words: usize) -> Option<Vec<u64>> {
     let n = inf.len();
-    let running = running_digest(&xy, &inf, words);
+    let running = running_digest(&dev.digest_keys, &xy, &inf, words);
     let d = running[n - 1];
     dev.clock += 1;
     let now = dev.clock;
@@ -106,14 +109,17 @@ fn msm_packed(dev: &mut Device, curve: u32, group: c_int, words: usize, xy: Vec<
                 }
             };
             if dev.bases.len() >= MAX_RESIDENT { evict(dev); }
-            // (the budget is a property of the context and read at upload time: set for this upload, the keys' uploads set their own)
-            unsafe { ffi::pcdhip_set_precompute_budget(dev.ctx, RESIDENT_BUDGET_BYTES) };
+            // (the budget is a property of the context and read at upload time: set for this upload and put back afterwards -- ADVICE r05:
+            //  writing 0 here overwrote whatever budget the host had configured on the shared context)
+            let mut saved_budget: usize = 0;
+            unsafe { ffi::pcdhip_get_precompute_budget(dev.ctx, &mut saved_budget) };
+            unsafe { ffi::pcdhip_set_precompute_budget(dev.ctx, if saved_budget != 0 { saved_budget.min(RESIDENT_BUDGET_BYTES) } else { RESIDENT_BUDGET_BYTES }) };
             let mut h = core::ptr::null_mut();
             let mut rc = unsafe { ffi::pcdhip_bases_upload(dev.ctx, curve as c_int, group, xy.as_ptr(), inf.as_ptr(), n, &mut h) };
             if rc != 0 && evict(dev) {   // out of memory, most likely: let the least recently used vector go and try once more
                 rc = unsafe { ffi::pcdhip_bases_upload(dev.ctx, curve as c_int, group, xy.as_ptr(), inf.as_ptr(), n, &mut h) };
             }
-            unsafe { ffi::pcdhip_set_precompute_budget(dev.ctx, 0) };
+            unsafe { ffi::pcdhip_set_precompute_budget(dev.ctx, saved_budget) };
             if rc != 0 { log_fallback("pcdhip_bases_upload failed (device memory?)"); return None; }
             let sample_at = sample_positions(n);
             let mut sample_xy = Vec::with_capacity(sample_at.len() * words);

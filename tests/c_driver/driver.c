@@ -149,7 +149,7 @@ int main(int argc, char** argv) {
     if (rc) { fprintf(stderr, "prove (sparse-window key): %s (%s)\n", pcdhip_strerror(rc), pcdhip_last_hip_error(ctx)); return 6; }
     bad |= memcmp(proof2, want, pw * 8) != 0 || memcmp(inf2, want_inf, 3) != 0 || plan[0] > 1 || plan[1] > m;
     bad |= pcdhip_groth16_set_sparse_window(ctx, 3) != PCDHIP_E_ARG || pcdhip_groth16_last_plan(ctx, NULL) != PCDHIP_E_ARG;
-    (void)pcdhip_groth16_set_sparse_window(ctx, -1);
+    (void)pcdhip_groth16_set_sparse_window(ctx, 0);
     (void)pcdhip_groth16_set_assembly(ctx, 0);
     pcdhip_g16_pk_free(ctx, pk2);
     free(proof2);

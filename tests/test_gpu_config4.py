@@ -31,24 +31,13 @@ def _same_point(co, cid, grp, got, want):
     return np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1])
 
 
-def test_config4_msm_g1_753_2p22_eight_shards(co, gpu_ctx):
-    from pcd_amd import capi
+# ---- case builders (seeded inputs + the oracle's expectation as a thunk): tests/golden/gen_at_size.py commits the thunks' results, the tests
+# ---- take them through the `expect` fixture (PCD_RECOMPUTE=1 runs the oracle on the spot and checks the file)
+def _msm_2p22_case(co):
     cid, grp, n = 2, 1, 1 << 22
-    fr = co.CURVE_FR[cid]
     pts = co.gen_points_mt(cid, grp, n, seed=4400, threads=THREADS)
-    sc = co.gen_scalars(fr, n, seed=4401)
-    mctx = capi.Context(devices=_devices(8))
-    try:
-        assert capi.lib().pcdhip_ctx_devices(mctx._ctx) == 8
-        b = mctx.bases_upload(cid, grp, pts)
-        c_bits, W, copies = mctx.bases_info(b)
-        assert copies == W, (c_bits, W, copies)   # every shard holds one copy per scalar window of ITS plan (2^19 points each)
-        got = mctx.msm(b, sc)
-        b.free()
-    finally:
-        mctx.close()
-    want = co.msm(cid, grp, pts, sc, nthreads=THREADS)
-    assert _same_point(co, cid, grp, got, want)
+    sc = co.gen_scalars(co.CURVE_FR[cid], n, seed=4401)
+    return (pts, sc), lambda: tuple(co.to_affine(cid, grp, co.msm(cid, grp, pts, sc, nthreads=THREADS)))
 
 
 def _statement(co, curve, nc, seed, mt=False):
@@ -59,14 +48,53 @@ def _statement(co, curve, nc, seed, mt=False):
     return r, keys, rs
 
 
-def test_config4_arity8_branches_then_sharded_merge(co, gpu_ctx):
+def _arity8_case(co):
+    branches = [(_statement(co, 2, (1 << 13) - 8 - i, seed=4500 + 10 * i), _statement(co, 3, (1 << 12) + 500 + i, seed=4505 + 10 * i)) for i in range(8)]
+    merge = _statement(co, 2, (1 << 17) - 8, seed=4600, mt=True)
+
+    def want():
+        out = []
+        for main, helper in branches:
+            out += [co.groth16_prove(k, r, rs[0], rs[1], nthreads=THREADS)[0] for r, k, rs in (main, helper)]
+        r, keys, rs = merge
+        return tuple(out + list(co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)))
+    return (branches, merge), want
+
+
+def _merge_2p22_case(co):
+    r, keys, rs = _statement(co, 2, (1 << 22) - 8, seed=2200, mt=True)
+    return (r, keys, rs), lambda: tuple(co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS))
+
+
+AT_SIZE = {"msm_c2g1_2p22": _msm_2p22_case, "arity8_branches_and_merge_2p17": _arity8_case, "merge_proof_c2_2p22": _merge_2p22_case}
+
+
+def test_config4_msm_g1_753_2p22_eight_shards(co, gpu_ctx, expect):
+    from pcd_amd import capi
+    cid, grp = 2, 1
+    (pts, sc), want_fn = _msm_2p22_case(co)
+    mctx = capi.Context(devices=_devices(8))
+    try:
+        assert capi.lib().pcdhip_ctx_devices(mctx._ctx) == 8
+        b = mctx.bases_upload(cid, grp, pts)
+        c_bits, W, copies = mctx.bases_info(b)
+        assert copies == W, (c_bits, W, copies)   # every shard holds one copy per scalar window of ITS plan (2^19 points each)
+        got = mctx.msm(b, sc)
+        b.free()
+    finally:
+        mctx.close()
+    want = expect("msm_c2g1_2p22", want_fn)
+    g = co.to_affine(cid, grp, got)
+    assert np.array_equal(g[0], want[0]) and np.array_equal(g[1], want[1])
+
+
+def test_config4_arity8_branches_then_sharded_merge(co, gpu_ctx, expect):
     from pcd_amd import capi, dag
     # eight prior messages: each branch proves a main (MNT4-753, domain 2^13) and a help (MNT6-753, domain 2^13) statement
-    jobs, wants = [], []
-    for i in range(8):
-        main = _statement(co, 2, (1 << 13) - 8 - i, seed=4500 + 10 * i)
-        helper = _statement(co, 3, (1 << 12) + 500 + i, seed=4505 + 10 * i)
-        wants.append([co.groth16_prove(k, r, rs[0], rs[1], nthreads=THREADS)[0] for r, k, rs in (main, helper)])
+    (branches, merge), want_fn = _arity8_case(co)
+    flat = expect("arity8_branches_and_merge_2p17", want_fn)
+    jobs, wants = [], [flat[2 * i:2 * i + 2] for i in range(8)]
+    for main, helper in branches:
 
         def branch(ctx, main=main, helper=helper):
             out = []
@@ -80,8 +108,8 @@ def test_config4_arity8_branches_then_sharded_merge(co, gpu_ctx):
     for got, want in zip(results, wants):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     # the merge node: one MNT4-753 proof whose five MSMs run on all eight (logical) devices
-    r, keys, rs = _statement(co, 2, (1 << 17) - 8, seed=4600, mt=True)
-    want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)
+    r, keys, rs = merge
+    want, winf = flat[16], flat[17]
     mctx = capi.Context(devices=_devices(8))
     try:
         mpk = mctx.g16_pk_upload(keys.host_struct(), 2)
@@ -93,20 +121,19 @@ def test_config4_arity8_branches_then_sharded_merge(co, gpu_ctx):
     assert np.array_equal(got, want) and np.array_equal(inf, winf)
 
 
-def test_config4_merge_proof_2p22_sharded_equals_single_device(co, gpu_ctx):
+def test_config4_merge_proof_2p22_sharded_equals_single_device(co, gpu_ctx, expect):
     """configs[4] AT ITS STATED SIZE in the driver-run suite (VERDICT r04 missing #6): one MNT4-753 Groth16 proof over 2^22 constraints through a
     context of eight shards -- every query cut into eight point ranges, five MSMs per shard with the assembly products folded in, the witness
     map's chains on three of them, partial sums on device 0 -- must be byte-identical to the same proof through an ordinary single-device
-    context.  The 230 s of the CPU oracle at this size stay out of the suite (tools/config4_full.py, profiles/r04_config4_full.log: equal);
-    what anchors the single-device path to the oracle here is the 2^22-pair MSM above and the proofs at 2^20 in test_gpu_at_size.py.
+    context -- AND (round 6) to the CPU oracle's proof of the same statement: its 230 s at this size (on 64 threads) are spent once, in the build
+    container (tests/golden/gen_at_size.py -> at_size.npz["merge_proof_c2_2p22"]); PCD_RECOMPUTE=1 spends them here.
     With fewer than eight GPUs the shards share devices, so the window-shifted copies are capped per vector (on an 8-GPU node every
     device holds its share of the key with all copies)."""
     from pcd_amd import capi
-    curve, fr = 2, co.CURVE_FR[2]
-    r = co.synthetic_r1cs(fr, (1 << 22) - 8, 2, seed=2200)
-    keys = co.synthetic_keys(curve, r, seed=2201, mt=True)
+    curve = 2
+    (r, keys, rs), want_fn = _merge_2p22_case(co)
     assert keys.domain_size == 1 << 22
-    rs = co.gen_field(fr, 2, seed=2202)
+    oracle_proof, oracle_inf = expect("merge_proof_c2_2p22", want_fn)
     one = capi.Context(0)
     try:
         one.set_precompute_budget(24 << 30)        # (all 45 copies of one 2^22-point MNT4-753 query would be ~40 GB; five queries)
@@ -116,6 +143,7 @@ def test_config4_merge_proof_2p22_sharded_equals_single_device(co, gpu_ctx):
         pk.free()
     finally:
         one.close()
+    assert np.array_equal(want, oracle_proof) and np.array_equal(winf, oracle_inf), "single-device 2^22 proof differs from the CPU oracle's"
     ndev = capi.lib().pcdhip_device_count()
     mctx = capi.Context(devices=_devices(8))
     try:
@@ -148,6 +176,7 @@ def test_precompute_fallback_forced(co, gpu_ctx, cid, log_n, budget_mb, expect):
     ctx = gpu_ctx
     try:
         ctx.set_precompute_budget(budget_mb << 20)
+        assert ctx.get_precompute_budget() == budget_mb << 20
         b = ctx.bases_upload(cid, 1, pts)
         c_bits, W, copies = ctx.bases_info(b)
         assert copies == expect and copies < W, (c_bits, W, copies)

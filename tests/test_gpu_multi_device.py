@@ -3,10 +3,14 @@ two logical shards on one device run exactly the code a two-GPU context runs (pe
 
   * sharded MSM and sharded Groth16 prove through a multi-device context == the single-device result == the oracle, bit for bit
   * DAG branches: N host threads x N contexts proving different statements concurrently (pcd_amd/dag.py), each == the oracle"""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+THREADS = min(os.cpu_count() or 1, 64)
 
 
 def _devices(k):
@@ -23,7 +27,7 @@ def test_sharded_msm(co, gpu_ctx, cid, grp, n, parts):
     sc = co.gen_scalars(fr, n, seed=701 + n, dist=1)
     inf = np.zeros(n, dtype=np.uint8)
     inf[n // 2] = 1
-    want = co.to_affine(cid, grp, co.msm(cid, grp, pts, sc, inf=inf, nthreads=8))
+    want = co.to_affine(cid, grp, co.msm(cid, grp, pts, sc, inf=inf, nthreads=THREADS))
     mctx = capi.Context(devices=_devices(parts))
     try:
         assert capi.lib().pcdhip_ctx_devices(mctx._ctx) == parts
@@ -33,7 +37,7 @@ def test_sharded_msm(co, gpu_ctx, cid, grp, n, parts):
         # a sub-range that starts inside one shard and ends inside another, and one that misses a shard entirely
         for off, cnt in ((n // 3, n // 2), (0, max(1, n // (2 * parts)))):
             got = co.to_affine(cid, grp, mctx.msm(b, sc[:cnt], offset=off, n=cnt))
-            w = co.to_affine(cid, grp, co.msm(cid, grp, pts[off:off + cnt], sc[:cnt], inf=inf[off:off + cnt], nthreads=8))
+            w = co.to_affine(cid, grp, co.msm(cid, grp, pts[off:off + cnt], sc[:cnt], inf=inf[off:off + cnt], nthreads=THREADS))
             assert np.array_equal(got[0], w[0]) and np.array_equal(got[1], w[1]), (off, cnt)
         b.free()
     finally:
@@ -48,7 +52,7 @@ def test_sharded_groth16_prove(co, gpu_ctx, curve, nc, parts):
     r = co.synthetic_r1cs(fr, nc, 2, seed=800 + nc)
     keys = co.synthetic_keys(curve, r, seed=801 + nc)
     rs = co.gen_field(fr, 2, seed=802)
-    want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=8)
+    want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)
     pk = gpu_ctx.g16_pk_upload(keys.host_struct(), curve)
     single, _ = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1])
     gpu_ctx.groth16_set_schedule(1)               # the witness map first, then all five MSMs: same proof
@@ -78,7 +82,7 @@ def test_dag_branches_threads_x_contexts(co, gpu_ctx):
         r = co.synthetic_r1cs(fr, nc, 2, seed=900 + i)
         keys = co.synthetic_keys(curve, r, seed=910 + i)
         rs = co.gen_field(fr, 2, seed=920 + i)
-        wants.append(co.groth16_prove(keys, r, rs[0], rs[1], nthreads=4)[0])
+        wants.append(co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)[0])
 
         def branch(ctx, curve=curve, r=r, keys=keys, rs=rs):
             pk = ctx.g16_pk_upload(keys.host_struct(), curve)
@@ -102,7 +106,7 @@ def test_witness_map_chains_on_three_devices(co, gpu_ctx, curve, nc, parts):
     r = co.skewed_r1cs(fr, nc, 2, seed=850 + nc)
     keys = co.synthetic_keys(curve, r, seed=851 + nc)
     rs = co.gen_field(fr, 2, seed=852)
-    want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=8)
+    want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)
     mctx = capi.Context(devices=_devices(parts))
     try:
         mpk = mctx.g16_pk_upload(keys.host_struct(), curve)
@@ -114,7 +118,7 @@ def test_witness_map_chains_on_three_devices(co, gpu_ctx, curve, nc, parts):
             assert np.array_equal(got, want) and np.array_equal(inf, winf), (on, sched)
         # another statement under the same key and matrices: scale the witness-independent part by proving with other blinding factors
         rs2 = co.gen_field(fr, 2, seed=853)
-        want2, _ = co.groth16_prove(keys, r, rs2[0], rs2[1], nthreads=8)
+        want2, _ = co.groth16_prove(keys, r, rs2[0], rs2[1], nthreads=THREADS)
         got2, _ = mctx.groth16_prove(mpk, r, rs2[0], rs2[1], resident_r1cs=True)
         assert np.array_equal(got2, want2)
         mpk.free()
@@ -133,11 +137,11 @@ def test_bit_identity_at_1_2_4_8_shards(co, gpu_ctx):
     n = 70000
     pts = co.gen_points(cid, 1, n, seed=990)
     sc = co.gen_scalars(fr, n, seed=991, dist=1)
-    want_msm = co.to_affine(cid, 1, co.msm(cid, 1, pts, sc, nthreads=8))
+    want_msm = co.to_affine(cid, 1, co.msm(cid, 1, pts, sc, nthreads=THREADS))
     r = co.witness_r1cs(fr, 20000, 2, seed=992)
     keys = co.synthetic_keys(cid, r, seed=993)
     rs = co.gen_field(fr, 2, seed=994)
-    want_proof, want_inf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=8)
+    want_proof, want_inf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)
     for parts in (1, 2, 4, 8):
         devs = _devices(parts)
         mctx = capi.Context(devices=devs) if parts > 1 else capi.Context(devs[0])

@@ -77,23 +77,35 @@ def test_prove_witness_like_sharded(co, gpu_ctx, cid, nc, parts):
         mctx.close()
 
 
-def test_main_proof_mnt4_298_2p20_witness_like(co, gpu_ctx):
-    """BASELINE configs[1]/[2]'s main proof shape at 2^20 rows with the witness-like assignment, consistent key, resident matrices,
-    chained and folded assembly"""
+def _main_2p20_case(co):
     cid, fr = 0, co.CURVE_FR[0]
     r = co.witness_r1cs(fr, (1 << 20) - 8, 2, seed=4600)
-    fz, fo = _assignment_shape(co, r)
-    assert fz + fo >= 0.70
     keys = co.synthetic_keys(cid, r, seed=4601, mt=True)
     rs = co.gen_field(fr, 2, seed=4602)
-    want, winf = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS)
+    return (r, keys, rs), lambda: tuple(co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS))
+
+
+AT_SIZE = {"prove_c0_2p20_witness_like": _main_2p20_case}   # (tests/golden/gen_at_size.py; conftest.Expect)
+
+
+def test_main_proof_mnt4_298_2p20_witness_like(co, gpu_ctx, expect):
+    """BASELINE configs[1]/[2]'s main proof shape at 2^20 rows with the witness-like assignment, consistent key, resident matrices,
+    chained and folded assembly"""
+    cid = 0
+    (r, keys, rs), want_fn = _main_2p20_case(co)
+    fz, fo = _assignment_shape(co, r)
+    assert fz + fo >= 0.70
+    want, winf = expect("prove_c0_2p20_witness_like", want_fn)
+    gpu_ctx.groth16_set_sparse_window(-1)   # opt in to the key's second layout under the automatic rule (9.2 GB more at this size: fits)
     pk = gpu_ctx.g16_pk_upload(keys.host_struct(), cid)
+    gpu_ctx.groth16_set_sparse_window(0)
     gpu_ctx.g16_pk_set_r1cs(pk, r)
     try:
         for mode in (2, 1):
             gpu_ctx.groth16_set_assembly(mode)
             got, inf = gpu_ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
             assert np.array_equal(got, want) and np.array_equal(inf, winf), mode
+            assert gpu_ctx.groth16_last_plan()[0] == (mode == 2), mode   # the chained form takes the shorter-window copies, the folded one never
     finally:
         gpu_ctx.groth16_set_assembly(0)
         pk.free()
@@ -170,5 +182,5 @@ def test_sparse_window_plan(co, gpu_ctx, cid, nc, bits):
         finally:
             pk.free()
     finally:
-        gpu_ctx.groth16_set_sparse_window(-1)
+        gpu_ctx.groth16_set_sparse_window(0)   # (the library's default: the second layout is opt-in)
         gpu_ctx.groth16_set_assembly(0)

@@ -29,7 +29,7 @@ while time.time() - t0 < budget:
     spw = rnd.choice((-1, 0, 7, 9, 11, 13))   # (round 5) the key's second layout for a shorter window, taken by proofs over sparse assignments
     ctx.groth16_set_sparse_window(spw)
     pk = ctx.g16_pk_upload(keys.host_struct(), cid)
-    ctx.groth16_set_sparse_window(-1)
+    ctx.groth16_set_sparse_window(0)
     resident = rnd.random() < 0.5
     if resident: ctx.g16_pk_set_r1cs(pk, r)
     asm = rnd.randrange(3)
