@@ -333,7 +333,7 @@ def run(args, stdout_fd):
             ts = []
             for _ in range(7):
                 t0 = time.perf_counter(); r_host = ctx.msm(bases, arr); ts.append((time.perf_counter() - t0) * 1e3)
-            if not np.array_equal(r_host, res):
+            if not np.array_equal(co.to_affine(CURVE, GROUP, r_host)[0], co.to_affine(CURVE, GROUP, res)[0]):   # (same point; the Jacobian representative may differ)
                 raise SystemExit("pcdhip_msm (host scalars) and pcdhip_msm_dev (resident scalars) disagree")
             host_scalars[kind] = float(np.median(ts))
     mad_peak_live = ctx.mad_rate()   # the v_mad_u64_u32 issue rate of THIS box, right behind the kernels it prices (boxes differ by ~10 % in sustained clock)
@@ -509,6 +509,44 @@ def traffic_from_profile():
     return t.get("hbm_bytes_per_launch"), "profiles/traffic_msm_accumulate.json (PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; same kernel sources)"
 
 
+def fft_source_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("fft.hip.h", "fp.hip.h", "inst_field.hip"):
+        h.update(open(os.path.join(ROOT, "pcd_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def fft_roofline(fid, n, eb, N, passes, prods):
+    """[{pass, bound, hbm: {achieved GB/s, frac}, mad: {frac}, traffic ...}] -- the binding roof of a transform pass is the integer multiply-add
+    issue rate (its butterflies), the HBM figure is what north_star asks rocprof to show: algorithmic bytes 2 n s per pass over the LIVE pass
+    time; `traffic` (FETCH x 2 + WRITE, separate --pmc runs) and the profiler's own duration come from profiles/traffic_fft_pass.json,
+    reported only while its source hash matches the kernels that ran (tools/profile_fft.sh re-measures)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_fft_pass.json")
+    prof, note = None, "profiles/traffic_fft_pass.json is missing"
+    if os.path.exists(tpath):
+        t = json.load(open(tpath))
+        if t.get("source_sha16") == fft_source_sha16() and t.get("n") == n:
+            key = [k for k in t["kernels"] if ("F298B" if fid == 1 else "F753B") in k]
+            prof = t["kernels"][key[0]] if key else None
+            note = "profiles/traffic_fft_pass.json (rocprofv3, separate --pmc runs: FETCH_SIZE x 2 + WRITE_SIZE; same kernel sources)"
+        else:
+            note = f"profiles/traffic_fft_pass.json was measured on sources {t.get('source_sha16')}, this build is {fft_source_sha16()}: stale, not reported"
+    out = []
+    for i, (p, k) in enumerate(zip(passes, prods)):
+        alg = 2 * n * eb
+        e = {"pass": i, "bound": "valu_int32_mad", "frac": round(n * k * 2 * N * N / (p * 1e-3) / MAD_PEAK, 3), "kernel_ms": round(p, 4),
+             "hbm": {"achieved": round(alg / (p * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "algorithmic_bytes": alg},
+             "traffic": None, "traffic_source": note}
+        if prof and i < len(prof):
+            e["traffic"] = prof[i].get("hbm_bytes")
+            e["traffic_over_algorithmic_bytes"] = prof[i].get("traffic_over_algorithmic")
+            e["profiler_kernel_us"] = prof[i].get("mean_us")
+        out.append(e)
+    return out
+
+
 def fft_section(ctx, co, log_n=20):
     """Radix-2 transform passes at n = 2^20 over the two main scalar fields, resident vector, per pass: device ms (HIP events around
     each pass), achieved HBM GB/s = 2 n s / t (one read and one write of the vector; s = 44 / 108 B device image) and the fraction
@@ -549,6 +587,8 @@ def fft_section(ctx, co, log_n=20):
                      "pass_GBs": [round(2 * n * eb / (p * 1e-3) / 1e9, 1) for p in passes],
                      "pass_hbm_frac": [round(2 * n * eb / (p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for p in passes],
                      "pass_mad_frac": [round(n * k * 2 * N * N / (p * 1e-3) / MAD_PEAK, 3) for p, k in zip(passes, prods)],
+                     # per pass, both roofs of the LIVE durations above; `traffic` = counter bytes of the same pass from the committed rocprofv3 runs
+                     "roofline": fft_roofline(fid, n, eb, N, passes, prods),
                      "call_wall_ms": {"resident_vector (pcdhip_fft_dev)": round(t_dev, 3), "host_vector_pinned (pcdhip_fft)": round(t_pin, 3),
                                       "host_vector_pageable (pcdhip_fft)": round(t_page, 3), "host_bytes_each_way": n * (40 if N == 11 else 96),
                                       "note": "the S2 hook moves the vector over PCIe both ways per transform; a host that chains transforms "
@@ -820,6 +860,7 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None, variants=True):
         r.z = capi.pinned_like(r.z)
         ctx.groth16_prove(vpk, r, rs[0], rs[1], resident_r1cs=True)
         wall, proof, tm, walls = median_prove(ctx, vpk, r, rs)
+        vmem = ctx.g16_pk_memory(vpk)
         sparse_used, general = ctx.groth16_last_plan()   # (pcdhip_groth16_set_sparse_window: the copies for a shorter window, taken when <= 1/8 of z is general)
         ctx.groth16_set_assembly(2)
         p_chained = ctx.groth16_prove(vpk, r, rs[0], rs[1], resident_r1cs=True)[0]
@@ -832,8 +873,9 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None, variants=True):
         res = {"gpu_wall_ms": round(wall, 2), "gpu_wall_ms_min_max": [round(min(walls), 2), round(max(walls), 2)],
                "gpu_device_ms": {k: round(float(v), 3) for k, v in tm.items()},
                "query_infinity_frac": {"a": round(float(np.mean(keys.a_inf)), 4), "b": round(float(np.mean(keys.b_g2_inf)), 4)},
+               "key_bytes": vmem,
                "sparse_window_plan": {"used": bool(sparse_used), "general_scalars": int(general),
-                                      "window": "forced %d bits" % sparse_bits if sparse_bits is not None else "opt-in, automatic rule (four bits below the key's, when the copies fit a quarter of the free memory)"}}
+                                      "window": "off (library default)" if sparse_bits == 0 else "forced %d bits" % sparse_bits if sparse_bits is not None else "opt-in, automatic rule (four bits below the key's, when the copies fit a quarter of the free memory)"}}
         if cpu:
             t0 = time.perf_counter()
             want, _ = co.groth16_prove(keys, r, rs[0], rs[1], nthreads=threads)
@@ -860,6 +902,7 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None, variants=True):
         pk = ctx.g16_pk_upload(keys.host_struct(), curve)
         ctx.g16_pk_set_r1cs(pk, r)                              # matrices are fixed per circuit: resident like the key
         plan = ctx.g16_pk_info(pk)                              # (window bits, windows) of the key's five queries
+        key_mem = ctx.g16_pk_memory(pk)                         # device bytes of the five queries with their window-shifted copies
         up_s = time.time() - t0
         r.z = capi.pinned_like(r.z)                             # the assignment is handed over in page-locked host memory
         ctx.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)   # warm-up (FFT tables, workspaces)
@@ -886,7 +929,10 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None, variants=True):
                       # fraction of the a / b query entries that are the point at infinity (as a setup over this R1CS makes them)
                       "query_infinity_frac": {"a": round(float(np.mean(keys.a_inf)), 4), "b": round(float(np.mean(keys.b_g2_inf)), 4)},
                       "cpu_port_ms": round(cpu_ms, 1), "cpu_threads": threads, "domain": int(keys.domain_size),
-                      "key_upload_precompute_s": round(up_s, 2), "input_gen_s": round(gen_s, 2)}
+                      "key_upload_precompute_s": round(up_s, 2), "input_gen_s": round(gen_s, 2),
+                      # HBM this proof's key holds (pcdhip_g16_pk_memory): the five queries x their window-shifted copies; `sparse_window` = the second
+                      # layout for a shorter window (opt-in, 0 here: only the witness-like variant below asks for it)
+                      "key_bytes": key_mem}
         if roofline_curve is None:
             # executed multiply-adds of this proof's five accumulations (pairs whose base is the point at infinity are left out of the A / B_1 / B
             # lists when enough of them are: capi.hip launch_assignment) + its 7 transforms (3 passes, ~5 products per element and pass): the
@@ -905,7 +951,7 @@ def pcd_step(ctx, co, proofs, max_threads, roofline_curve=None, variants=True):
             pk.free()
             pk = None
             dense = co.synthetic_keys(curve, r, seed=SEED + 10 + curve, consistent=False, mt=curve >= 2)
-            info[name]["dense_keys"] = variant(curve, r, dense, rs, cpu=False)
+            info[name]["dense_keys"] = variant(curve, r, dense, rs, cpu=False, sparse_bits=0)
             total_dense += info[name]["dense_keys"]["gpu_wall_ms"]
             del dense
             # (c) the assignment a verifier circuit really produces (coracle.witness_r1cs: runs of bits with booleanity rows, packed words, a few

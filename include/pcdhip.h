@@ -245,6 +245,10 @@ void pcdhip_g16_pk_free(pcdhip_ctx* ctx, pcdhip_g16_pk* pk);
 /* The MSM plan of a resident key's queries, in the order a, b_g1, b_g2, l, h: window bits and scalar windows (what a bench needs to count
  * the multiply-adds a proof executes; a key's large queries run one bit under the lone MSM's window, pcdhip_g16_pk_upload). */
 int pcdhip_g16_pk_info(const pcdhip_g16_pk* pk, int window_bits[5], int windows[5]);
+/* Device memory of a resident key's base vectors, in bytes: out[0] the five queries with their window-shifted copies (summed over the shards of a
+ * multi-device key), out[1] the second layout for a shorter window (pcdhip_groth16_set_sparse_window; 0 when not built), out[2] / out[3] the
+ * copies per point of the a query in the two layouts.  What a host that keeps several keys resident budgets with (T1). */
+int pcdhip_g16_pk_memory(const pcdhip_g16_pk* pk, uint64_t out[4]);
 /* Keep the circuit's constraint matrices (`ConstraintMatrices` from `cs.to_matrices()`, fixed per circuit like
  * the key) resident on the device; pcdhip_groth16_prove then accepts A = B = C = NULL and only the assignment
  * z crosses PCIe per proof. */

@@ -56,7 +56,7 @@ EXPORTS = [
     "pcdhip_bases_upload", "pcdhip_bases_free", "pcdhip_msm", "pcdhip_msm_dev", "pcdhip_msm_config", "pcdhip_msm_submit", "pcdhip_msm_collect", "pcdhip_msm_submit_partial", "pcdhip_msm_ticket_wait", "pcdhip_msm_ticket_status", "pcdhip_bases_info", "pcdhip_stream_wait",
     "pcdhip_set_precompute", "pcdhip_set_precompute_budget", "pcdhip_get_precompute_budget", "pcdhip_msm_set_sort", "pcdhip_msm_set_accumulate", "pcdhip_msm_profile", "pcdhip_msm_last_timings", "pcdhip_msm_last_plan", "pcdhip_mad_rate", "pcdhip_points_sum", "pcdhip_msm_dev_partial", "pcdhip_points_sum_dev", "pcdhip_to_affine",
     "pcdhip_fft", "pcdhip_fft_dev", "pcdhip_fft_general", "pcdhip_fft_seq", "pcdhip_domain_size", "pcdhip_fft_last_timings", "pcdhip_groth16_witness_map",
-    "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_g16_pk_info", "pcdhip_g16_witness_map_resident", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_groth16_set_sparse_window", "pcdhip_groth16_last_plan", "pcdhip_groth16_set_witness_split", "pcdhip_groth16_set_schedule", "pcdhip_set_lane_reserve", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
+    "pcdhip_g16_pk_upload", "pcdhip_g16_pk_free", "pcdhip_g16_pk_set_r1cs", "pcdhip_g16_pk_info", "pcdhip_g16_pk_memory", "pcdhip_g16_witness_map_resident", "pcdhip_groth16_prove", "pcdhip_groth16_last_timings", "pcdhip_groth16_set_assembly", "pcdhip_groth16_set_sparse_window", "pcdhip_groth16_last_plan", "pcdhip_groth16_set_witness_split", "pcdhip_groth16_set_schedule", "pcdhip_set_lane_reserve", "pcdhip_fixed_base_mul", "pcdhip_groth16_setup",
     "pcdhip_serialized_size", "pcdhip_serialize_points", "pcdhip_deserialize_points", "pcdhip_deserialize_points_unchecked", "pcdhip_proof_serialized_size", "pcdhip_proof_serialize",
     "pcdhip_proof_deserialize", "pcdhip_vk_serialized_size", "pcdhip_vk_serialize", "pcdhip_vk_deserialize",
     "pcdhip_process_vk", "pcdhip_pvk_free", "pcdhip_groth16_verify_prepared", "pcdhip_groth16_verify_batch_rlc",
@@ -371,8 +371,14 @@ class Context:
         self._check(lib().pcdhip_g16_pk_info(pk._h, c, w))
         return {k: (int(c[i]), int(w[i])) for i, k in enumerate(("a", "b_g1", "b_g2", "l", "h"))}
 
+    def g16_pk_memory(self, pk):
+        """device bytes of a resident key's base vectors: {"ordinary", "sparse_window", "copies", "sparse_copies"}"""
+        out = (C.c_uint64 * 4)()
+        self._check(lib().pcdhip_g16_pk_memory(pk._h, out))
+        return {"ordinary": int(out[0]), "sparse_window": int(out[1]), "copies": int(out[2]), "sparse_copies": int(out[3])}
+
     def groth16_set_sparse_window(self, bits):
-        """-1 automatic, 0 off, 6..22 forced window bits of the sparse-assignment copies (takes effect at the next key upload)"""
+        """0 off (default), -1 automatic, 6..22 forced window bits of the sparse-assignment copies (takes effect at the next key upload)"""
         self._check(lib().pcdhip_groth16_set_sparse_window(self._ctx, int(bits)))
 
     def groth16_last_plan(self):

@@ -288,6 +288,7 @@ void pcdhip_destroy(pcdhip_ctx* ctx) {
   for (auto& kv : ctx->fft_tables) {
     (void)hipFree(kv.second.tw_fwd); (void)hipFree(kv.second.tw_inv);
     (void)hipFree(kv.second.coset); (void)hipFree(kv.second.coset_inv_scaled);
+    (void)hipFree(kv.second.tw0_fwd); (void)hipFree(kv.second.tw0_inv);
   }
   if (ctx->xstream_ev) (void)hipEventDestroy(ctx->xstream_ev);
   if (ctx->wm_ev) (void)hipEventDestroy(ctx->wm_ev);
@@ -503,6 +504,26 @@ int pcdhip_g16_pk_info(const pcdhip_g16_pk* pk, int window_bits[5], int windows[
     int rc = q[i] ? pcdhip_bases_info(q[i], 0, &window_bits[i], &windows[i], &copies) : PCDHIP_E_ARG;
     if (rc) return rc;
   }
+  return PCDHIP_OK;
+}
+// bytes of device memory a key's base vectors hold: out[0] the five queries with their window-shifted copies (every shard of a multi-device
+// key), out[1] the second layout of the assignment queries for a shorter window (0 when not built), out[2] / out[3] the copies per point of the
+// a query in the two layouts (device 0's shard)
+int pcdhip_g16_pk_memory(const pcdhip_g16_pk* pk, uint64_t out[4]) {
+  if (!pk || !out) return PCDHIP_E_ARG;
+  out[0] = out[1] = out[2] = out[3] = 0;
+  auto bytes = [](const pcdhip_bases* b) -> uint64_t {
+    if (!b || !b->dptr) return 0;
+    return (uint64_t)std::max<size_t>(b->n, 1) * group_entry(b->curve_id, b->group_id).base_stride_words * 4 * (uint64_t)b->groups + (b->inf_bits ? (b->n + 7) / 8 : 0);
+  };
+  std::vector<const pcdhip_g16_pk*> parts;
+  if (pk->shards.empty()) parts.push_back(pk); else for (const pcdhip_g16_pk* s : pk->shards) parts.push_back(s);
+  for (const pcdhip_g16_pk* s : parts) {
+    out[0] += bytes(s->a_query) + bytes(s->b_g1_query) + bytes(s->b_g2_query) + bytes(s->l_query) + bytes(s->h_query);
+    out[1] += bytes(s->a_sparse) + bytes(s->b_g1_sparse) + bytes(s->b_g2_sparse) + bytes(s->l_sparse);
+  }
+  out[2] = parts[0]->a_query ? (uint64_t)parts[0]->a_query->groups : 0;
+  out[3] = parts[0]->a_sparse ? (uint64_t)parts[0]->a_sparse->groups : 0;
   return PCDHIP_OK;
 }
 int pcdhip_stream_wait(pcdhip_ctx* ctx, void* other_stream, int direction) {
@@ -1453,17 +1474,56 @@ int pcdhip_g16_pk_upload(pcdhip_ctx* ctx, const pcdhip_g16_pk_host* h, pcdhip_g1
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
       if (cs != pk->a_query->c && (ctx->g16_sparse_window > 0 || extra <= free_b / 4)) {
         const int saved_c = C->msm_c, saved_pre = C->precompute;
-        C->msm_c = cs; C->msm_c_bias = 0; C->precompute = -1;
-        int rs = up(qa, &pk->a_sparse);
-        rs = rs ? rs : up(qb1, &pk->b_g1_sparse);
-        rs = rs ? rs : up(qb2, &pk->b_g2_sparse);
-        rs = rs ? rs : up(ql, &pk->l_sparse);
-        C->msm_c = saved_c; C->precompute = saved_pre;
-        const bool whole = !rs && pk->a_sparse->c == cs && pk->b_g1_sparse->c == cs && pk->b_g2_sparse->c == cs && pk->l_sparse->c == cs &&
-                           pk->a_sparse->groups == pk->b_g1_sparse->groups && pk->a_sparse->groups == pk->b_g2_sparse->groups && pk->a_sparse->groups == pk->l_sparse->groups;
-        if (!whole) {  // (not enough memory for all four, or fewer groups than windows somewhere: the key works without them)
+        auto drop_sparse = [&]() {
           pcdhip_bases_free(C, pk->a_sparse); pcdhip_bases_free(C, pk->b_g1_sparse); pcdhip_bases_free(C, pk->b_g2_sparse); pcdhip_bases_free(C, pk->l_sparse);
           pk->a_sparse = pk->b_g1_sparse = pk->b_g2_sparse = pk->l_sparse = nullptr;
+        };
+        // The four layouts must agree in window AND in the number of copies (they share one sorted entry list: MsmSharedSort), while memory (the
+        // device's, or pcdhip_set_precompute_budget's bound per vector) grants the wide G2 vector fewer copies than the G1 ones: upload with all
+        // copies, then bring everyone down to the smallest count granted (`precompute` = k copies).
+        auto up_sparse = [&](int copies) -> int {
+          C->msm_c = cs; C->msm_c_bias = 0; C->precompute = copies;
+          // (the G2 vector first: it is the widest, so the count it is granted is the one the G1 vectors are then asked for)
+          int rs = up(qb2, &pk->b_g2_sparse);
+          if (!rs && pk->b_g2_sparse->groups >= 2 && pk->b_g2_sparse->groups < Ws) C->precompute = pk->b_g2_sparse->groups;
+          rs = rs ? rs : up(qa, &pk->a_sparse);
+          rs = rs ? rs : up(qb1, &pk->b_g1_sparse);
+          rs = rs ? rs : up(ql, &pk->l_sparse);
+          C->msm_c = saved_c; C->precompute = saved_pre;
+          return rs;
+        };
+        auto sparse_whole = [&]() {
+          return pk->a_sparse && pk->b_g1_sparse && pk->b_g2_sparse && pk->l_sparse && pk->a_sparse->groups >= 2 &&
+                 pk->a_sparse->c == cs && pk->b_g1_sparse->c == cs && pk->b_g2_sparse->c == cs && pk->l_sparse->c == cs &&
+                 pk->a_sparse->groups == pk->b_g1_sparse->groups && pk->a_sparse->groups == pk->b_g2_sparse->groups && pk->a_sparse->groups == pk->l_sparse->groups;
+        };
+        auto try_sparse = [&]() -> bool {
+          int rs = up_sparse(-1);
+          if (!rs && !sparse_whole() && pk->a_sparse && pk->b_g1_sparse && pk->b_g2_sparse && pk->l_sparse) {
+            const int k = std::min(std::min(pk->a_sparse->groups, pk->b_g1_sparse->groups), std::min(pk->b_g2_sparse->groups, pk->l_sparse->groups));
+            drop_sparse();
+            if (k >= 2) rs = up_sparse(k);
+          }
+          if (rs || !sparse_whole()) { drop_sparse(); (void)hipGetLastError(); return false; }   // (the key works without them)
+          return true;
+        };
+        bool have = try_sparse();
+        // A window asked for OUTRIGHT (bits > 0) when the ordinary copies have already taken the memory: fewer ordinary copies + the second layout
+        // instead of all ordinary copies and none -- the ordinary queries are uploaded again with half the copies (a Horner combine over the
+        // windows that share a copy comes back for dense assignments) until the second layout fits beside them.
+        for (int round = 0; !have && ctx->g16_sparse_window > 0 && round < 4; round++) {
+          const int k = std::min(std::min(pk->a_query->groups, pk->b_g1_query->groups), std::min(pk->b_g2_query->groups, pk->l_query->groups)) / 2;
+          if (k < 2) break;
+          pcdhip_bases_free(C, pk->a_query); pcdhip_bases_free(C, pk->b_g1_query); pcdhip_bases_free(C, pk->b_g2_query); pcdhip_bases_free(C, pk->l_query);
+          pk->a_query = pk->b_g1_query = pk->b_g2_query = pk->l_query = nullptr;
+          C->precompute = k; C->msm_c_bias = (hi - lo >= ((size_t)1 << 18)) ? -1 : 0;
+          int ro = up(qa, &pk->a_query);
+          ro = ro ? ro : up(qb1, &pk->b_g1_query);
+          ro = ro ? ro : up(qb2, &pk->b_g2_query);
+          ro = ro ? ro : up(ql, &pk->l_query);
+          C->precompute = saved_pre;
+          if (ro) { pcdhip_g16_pk_free(C, pk); return ro; }
+          have = try_sparse();
         }
       }
     }
@@ -1790,6 +1850,7 @@ int prove_sharded_impl(pcdhip_ctx* ctx, const pcdhip_g16_pk* pk, const pcdhip_cs
                        const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out, uint8_t* inf_out) {
   const size_t G = pk->shards.size();
   if (ctx->peers.size() != G) return PCDHIP_E_ARG;
+  ctx->g16_last_sparse = 0; ctx->g16_last_general = 0;   // (a sharded proof folds the assembly products in: it never counts, never takes a second layout)
   const int cid = pk->curve_id, fr = kCurveFr[cid];
   const FieldEntry& fe = field_entry(fr);
   const size_t m = pk->num_vars, ni = pk->num_inputs;

@@ -19,6 +19,9 @@ namespace pcd {
 
 struct FftTables {  // per (field, log_n): powers of w, w^-1, g, g^-1 (*1/n folded in), resident for reuse
   uint32_t *tw_fwd = nullptr, *tw_inv = nullptr, *coset = nullptr, *coset_inv_scaled = nullptr;
+  // the inter-pass twiddles of the FIRST pass of a multi-pass transform, laid out in the order that pass stores (fft.hip.h "first-pass twiddles"):
+  // tw0[o] = w^((o >> d0) (o mod 2^d0)); null for single-pass sizes
+  uint32_t *tw0_fwd = nullptr, *tw0_inv = nullptr;
   uint32_t consts[6 * 32] = {0};  // host copy of w, w^-1, g, g^-1, 1/n, 1/Z(g) (computed once, on the device)
 };
 

@@ -41,6 +41,21 @@ __global__ void fft_fill_powers(uint32_t* __restrict__ tw, uint32_t n, const F b
   for (uint32_t i = lo; i < n && i < lo + 256; i++) { cur.store(tw + (size_t)i * F::WORDS); cur = cur * base; }
 }
 
+// First-pass twiddles (round 6).  The twiddle an output of pass i takes is w^(s p k): in every pass but the first the T columns of a tile share
+// p, so a workgroup reads R entries of the root table; in the FIRST pass (s = 1) the exponent is idx * k mod n -- a different entry for every
+// output, gathered at stride k from the n-entry table: 2^20 gathers of 44 / 108 B that pull whole 128-B lines (rocprofv3, profiles/r06_fft_pass.csv
+// before: FETCH x 2 = 257 MB in the first 298-bit pass at 2^20 against 46 MB of vector -- 3.8 TB/s of HBM traffic in 79 us, the one pass of the
+// transform that HBM bounds).  The same factors laid out once per (field, n, direction) in the order the pass STORES -- tw0[o], o the output
+// index -- are read as one coalesced stream of n elements.
+template <class F>
+__global__ void __launch_bounds__(256) fft_first_pass_twiddles(const uint32_t* __restrict__ tw, uint32_t* __restrict__ tw0, int logn, int d) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << logn;
+  if (o >= n) return;
+  const uint32_t idx = o >> d, k = o & ((1u << d) - 1u);
+  const uint32_t ex = (uint32_t)(((uint64_t)idx * k) & (n - 1));
+  F::load(tw + (size_t)ex * F::WORDS).store(tw0 + (size_t)o * F::WORDS);
+}
+
 // Butterfly arithmetic of a pass.  Plain: every addition / subtraction reduces (753-bit fields: R'/p ~ 8 leaves no room).
 // Lazy (298-bit fields, R'/p > 2^10): elements travel through the layers of a pass as UNREDUCED signed 28-bit-radix limbs
 // (Fp::Lz); a butterfly's sum and difference are limb-wise with no carry chain and no reduction (the difference adds a multiple of
@@ -110,7 +125,8 @@ template <class F>
 __global__ void __launch_bounds__(256) fft_pass_kernel(const uint32_t* __restrict__ x, uint32_t* __restrict__ y,
                                                        const uint32_t* __restrict__ tw, int logn, int d, int logT, int logs,
                                                        const uint32_t* __restrict__ pre, const uint32_t* __restrict__ post,
-                                                       int use_scale, const F scale_c, size_t batch_stride) {
+                                                       int use_scale, const F scale_c, size_t batch_stride,
+                                                       const uint32_t* __restrict__ tw_out = nullptr /* first pass: twiddles in store order */) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   // blockIdx.y: which of several equal transforms laid out `batch_stride` words apart (the rows of a mixed-radix domain go through
   // their radix-2 passes in ONE launch per pass: a 2^14-point row alone is 16 workgroups on a 256-CU chip)
@@ -209,8 +225,8 @@ __global__ void __launch_bounds__(256) fft_pass_kernel(const uint32_t* __restric
     uint32_t idx = i0 + tt;
     uint32_t q = idx & smask, sp = idx - q;  // s * p
     uint32_t ex = (uint32_t)(((uint64_t)sp * k) & (n - 1));
-    F v = A::finish(ve, F::load(tw + (size_t)ex * EW), ex != 0);
     uint32_t o = q + ((sp << d) + (k << logs));
+    F v = A::finish(ve, F::load(tw_out ? tw_out + (size_t)o * EW : tw + (size_t)ex * EW), ex != 0);
     if (post) v = v * F::load(post + (size_t)o * EW);
     if (use_scale) v = v * scale_c;
     v.store(y + (size_t)o * EW);

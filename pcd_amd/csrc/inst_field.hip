@@ -84,6 +84,13 @@ hipError_t make_tables(hipStream_t st, int log_n, FftTables* t) {
   hipLaunchKernelGGL(fft_fill_powers<FT>, gd, bd, 0, st, t->tw_inv, n, c.winv, FT::one());
   hipLaunchKernelGGL(fft_fill_powers<FT>, gd, bd, 0, st, t->coset, n, c.g, FT::one());
   hipLaunchKernelGGL(fft_fill_powers<FT>, gd, bd, 0, st, t->coset_inv_scaled, n, c.ginv, c.ninv);  // g^-j / n
+  const std::vector<FftPass> plan = fft_plan(log_n);
+  if (plan.size() > 1) {  // the first pass' twiddles in the order it stores them (fft.hip.h "first-pass twiddles")
+    PCD_HIP_TRY(hipMalloc(&t->tw0_fwd, bytes));
+    PCD_HIP_TRY(hipMalloc(&t->tw0_inv, bytes));
+    hipLaunchKernelGGL(fft_first_pass_twiddles<FT>, dim3((n + 255) / 256), dim3(256), 0, st, t->tw_fwd, t->tw0_fwd, log_n, plan[0].d);
+    hipLaunchKernelGGL(fft_first_pass_twiddles<FT>, dim3((n + 255) / 256), dim3(256), 0, st, t->tw_inv, t->tw0_inv, log_n, plan[0].d);
+  }
   PCD_HIP_TRY(hipGetLastError());
   return hipStreamSynchronize(st);
 }
@@ -122,7 +129,8 @@ hipError_t run_batched(hipStream_t st, const FftTables& t, uint32_t* x, uint32_t
     FTP scale_p;
     memcpy(&scale_p, &scale, sizeof scale);
     hipLaunchKernelGGL(fft_pass_kernel<FTP>, dim3(blocks, batch), dim3(256), lds, st, src, dst, tw, log_n, d, logT, logs, pre, post,
-                       (last ? use_scale : 0), scale_p, ((size_t)EW) << log_n);
+                       (last ? use_scale : 0), scale_p, ((size_t)EW) << log_n,
+                       (first && P > 1) ? ((inverse || raw) ? t.tw0_inv : t.tw0_fwd) : nullptr);
     if (pass_ms) PCD_HIP_TRY(hipEventRecord(ev[i + 1], st));
     logs += d;
     std::swap(src, dst);

@@ -148,6 +148,15 @@ int main(int argc, char** argv) {
     if (!rc) rc = pcdhip_groth16_last_plan(ctx, plan);
     if (rc) { fprintf(stderr, "prove (sparse-window key): %s (%s)\n", pcdhip_strerror(rc), pcdhip_last_hip_error(ctx)); return 6; }
     bad |= memcmp(proof2, want, pw * 8) != 0 || memcmp(inf2, want_inf, 3) != 0 || plan[0] > 1 || plan[1] > m;
+    {  /* what the two keys hold (pcdhip_g16_pk_memory): the second key carries the second layout, the first does not (opt-in);
+        * and the budget getter hands back what was set (a layer that changes it for one upload restores the host's setting) */
+      uint64_t mem1[4] = {0, 0, 0, 0}, mem2[4] = {0, 0, 0, 0};
+      size_t budget = 1;
+      bad |= pcdhip_g16_pk_memory(pk, mem1) != PCDHIP_OK || pcdhip_g16_pk_memory(pk2, mem2) != PCDHIP_OK || pcdhip_g16_pk_memory(NULL, mem1) != PCDHIP_E_ARG;
+      bad |= mem1[0] == 0 || mem1[1] != 0 || mem1[3] != 0 || mem2[0] == 0 || ((mem2[1] != 0) != (mem2[3] >= 2)) || (plan[0] == 1 && mem2[1] == 0);
+      bad |= pcdhip_set_precompute_budget(ctx, (size_t)3 << 30) != PCDHIP_OK || pcdhip_get_precompute_budget(ctx, &budget) != PCDHIP_OK || budget != (size_t)3 << 30;
+      bad |= pcdhip_set_precompute_budget(ctx, 0) != PCDHIP_OK || pcdhip_get_precompute_budget(ctx, NULL) != PCDHIP_E_ARG;
+    }
     bad |= pcdhip_groth16_set_sparse_window(ctx, 3) != PCDHIP_E_ARG || pcdhip_groth16_last_plan(ctx, NULL) != PCDHIP_E_ARG;
     (void)pcdhip_groth16_set_sparse_window(ctx, 0);
     (void)pcdhip_groth16_set_assembly(ctx, 0);

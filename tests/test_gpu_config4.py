@@ -66,7 +66,37 @@ def _merge_2p22_case(co):
     return (r, keys, rs), lambda: tuple(co.groth16_prove(keys, r, rs[0], rs[1], nthreads=THREADS))
 
 
-AT_SIZE = {"msm_c2g1_2p22": _msm_2p22_case, "arity8_branches_and_merge_2p17": _arity8_case, "merge_proof_c2_2p22": _merge_2p22_case}
+def _witness_like_z(co, fr, m, seed):
+    """an assignment shaped like a verifier circuit's (58 % zeros, 36 % ones, 6 % general field elements; z_0 = 1), Montgomery form.  It does not
+    satisfy the system -- a Groth16 proof is a function of (key, matrices, z) either way, and the oracle computes the same function."""
+    i = np.arange(m, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = (i + np.uint64(seed)) * np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    u = ((x ^ (x >> np.uint64(31))) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    can = co.fp_op(fr, "to_canonical", co.gen_field(fr, m, seed=seed + 1))
+    can[u < 0.94] = 0
+    can[(u >= 0.58) & (u < 0.94), 0] = 1
+    can[0] = 0
+    can[0, 0] = 1
+    return np.ascontiguousarray(co.fp_op(fr, "from_canonical", can))
+
+
+def _merge_2p22_witness_like_case_on(co, r, keys, rs):
+    import copy
+    rw = copy.copy(r)
+    rw.z = _witness_like_z(co, co.CURVE_FR[2], r.z.shape[0], seed=2210)
+    return (rw, keys, rs), lambda: tuple(co.groth16_prove(keys, rw, rs[0], rs[1], nthreads=THREADS))
+
+
+def _merge_2p22_witness_like_case(co):
+    """the same key and matrices, a witness-like assignment (the merge node's real one is bit decompositions: data_structures.rs:269-304)"""
+    return _merge_2p22_witness_like_case_on(co, *_statement(co, 2, (1 << 22) - 8, seed=2200, mt=True))
+
+
+AT_SIZE = {"msm_c2g1_2p22": _msm_2p22_case, "arity8_branches_and_merge_2p17": _arity8_case, "merge_proof_c2_2p22": _merge_2p22_case,
+           "merge_proof_c2_2p22_witness_like": _merge_2p22_witness_like_case}
 
 
 def test_config4_msm_g1_753_2p22_eight_shards(co, gpu_ctx, expect):
@@ -128,18 +158,38 @@ def test_config4_merge_proof_2p22_sharded_equals_single_device(co, gpu_ctx, expe
     context -- AND (round 6) to the CPU oracle's proof of the same statement: its 230 s at this size (on 64 threads) are spent once, in the build
     container (tests/golden/gen_at_size.py -> at_size.npz["merge_proof_c2_2p22"]); PCD_RECOMPUTE=1 spends them here.
     With fewer than eight GPUs the shards share devices, so the window-shifted copies are capped per vector (on an 8-GPU node every
-    device holds its share of the key with all copies)."""
+    device holds its share of the key with all copies).
+
+    Key memory at this size: the single-device key is uploaded under a budget per vector AND with the second layout for a
+    shorter window asked for outright -- fewer ordinary copies + the shorter-window copies brought down to one common count (the G2 vector is
+    granted fewer than the G1 ones) -- and proves a witness-like assignment over the same key and matrices on those copies
+    (pcdhip_groth16_last_plan), byte-equal to the oracle and to the eight shards (which fold the assembly products in and never take them)."""
     from pcd_amd import capi
     curve = 2
     (r, keys, rs), want_fn = _merge_2p22_case(co)
     assert keys.domain_size == 1 << 22
     oracle_proof, oracle_inf = expect("merge_proof_c2_2p22", want_fn)
+    (rw, _, _), want_w_fn = _merge_2p22_witness_like_case_on(co, r, keys, rs)
+    oracle_w, oracle_w_inf = expect("merge_proof_c2_2p22_witness_like", want_w_fn)
     one = capi.Context(0)
     try:
         one.set_precompute_budget(24 << 30)        # (all 45 copies of one 2^22-point MNT4-753 query would be ~40 GB; five queries)
+        one.groth16_set_sparse_window(13)
         pk = one.g16_pk_upload(keys.host_struct(), curve)
+        one.groth16_set_sparse_window(0)
+        mem, plan = one.g16_pk_memory(pk), one.g16_pk_info(pk)
+        print(f"2^22 MNT4-753 key on one device: {mem}, plan {plan}")
+        assert 2 <= mem["copies"] < plan["a"][1] and mem["sparse_copies"] >= 2 and mem["sparse_window"] > 0   # fewer ordinary copies + the second layout
+        assert mem["ordinary"] + mem["sparse_window"] < 200 << 30
         one.g16_pk_set_r1cs(pk, r)
+        one.groth16_set_assembly(2)
         want, winf = one.groth16_prove(pk, r, rs[0], rs[1], resident_r1cs=True)
+        used, counted = one.groth16_last_plan()
+        assert not used and counted * 8 > r.z.shape[0]                   # a dense assignment stays on the ordinary copies
+        got_w, inf_w = one.groth16_prove(pk, rw, rs[0], rs[1], resident_r1cs=True)
+        used, counted = one.groth16_last_plan()
+        assert used and 0 < counted * 8 <= rw.z.shape[0], (used, counted)   # the witness-like one takes the shorter-window copies
+        assert np.array_equal(got_w, oracle_w) and np.array_equal(inf_w, oracle_w_inf), "single-device witness-like 2^22 proof differs from the CPU oracle's"
         pk.free()
     finally:
         one.close()
@@ -155,6 +205,9 @@ def test_config4_merge_proof_2p22_sharded_equals_single_device(co, gpu_ctx, expe
         for _ in range(2):
             got, inf = mctx.groth16_prove(mpk, r, rs[0], rs[1], resident_r1cs=True)
             assert np.array_equal(got, want) and np.array_equal(inf, winf)
+        got, inf = mctx.groth16_prove(mpk, rw, rs[0], rs[1], resident_r1cs=True)
+        assert np.array_equal(got, oracle_w) and np.array_equal(inf, oracle_w_inf)
+        assert mctx.groth16_last_plan() == (False, 0)
         mpk.free()
     finally:
         mctx.close()

@@ -1,6 +1,8 @@
 """CPU: the C++ oracle (oracle/*.hpp, restatement of the upstream ark-ec / ark-poly / ark-groth16
 algorithms) against the committed golden vectors produced by the independent pure-Python big-integer
 oracle (tests/golden/gen_golden.py).  The reference itself holds no vectors for this path."""
+import os
+
 import numpy as np
 import pytest
 
@@ -85,3 +87,39 @@ def test_groth16_setup_prove_verify(co, golden, cid):
 def test_pairing(co, golden, cid):
     g = golden("pairing")
     assert np.array_equal(co.pairing(cid, g[f"c{cid}_p"], g[f"c{cid}_q"]), g[f"c{cid}_gt"])
+
+
+# ---- tests/golden/at_size.npz: the oracle's results for the at-size GPU tests (tests/golden/gen_at_size.py; conftest.Expect) ----
+def _at_size_cases():
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for m in ("test_gpu_at_size", "test_gpu_config4", "test_gpu_witness_like"):
+        out.update(importlib.import_module(m).AT_SIZE)
+    return out
+
+
+def test_at_size_fixture_is_complete():
+    """every at-size case of the GPU suite has its expectation in the committed file, and the file holds nothing else: the GPU run then spends no
+    oracle time on them (PCD_RECOMPUTE=1 brings it back) and cannot silently fall back to recomputing a missing one"""
+    from conftest import Expect
+    e = Expect()
+    cases = _at_size_cases()
+    missing = [k for k in cases if e.stored(k) is None]
+    assert not missing, f"run tests/golden/gen_at_size.py: no expectation for {missing}"
+    stale = {k.split("/")[0] for k in e._npz.files} - set(cases)
+    assert not stale, f"at_size.npz holds keys without a case builder: {stale}"
+
+
+@pytest.mark.parametrize("key", ["prove_c1_2p16", "wm_skewed_2p20_sha256"])
+def test_at_size_fixture_spot_check(co, key):
+    """the cheap entries re-derived here, in the CPU suite: same case builder, the oracle on the spot, equal to the committed value"""
+    from conftest import Expect
+    e = Expect()
+    have = e.stored(key)
+    assert have is not None
+    _, want_fn = _at_size_cases()[key](co)
+    got = want_fn()
+    a, b = (have, got) if isinstance(have, tuple) else ((have,), (got,))
+    assert len(a) == len(b) and all(np.array_equal(x, np.asarray(y)) for x, y in zip(a, b))

@@ -9,7 +9,8 @@ from pcd_amd import capi
 
 ctx = capi.Context(0)
 reps = int(os.environ.get("FFT_REPS", "5"))
-for fid, logn in ((1, 20), (3, 20), (1, 22)):
+cases = [tuple(int(v) for v in c.split(":")) for c in os.environ["FFT_CASES"].split(",")] if os.environ.get("FFT_CASES") else [(1, 20), (3, 20), (1, 22)]
+for fid, logn in cases:
     n = 1 << logn
     x = ctx.buf_upload(fid, co.gen_field(fid, n, seed=1))
     ctx.fft(fid, x)
