@@ -4,7 +4,7 @@
 // take the doubling path of an addition (equal points), the cancellation path (opposite points), an infinity operand, or a branch with
 // a different operation mix than its neighbours.  Both forms must give the same VALUES (representatives in [0, 2p) may differ).
 // Also the round-3 reproducer: one item, three active lanes, both operands finite, result compared AS STORED after canonicalisation on
-// the device (the shape in which ROCm 7.2's MachineCopyPropagation dropped a live copy).
+// the device (the shape in which ROCm 7.2's MachineCopyPropagation dropped a live copy; profiles/DESIGN_history_r01-r05.md section 4).
 // Built by __graft_entry__.build() (hipcc, gfx950) into tests/gpucheck/libgpucheck.so; tests/test_gpu_mailbox.py drives it.
 #include <cstdio>
 #include <vector>

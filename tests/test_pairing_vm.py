@@ -88,7 +88,7 @@ def test_bounds_the_interpreter_relies_on(gen, envs):
 
 
 def test_schedule_depth_and_flat_records(gen, envs):
-    """What the verification's latency rests on: a doubling and an addition step are three product levels
+    """What the verification's latency rests on (profiles/DESIGN_history_r01-r05.md section 5, round 4): a doubling and an addition step are three product levels
     deep -- six steps -- on all four curves, no step holds more than 64 instruction slots, and the flat record list the device walks is the
     script with its programs expanded: same steps in the same order, the bank flip on each program's last step, the table selections and
     the inversion attached to the step they precede."""

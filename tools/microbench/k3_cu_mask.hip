@@ -4,7 +4,7 @@
 //      workgroups are dealt to the XCDs round-robin, so each XCD needs a free CU of its own);
 //  (2) the latency of a chain of 20 dependent one-wave launches on an unmasked high-priority stream while a register-heavy kernel with
 //      long-lived workgroups fills the device from (a) an unmasked stream, (b) a masked stream -- the situation of a bucket-reduction
-//      tail behind another MSM's accumulation waves.
+//      tail behind another MSM's accumulation waves (profiles/DESIGN_history_r01-r05.md section 7).
 // Build: hipcc --offload-arch=gfx950 -O3 k3_cu_mask.hip -o ../../build/k3_cu_mask
 #include <hip/hip_runtime.h>
 #include <stdint.h>
