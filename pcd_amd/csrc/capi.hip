@@ -295,6 +295,8 @@ void pcdhip_destroy(pcdhip_ctx* ctx) {
   for (int c = 0; c < 4; c++) if (ctx->vm_block[c]) (void)hipFree(ctx->vm_block[c]);
   for (int k = 0; k < pcdhip_ctx::PIPE_SLOTS; k++) if (ctx->pipe_done[k]) (void)hipEventDestroy(ctx->pipe_done[k]);
   if (ctx->pipe_host) (void)hipHostFree(ctx->pipe_host);
+  if (ctx->count_host) (void)hipHostFree(ctx->count_host);
+  if (ctx->count_ev) (void)hipEventDestroy(ctx->count_ev);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   (void)hipStreamDestroy(ctx->stream);
@@ -1696,9 +1698,14 @@ struct G16Run {
     hipStream_t st = ctx->stream;
     TRY(hipMemsetAsync(general_dev, 0, 4, st));
     hipLaunchKernelGGL(count_general_kernel, dim3((unsigned)std::min<size_t>((m + 255) / 256, 1024)), dim3(256), 0, st, z_can, (uint32_t)m, (int)sw, general_dev);
-    uint32_t general = 0;
-    TRY(hipMemcpyAsync(&general, general_dev, 4, hipMemcpyDeviceToHost, st));
-    TRY(hipStreamSynchronize(st));
+    // (a page-locked word and an event of its own instead of a pageable copy + a synchronisation of the whole stream -- the host
+    //  waits for exactly the count kernel and its 4-byte copy, whatever else a caller has queued behind them on this stream)
+    if (!ctx->count_host) TRY(hipHostMalloc((void**)&ctx->count_host, 64, hipHostMallocDefault));
+    if (!ctx->count_ev) TRY(hipEventCreateWithFlags(&ctx->count_ev, hipEventDisableTiming));
+    TRY(hipMemcpyAsync(ctx->count_host, general_dev, 4, hipMemcpyDeviceToHost, st));
+    TRY(hipEventRecord(ctx->count_ev, st));
+    TRY(hipEventSynchronize(ctx->count_ev));
+    const uint32_t general = *(volatile uint32_t*)ctx->count_host;
     ctx->g16_last_general = general;
     sparse = (uint64_t)general * 8 <= m;
     ctx->g16_last_sparse = sparse ? 1 : 0;

@@ -121,6 +121,8 @@ struct pcdhip_ctx {
   bool pipe_partial[PIPE_SLOTS] = {};   // the slot's last ticket was released by pcdhip_msm_ticket_wait: its error word is checked at the next submit
   hipEvent_t pipe_done[PIPE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t* pipe_host = nullptr;  // PIPE_SLOTS x PIPE_HOST_WORDS u64
+  uint32_t* count_host = nullptr; // one page-locked word + an event: the count of general scalars of a proof's assignment (G16Run::decide_sparse)
+  hipEvent_t count_ev = nullptr;
   static constexpr size_t PIPE_HOST_WORDS = 256;  // >= one Jacobian point in the C-ABI image (216 u64 for Fq3-753) + the error word
   size_t pipe_out_bytes[PIPE_SLOTS] = {0, 0, 0, 0};
   int pipe_next = 0;

@@ -177,3 +177,18 @@ def test_bench_multi_gpu_failure_still_prints_one_line(tmp_path):
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["metric"] == "msm_mscalar_mul_per_s" and "multi_gpu_error" in out and out["n_gpus_requested"] == 1
+
+
+def test_toolchain_the_copyprop_workaround_was_validated_on():
+    """pcd_amd/csrc/Makefile builds with `-mllvm -disable-copyprop` because ROCm 7.2's MachineCopyPropagation deletes a live copy in one kernel
+    (tests/gpucheck re-runs the reproducer on the GPU).  The flag, and the conclusion that it costs nothing, were validated on
+    HIP 7.2 only: a different toolchain must not pass silently -- re-run tests/test_gpu_mailbox.py and
+    tools/ab_libs.sh with and without the flag on the new toolchain, then update the version here."""
+    import re
+    import subprocess
+    out = subprocess.run(["hipcc", "--version"], capture_output=True, text=True).stdout
+    m = re.search(r"HIP version:\s*(\d+)\.(\d+)", out)
+    assert m, out
+    assert (int(m.group(1)), int(m.group(2))) == (7, 2), f"hipcc is HIP {m.group(1)}.{m.group(2)}: the -disable-copyprop work-around was validated on 7.2 only"
+    mk = open(os.path.join(ROOT, "pcd_amd", "csrc", "Makefile")).read()
+    assert "-mllvm -disable-copyprop" in mk
