@@ -993,6 +993,27 @@ struct Fp3S {
 #pragma unroll
     for (int i = 0; i < F::N; i++) r.v[i] = t ? a.v[i] : b.v[i];
     return r; }
+#if defined(PCD_FP3S_DPP) && PCD_FP3S_DPP
+  // EXPERIMENT (round 6; measured and left off: DESIGN.md section 4): both partners' coefficients by DPP wave shifts instead of
+  // two ds_bpermute round trips -- lane + 1 / + 2 (wave_shl:1 once / twice) for the roles whose partner sits above, lane - 1 / - 2
+  // (wave_shr:1) for those below; 4 DPP moves + 2 selects per limb, no LDS traffic, no waitcnt.  A triple's lanes are active together,
+  // so every shifted value that is USED comes from an active lane of the same triple.
+  PCD_DEV static void partners(const F& a, F& an, F& an2) {
+    const unsigned k = role();
+#pragma unroll
+    for (int i = 0; i < F::N; i++) {
+      const int v = (int)a.v[i];
+      const int s1 = __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);    // wave_shl:1 -- from lane + 1
+      const int s2 = __builtin_amdgcn_update_dpp(0, s1, 0x130, 0xf, 0xf, false);   //              from lane + 2
+      const int r1 = __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);    // wave_shr:1 -- from lane - 1
+      const int r2 = __builtin_amdgcn_update_dpp(0, r1, 0x138, 0xf, 0xf, false);   //              from lane - 2
+      an.v[i] = (uint32_t)(k == 2 ? r2 : s1);
+      an2.v[i] = (uint32_t)(k == 0 ? s2 : r1);
+    }
+  }
+#else
+  PCD_DEV static void partners(const F& a, F& an, F& an2) { an = from_lane(a, lane_next()); an2 = from_lane(a, lane_next2()); }
+#endif
   PCD_DEV static bool all3(bool b) {  // (no short circuit: all three lanes shuffle)
     const int o1 = __shfl((int)b, lane_next(), 64), o2 = __shfl((int)b, lane_next2(), 64);
     return b & (o1 != 0) & (o2 != 0);
@@ -1013,9 +1034,10 @@ struct Fp3S {
   //   x2 = an (times nr on lanes 0, 1),  x3 = an2 (times nr on lane 0)
   PCD_DEV Fp3S operator*(const Fp3S& b) const {
     if constexpr (F::MAILBOX) return mb_mul(b);
-    const int ln = lane_next(), ln2 = lane_next2();
     const unsigned k = role();
-    const F an = from_lane(c, ln), an2 = from_lane(c, ln2), bn = from_lane(b.c, ln), bn2 = from_lane(b.c, ln2);
+    F an, an2, bn, bn2;
+    partners(c, an, an2);
+    partners(b.c, bn, bn2);
     const F x2 = sel(k < 2, an.mul_small(NR), an), x3 = sel(k == 0, an2.mul_small(NR), an2);
     const F y1 = sel(k == 0, b.c, sel(k == 1, bn2, bn));
     const F y2 = sel(k == 0, bn2, sel(k == 1, bn, b.c));
@@ -1073,9 +1095,9 @@ struct Fp3S {
   }
   PCD_DEV Fp3S sqr() const {
     if constexpr (F::MAILBOX) return mb_sqr();
-    const int ln = lane_next(), ln2 = lane_next2();
     const unsigned k = role();
-    const F an = from_lane(c, ln), an2 = from_lane(c, ln2);
+    F an, an2;
+    partners(c, an, an2);
     const F x1 = sel(k == 0, c, sel(k == 1, an2.dbl(), an2));
     const F y1 = sel(k == 2, an2, c);
     const F x2 = an.mul_small_var(k == 0 ? 2 * NR : (k == 1 ? NR : 2));
