@@ -521,20 +521,34 @@ struct EC {
 // every slot with role-selected operands and handing results across with `ds_swizzle`-class shuffles (`__shfl_xor 1`).  8 product
 // slots instead of 16 products for an addition, 5 instead of 9 for a doubling.  Both lanes pass the same points and both return the
 // whole result.  Prime-field groups only (the extension-field groups are already spread over lanes at the field level).
+// (Round 6: the lane-split extension-field groups take the same form with an item of 2 L lanes, L = 2 / 3 lanes per point: the first L
+//  lanes are the "even" half, the next L the "odd" one, each half a whole lane-split point, products collective inside a half as before,
+//  results handed across at distance L.  Their pair levels were the chain the help proofs wait for: DESIGN.md section 4.)
+template <class F, class = void> struct HalfLanes { static constexpr int L = 1; };
+template <class F> struct HalfLanes<F, typename std::enable_if<(F::LANES > 1)>::type> { static constexpr int L = F::LANES; };
 template <class G>
 struct EC2 {
   typedef typename G::F F;
   typedef Jac<F> J;
   typedef EC<G> E;
-  PCD_DEV static bool odd() { return (threadIdx.x & 1u) != 0; }
-  PCD_DEV static F xch(const F& a) { F r;
+  static constexpr int L = HalfLanes<F>::L;   // lanes per point; an item is 2 L adjacent lanes starting at a multiple of 2 L
+  PCD_DEV static bool odd() { return (((threadIdx.x & 63u) / (unsigned)L) & 1u) != 0; }
+  template <class B> PCD_DEV static B xch_base(const B& a) { B r;
+    if constexpr (L == 1) {
 #pragma unroll
-    for (int i = 0; i < F::N; i++) r.v[i] = (uint32_t)__shfl_xor((int)a.v[i], 1, 64);
-    return r; }
-  PCD_DEV static F sel(bool t, const F& a, const F& b) { F r;
+      for (int i = 0; i < B::N; i++) r.v[i] = (uint32_t)__shfl_xor((int)a.v[i], 1, 64);
+    } else {
+      const int partner = (int)(threadIdx.x & 63u) + (odd() ? -L : L);
 #pragma unroll
-    for (int i = 0; i < F::N; i++) r.v[i] = t ? a.v[i] : b.v[i];
+      for (int i = 0; i < B::N; i++) r.v[i] = (uint32_t)__shfl((int)a.v[i], partner, 64);
+    }
     return r; }
+  template <class B> PCD_DEV static B sel_base(bool t, const B& a, const B& b) { B r;
+#pragma unroll
+    for (int i = 0; i < B::N; i++) r.v[i] = t ? a.v[i] : b.v[i];
+    return r; }
+  PCD_DEV static F xch(const F& a) { if constexpr (L == 1) return xch_base(a); else return F{xch_base(a.c)}; }
+  PCD_DEV static F sel(bool t, const F& a, const F& b) { if constexpr (L == 1) return sel_base(t, a, b); else return F{sel_base(t, a.c, b.c)}; }
   // one product slot: the even lane computes ea * eb, the odd lane oa * ob
   PCD_DEV static F slot(const F& ea, const F& eb, const F& oa, const F& ob) { const bool o = odd(); return sel(o, oa, ea) * sel(o, ob, eb); }
 
@@ -599,8 +613,86 @@ struct EC2 {
     return out;
   }
 };
+// FOUR lanes per group operation (round 6; prime-field groups): a quad of adjacent lanes shares one addition or doubling.  The formulas are
+// five / four product levels deep (add-2007-bl: {Z1Z1, Z2Z2, Y1 Z2, Y2 Z1} -> {U1, U2, S1, S2} -> {I, (Z1+Z2)^2, r^2} -> {J, V, Z3} ->
+// {S1 J, r (V - X3)};  dbl-2007-bl: {XX, YY, ZZ, (Y+Z)^2} -> {YYYY, ZZ^2, (X+YY)^2} -> M^2 -> M (S - X3)) against eight / five slots of the
+// two-lane form: a pair level of the bucket reduction is 9 dependent products instead of 13.  Every lane of the quad computes one product
+// of a level with role-selected operands; results travel by quad broadcasts (DPP quad_perm: a VALU move, no LDS round trip).  All four
+// lanes pass the same points and all four return the whole result.
+template <class G>
+struct EC4 {
+  typedef typename G::F F;
+  typedef Jac<F> J;
+  template <int K> PCD_DEV static F bc(const F& a) { F r;   // lane K of every quad to all four of its lanes
+#pragma unroll
+    for (int i = 0; i < F::N; i++) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], K * 0x55, 0xF, 0xF, false);
+    return r; }
+  PCD_DEV static F sel4(uint32_t l, const F& a0, const F& a1, const F& a2, const F& a3) { F r;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) { const uint32_t lo = (l & 1u) ? a1.v[i] : a0.v[i], hi = (l & 1u) ? a3.v[i] : a2.v[i]; r.v[i] = (l & 2u) ? hi : lo; }
+    return r; }
+  PCD_DEV static J dbl4(const J& p) {
+    if (p.is_inf()) return p;
+    const uint32_t l = threadIdx.x & 3u;
+    const F yz = p.Y + p.Z;
+    const F a1 = sel4(l, p.X, p.Y, p.Z, yz);
+    const F s1 = a1 * a1;                                   // 0: XX   1: YY   2: ZZ   3: (Y + Z)^2
+    const F XX = bc<0>(s1), YY = bc<1>(s1), ZZ = bc<2>(s1), YZ2 = bc<3>(s1);
+    const F xyy = p.X + YY;
+    const F a2 = sel4(l, YY, ZZ, xyy, xyy);
+    const F s2 = a2 * a2;                                   // 0: YYYY   1: ZZ^2   2: (X + YY)^2   (3: the same again)
+    const F YYYY = bc<0>(s2), ZZ2 = bc<1>(s2), XYY2 = bc<2>(s2);
+    const F S = (XYY2 - XX - YYYY).dbl();
+    const F M = XX.dbl() + XX + G::mul_by_a(ZZ2);
+    J r;
+    r.X = M * M - S.dbl();                                  // (computed by all four lanes)
+    r.Z = YZ2 - YY - ZZ;
+    r.Y = M * (S - r.X) - YYYY.dbl().dbl().dbl();
+    return r;
+  }
+  PCD_DEV static J add4(const J& p, const J& q) {
+    if (p.is_inf()) return q;
+    if (q.is_inf()) return p;
+    const uint32_t l = threadIdx.x & 3u;
+    const F a1 = sel4(l, p.Z, q.Z, p.Y, q.Y), b1 = sel4(l, p.Z, q.Z, q.Z, p.Z);
+    const F s1 = a1 * b1;                                   // 0: Z1Z1   1: Z2Z2   2: Y1 Z2   3: Y2 Z1
+    const F Z1Z1 = bc<0>(s1), Z2Z2 = bc<1>(s1);
+    const F a2 = sel4(l, p.X, q.X, s1, s1), b2 = sel4(l, Z2Z2, Z1Z1, Z2Z2, Z1Z1);
+    const F s2 = a2 * b2;                                   // 0: U1   1: U2   2: S1   3: S2
+    const F U1 = bc<0>(s2), U2 = bc<1>(s2), S1 = bc<2>(s2), S2 = bc<3>(s2);
+    const F H = U2 - U1;
+    F r = S2 - S1;
+    if (H.is_zero()) return r.is_zero() ? dbl4(p) : J::infinity();
+    r = r.dbl();
+    const F h2 = H.dbl(), zs = p.Z + q.Z;
+    const F a3 = sel4(l, h2, zs, r, r);
+    const F s3 = a3 * a3;                                   // 0: I = (2H)^2   1: (Z1 + Z2)^2   2: r^2   (3: the same again)
+    const F I = bc<0>(s3), ZS = bc<1>(s3), rr = bc<2>(s3);
+    const F zc = ZS - Z1Z1 - Z2Z2;
+    const F a4 = sel4(l, H, U1, zc, zc), b4 = sel4(l, I, I, H, H);
+    const F s4 = a4 * b4;                                   // 0: J = H I   1: V = U1 I   2: Z3   (3: the same again)
+    const F Jv = bc<0>(s4), V = bc<1>(s4);
+    J out;
+    out.Z = bc<2>(s4);
+    out.X = rr - Jv - V.dbl();
+    const F vx = V - out.X;
+    const F a5 = sel4(l, S1, r, S1, r), b5 = sel4(l, Jv, vx, Jv, vx);
+    const F s5 = a5 * b5;                                   // 0, 2: S1 J   1, 3: r (V - X3)
+    out.Y = bc<1>(s5) - bc<0>(s5).dbl();
+    return out;
+  }
+};
+#ifndef PCD_EC4
+#define PCD_EC4 1   // 0: the prime-field groups' pair levels keep two lanes per operation (EC2)
+#endif
 // groups whose latency-bound pair levels run two lanes per operation
 template <class G> struct TwoLaneOps { static constexpr bool value = false; };
 template <class FQ, class FRP, unsigned A, int CURVE, bool INL> struct TwoLaneOps<G1Cfg<FQ, FRP, A, CURVE, INL>> { static constexpr bool value = true; };
+// ... and the extension-field groups with two HALVES of L lanes per operation (round 6; PCD_EC2_SPLIT=0 restores one lane-split point per item)
+#ifndef PCD_EC2_SPLIT
+#define PCD_EC2_SPLIT 1
+#endif
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE, bool INL> struct TwoLaneOps<G2Cfg2<FQ, FRP, A, NR, CURVE, INL>> { static constexpr bool value = PCD_EC2_SPLIT != 0; };
+template <class FQ, class FRP, unsigned A, unsigned NR, int CURVE, bool INL> struct TwoLaneOps<G2Cfg3<FQ, FRP, A, NR, CURVE, INL>> { static constexpr bool value = PCD_EC2_SPLIT != 0; };
 
 }  // namespace pcd

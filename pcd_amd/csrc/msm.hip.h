@@ -1121,29 +1121,34 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(const uint32_t* __restric
 
 // Items of the bucket-reduction levels.  Prime-field groups spend TWO lanes on every item (EC2: 8 product slots per addition
 // instead of 16 products, 5 per doubling instead of 9); the extension-field groups are spread over lanes at the field level already.
-template <class G, bool ENABLE = true>
+template <class G, bool ENABLE = true, bool Q = true>
 struct MsmPairItems {
-  static constexpr bool TWO = ENABLE && TwoLaneOps<G>::value && MsmItems<G>::LANES == 1;
-  static constexpr uint32_t LANES = TWO ? 2 : MsmItems<G>::LANES, PER_WAVE = 64 / LANES;
+  // (an item whose group is lane-split over L lanes spends 2 L: two halves of L lanes, EC2 with L > 1)
+  static constexpr bool TWO = ENABLE && TwoLaneOps<G>::value && (MsmItems<G>::LANES == 1 || HalfLanes<typename MsmItems<G>::GA::F>::L == (int)MsmItems<G>::LANES);
+  // prime-field groups: four lanes per operation (EC4) where the caller allows it (Q) -- the LATE pair levels: a level with thousands of items is
+  // throughput, where four lanes spend 36 lane-products on an addition + doubling against 26 of the two-lane form (measured: all levels on four
+  // lanes moved a 2^20 MSM's tail by 2 %, a 2^16 one's by 16 %; profiles/r06_ab_ec4_all_levels.txt)
+  static constexpr bool QUAD = Q && TWO && MsmItems<G>::LANES == 1 && PCD_EC4 != 0;
+  static constexpr uint32_t BASE = MsmItems<G>::LANES, LANES = QUAD ? 4 : TWO ? 2 * BASE : BASE, PER_WAVE = 64 / LANES;
   PCD_DEV static bool idle() { return threadIdx.x >= PER_WAVE * LANES; }
   PCD_DEV static uint32_t item() { return blockIdx.x * PER_WAVE + threadIdx.x / LANES; }
   PCD_DEV static uint32_t local() { return threadIdx.x / LANES; }
-  PCD_DEV static bool writer() { return !TWO || (threadIdx.x & 1u) == 0; }  // (both lanes of a pair hold the whole result)
+  PCD_DEV static bool writer() { return QUAD ? (threadIdx.x & 3u) == 0 : (!TWO || (((threadIdx.x & 63u) / BASE) & 1u) == 0); }  // (every half / lane of an item holds the whole result)
   static uint32_t grid(uint32_t items) { return (items + PER_WAVE - 1) / PER_WAVE; }
 };
-template <class G, bool TWO = MsmPairItems<G, true>::TWO>
+template <class G, bool TWO = MsmPairItems<G, true>::TWO, bool Q = true>
 struct MsmPairOps {
   typedef typename MsmItems<G>::GA GA;
   typedef Jac<typename GA::F> J;
   PCD_DEV static J add(const J& a, const J& b) { return EC<GA>::add(a, b); }
   PCD_DEV static J dbl(const J& a) { return EC<GA>::dbl(a); }
 };
-template <class G>
-struct MsmPairOps<G, true> {
+template <class G, bool Q>
+struct MsmPairOps<G, true, Q> {
   typedef typename SplitOfTail<G>::type GA;  // G itself, or its mailbox variant (753-bit)
   typedef Jac<typename GA::F> J;
-  PCD_DEV static J add(const J& a, const J& b) { return EC2<GA>::add2(a, b); }
-  PCD_DEV static J dbl(const J& a) { return EC2<GA>::dbl2(a); }
+  PCD_DEV static J add(const J& a, const J& b) { if constexpr (MsmPairItems<G, true, Q>::QUAD) return EC4<GA>::add4(a, b); else return EC2<GA>::add2(a, b); }
+  PCD_DEV static J dbl(const J& a) { if constexpr (MsmPairItems<G, true, Q>::QUAD) return EC4<GA>::dbl4(a); else return EC2<GA>::dbl2(a); }
 };
 // Big buckets, two levels (all counts live on the device; grid-stride loops):
 //   A: one workgroup per segment of <= seg_len pieces -> partial[segment]      B: one workgroup per big bucket sums its partials.
@@ -1264,13 +1269,13 @@ __global__ void __launch_bounds__(64) msm_tail_level_kernel(const uint32_t* __re
 //   z = 0:  A'_{j-1} = 2 (A_{2j} + A_{2j+1})        z = 1:  L_j = A_{2j} + 2 A_{2j+1} -> C'[JC + j]        z = 2:  C'_j = C_{2j} + C_{2j+1}
 // (items and operations: MsmPairItems / MsmPairOps above)
 // one piece of a pair level: role 0 / 1 / 2 for item j of window w (the lanes of the item call it together)
-template <class G>
+template <class G, bool Q = true>
 PCD_DEV void msm_tail_pair_item(int role, uint32_t j, uint32_t w, const uint32_t* A_in, uint32_t mA, size_t strideA_in, const uint32_t* C_in,
                                 uint32_t mC, size_t strideC_in, uint32_t* A_out, size_t strideA_out, uint32_t* C_out, size_t strideC_out) {
-  typedef MsmPairOps<G> O;
+  typedef MsmPairOps<G, MsmPairItems<G, true>::TWO, Q> O;
   typedef typename O::GA GA;
   typedef typename GA::F F;
-  typedef MsmPairItems<G> IT;
+  typedef MsmPairItems<G, true, Q> IT;
   constexpr int PW = Jac<F>::WORDS;
   const uint32_t JA = (mA + 1) >> 1, JC = (mC + 1) >> 1;
   if (role < 2) {
@@ -1295,14 +1300,14 @@ PCD_DEV void msm_tail_pair_item(int role, uint32_t j, uint32_t w, const uint32_t
     if (IT::writer()) acc.store(C_out + (w * strideC_out + j) * PW);
   }
 }
-template <class G>
+template <class G, bool Q = true>
 __global__ void __launch_bounds__(64) msm_tail_pair_kernel(const uint32_t* __restrict__ A_in, uint32_t mA, size_t strideA_in,
                                                            const uint32_t* __restrict__ C_in, uint32_t mC, size_t strideC_in,
                                                            uint32_t* __restrict__ A_out, size_t strideA_out,
                                                            uint32_t* __restrict__ C_out, size_t strideC_out) {
-  typedef MsmPairItems<G> IT;
+  typedef MsmPairItems<G, true, Q> IT;
   if (IT::idle()) return;
-  msm_tail_pair_item<G>((int)blockIdx.z, IT::item(), blockIdx.y, A_in, mA, strideA_in, C_in, mC, strideC_in, A_out, strideA_out, C_out, strideC_out);
+  msm_tail_pair_item<G, Q>((int)blockIdx.z, IT::item(), blockIdx.y, A_in, mA, strideA_in, C_in, mC, strideC_in, A_out, strideA_out, C_out, strideC_out);
 }
 // The LAST pair levels in one launch: once a level's 2 JA + JC pieces fit the item slots of one workgroup of FOUR waves -- one wave per
 // SIMD of a CU: with eight, two waves share a SIMD and every level takes 1.6x as long, more than the launch it saves (measured: tail
@@ -1310,6 +1315,12 @@ __global__ void __launch_bounds__(64) msm_tail_pair_kernel(const uint32_t* __res
 // (L2-resident by then), a workgroup barrier where the per-level kernels had a dependent launch (~8 us each, eight of them at c = 20).
 // Not for the mailbox field variants (their LDS slots are per lane of ONE wave): the 753-bit groups keep a launch per level.
 constexpr uint32_t MSM_FUSED_WAVES = 4;
+// a pair level with more items than this (over all bucket windows; x 3 pieces of work each) keeps two lanes per operation for the prime-field
+// groups: 4096 items x 3 x 4 lanes = 768 waves, under one wave per SIMD of the chip -- below that a level is pure latency and four lanes pay
+#ifndef PCD_QUAD_MAX_ITEMS
+#define PCD_QUAD_MAX_ITEMS 4096
+#endif
+constexpr uint32_t MSM_QUAD_MAX_ITEMS = PCD_QUAD_MAX_ITEMS;
 template <class G>
 struct MsmFusedTail {
   static constexpr bool ENABLED = !MsmPairOps<G>::GA::F::Base::MAILBOX;
@@ -1823,7 +1834,10 @@ hipError_t msm_run(MsmWorkspace& ws, hipStream_t st, const MsmBasesView& bv, con
       }
       if (fused) {
         // (the host only follows the level sequence to know where the result ends up)
-      } else if (k == 1)
+      } else if (k == 1 && std::max(JA, JC) * (uint32_t)Wg > MSM_QUAD_MAX_ITEMS)   // a level this wide is throughput: two lanes per operation
+        hipLaunchKernelGGL((msm_tail_pair_kernel<G, false>), dim3(MsmPairItems<G, true, false>::grid(std::max(JA, JC)), Wg, 3), dim3(64), 0, st, A_in, mA,
+                           strideA_in, C_in, mC, strideC_in, A_out, strideAC, C_out, strideAC);
+      else if (k == 1)
         hipLaunchKernelGGL((msm_tail_pair_kernel<G>), dim3(MsmPairItems<G>::grid(std::max(JA, JC)), Wg, 3), dim3(64), 0, st, A_in, mA, strideA_in, C_in,
                            mC, strideC_in, A_out, strideAC, C_out, strideAC);
       else if (threads <= (1u << 15))
