@@ -18,6 +18,29 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Column accumulators as ONE multiply-add chain (round 6).  The product loops are written `acc += x * y; ... acc >>= 28`, but LLVM's Reassociate
+// pass rebuilds every column's sum as (p1 + p2 + ... + pn) + carry -- the carried-in accumulator ranks last -- which costs a 64-bit
+// v_lshl_add_u64 per column on top of the multiply-adds (180 of the 3 117 instructions of a 298-bit mixed addition; three work-arounds failed in
+// round 4: profiles/DESIGN_history_r01-r05.md section 7).  A partial sum with a SECOND use is a leaf for that pass: an always-true
+// `__builtin_assume` on every partial sum (no signed overflow / below 2^64 - 1: the column bounds derived above) gives it one, the chain
+// stays a chain of v_mad_*64_*32 whose addend is the running sum, and the assumes vanish before instruction selection.  Device code only.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PCD_NO_KEEP_CHAIN)
+__device__ __attribute__((weak)) int64_t pcd_never_s = INT64_MIN;   // (weak: the optimiser may not look through the initialiser, so the
+__device__ __attribute__((weak)) uint64_t pcd_never_u = UINT64_MAX;  //  comparisons below cannot be proven and folded away early)
+#define PCD_KEEP_S(acc) __builtin_assume((acc) != pcd_never_s)
+// (the plain products: only where they are CALLS -- the 27-limb fields, one body per kernel: 1 689 -> 1 630 instructions a product.  The inlined
+//  11-limb ones sit hundreds of times in the latency kernels, where the assumes cost minutes of compile time: PCD_KEEP_CHAIN_UNSIGNED forces them on)
+#if defined(PCD_KEEP_CHAIN_UNSIGNED)
+#define PCD_KEEP_U(acc) __builtin_assume((acc) != pcd_never_u)
+#else
+#define PCD_KEEP_U(acc) do { if constexpr (N > 11) __builtin_assume((acc) != pcd_never_u); } while (0)
+#endif
+#else
+#define PCD_KEEP_S(acc) ((void)0)
+#define PCD_KEEP_U(acc) ((void)0)
+#endif
+
+
 #include "params28_gen.h"
 #include "params_gen.h"
 
@@ -270,20 +293,20 @@ struct Fp {
 #pragma unroll
     for (int k = 0; k < N; k++) {
 #pragma unroll
-      for (int i = 0; i <= k; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+      for (int i = 0; i <= k; i++) { acc += (uint64_t)a.v[i] * b.v[k - i]; PCD_KEEP_U(acc); }
 #pragma unroll
-      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::mod(k - i);
+      for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_U(acc); }
       m[k] = ((uint32_t)acc * P::INV) & MASK;
-      acc += (uint64_t)m[k] * P::mod(0);
+      acc += (uint64_t)m[k] * P::mod(0); PCD_KEEP_U(acc);
       acc >>= 28;
     }
     Fp r;
 #pragma unroll
     for (int k = N; k < 2 * N - 1; k++) {
 #pragma unroll
-      for (int i = k - N + 1; i < N; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+      for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)a.v[i] * b.v[k - i]; PCD_KEEP_U(acc); }
 #pragma unroll
-      for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::mod(k - i);
+      for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_U(acc); }
       r.v[k - N] = (uint32_t)acc & MASK;
       acc >>= 28;
     }
@@ -310,22 +333,22 @@ struct Fp {
 #pragma unroll
     for (int k = 0; k < N; k++) {
 #pragma unroll
-      for (int i = 0; 2 * i < k; i++) acc += (uint64_t)a2[i] * a.v[k - i];
-      if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+      for (int i = 0; 2 * i < k; i++) { acc += (uint64_t)a2[i] * a.v[k - i]; PCD_KEEP_U(acc); }
+      if ((k & 1) == 0) { acc += (uint64_t)a.v[k / 2] * a.v[k / 2]; PCD_KEEP_U(acc); }
 #pragma unroll
-      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::mod(k - i);
+      for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_U(acc); }
       m[k] = ((uint32_t)acc * P::INV) & MASK;
-      acc += (uint64_t)m[k] * P::mod(0);
+      acc += (uint64_t)m[k] * P::mod(0); PCD_KEEP_U(acc);
       acc >>= 28;
     }
     Fp r;
 #pragma unroll
     for (int k = N; k < 2 * N - 1; k++) {
 #pragma unroll
-      for (int i = k - N + 1; 2 * i < k; i++) acc += (uint64_t)a2[i] * a.v[k - i];
-      if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+      for (int i = k - N + 1; 2 * i < k; i++) { acc += (uint64_t)a2[i] * a.v[k - i]; PCD_KEEP_U(acc); }
+      if ((k & 1) == 0) { acc += (uint64_t)a.v[k / 2] * a.v[k / 2]; PCD_KEEP_U(acc); }
 #pragma unroll
-      for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::mod(k - i);
+      for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_U(acc); }
       r.v[k - N] = (uint32_t)acc & MASK;
       acc >>= 28;
     }
@@ -385,14 +408,14 @@ struct Fp {
     for (int k = 0; k < N; k++) {
 #pragma unroll
       for (int i = 0; i <= k; i++) {
-        acc += (int64_t)a0.v[i] * b0.v[k - i];
+        acc += (int64_t)a0.v[i] * b0.v[k - i]; PCD_KEEP_S(acc);
         PCD_LZ_WIDE_MAC(a0.v[i], b0.v[k - i])
-        if (TERMS == 2) { acc += (int64_t)a1.v[i] * b1.v[k - i]; PCD_LZ_WIDE_MAC(a1.v[i], b1.v[k - i]) }
+        if (TERMS == 2) { acc += (int64_t)a1.v[i] * b1.v[k - i]; PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(a1.v[i], b1.v[k - i]) }
       }
 #pragma unroll
-      for (int i = 0; i < k; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_LZ_WIDE_MAC(m[i], P::mod(k - i)) }
+      for (int i = 0; i < k; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(m[i], P::mod(k - i)) }
       m[k] = (int32_t)(((uint32_t)acc * P::INV) & MASK);
-      acc += (int64_t)m[k] * (int32_t)P::mod(0);
+      acc += (int64_t)m[k] * (int32_t)P::mod(0); PCD_KEEP_S(acc);
       PCD_LZ_WIDE_MAC(m[k], P::mod(0))
       PCD_LZ_WIDE_CHECK();
       acc >>= 28;
@@ -402,12 +425,12 @@ struct Fp {
     for (int k = N; k < 2 * N - 1; k++) {
 #pragma unroll
       for (int i = k - N + 1; i < N; i++) {
-        acc += (int64_t)a0.v[i] * b0.v[k - i];
+        acc += (int64_t)a0.v[i] * b0.v[k - i]; PCD_KEEP_S(acc);
         PCD_LZ_WIDE_MAC(a0.v[i], b0.v[k - i])
-        if (TERMS == 2) { acc += (int64_t)a1.v[i] * b1.v[k - i]; PCD_LZ_WIDE_MAC(a1.v[i], b1.v[k - i]) }
+        if (TERMS == 2) { acc += (int64_t)a1.v[i] * b1.v[k - i]; PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(a1.v[i], b1.v[k - i]) }
       }
 #pragma unroll
-      for (int i = k - N + 1; i < N; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_LZ_WIDE_MAC(m[i], P::mod(k - i)) }
+      for (int i = k - N + 1; i < N; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(m[i], P::mod(k - i)) }
       r.v[k - N] = (uint32_t)acc & MASK;
       PCD_LZ_WIDE_CHECK();
       acc >>= 28;
@@ -437,15 +460,15 @@ struct Fp {
     for (int k = 0; k < N; k++) {
 #pragma unroll
       for (int i = 0; i <= k; i++) {
-        acc += (int64_t)a0.v[i] * b0.v[k - i]; PCD_LZ_WIDE_MAC(a0.v[i], b0.v[k - i])
-        acc += (int64_t)a1.v[i] * b1.v[k - i]; PCD_LZ_WIDE_MAC(a1.v[i], b1.v[k - i])
-        acc += (int64_t)a2.v[i] * b2.v[k - i]; PCD_LZ_WIDE_MAC(a2.v[i], b2.v[k - i])
-        acc += (int64_t)a3.v[i] * b3.v[k - i]; PCD_LZ_WIDE_MAC(a3.v[i], b3.v[k - i])
+        acc += (int64_t)a0.v[i] * b0.v[k - i]; PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(a0.v[i], b0.v[k - i])
+        acc += (int64_t)a1.v[i] * b1.v[k - i]; PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(a1.v[i], b1.v[k - i])
+        acc += (int64_t)a2.v[i] * b2.v[k - i]; PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(a2.v[i], b2.v[k - i])
+        acc += (int64_t)a3.v[i] * b3.v[k - i]; PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(a3.v[i], b3.v[k - i])
       }
 #pragma unroll
-      for (int i = 0; i < k; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_LZ_WIDE_MAC(m[i], P::mod(k - i)) }
+      for (int i = 0; i < k; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(m[i], P::mod(k - i)) }
       m[k] = (int32_t)(((uint32_t)acc * P::INV) & MASK);
-      acc += (int64_t)m[k] * (int32_t)P::mod(0);
+      acc += (int64_t)m[k] * (int32_t)P::mod(0); PCD_KEEP_S(acc);
       PCD_LZ_WIDE_MAC(m[k], P::mod(0))
       PCD_LZ_WIDE_CHECK();
       acc >>= 28;
@@ -455,13 +478,13 @@ struct Fp {
     for (int k = N; k < 2 * N - 1; k++) {
 #pragma unroll
       for (int i = k - N + 1; i < N; i++) {
-        acc += (int64_t)a0.v[i] * b0.v[k - i]; PCD_LZ_WIDE_MAC(a0.v[i], b0.v[k - i])
-        acc += (int64_t)a1.v[i] * b1.v[k - i]; PCD_LZ_WIDE_MAC(a1.v[i], b1.v[k - i])
-        acc += (int64_t)a2.v[i] * b2.v[k - i]; PCD_LZ_WIDE_MAC(a2.v[i], b2.v[k - i])
-        acc += (int64_t)a3.v[i] * b3.v[k - i]; PCD_LZ_WIDE_MAC(a3.v[i], b3.v[k - i])
+        acc += (int64_t)a0.v[i] * b0.v[k - i]; PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(a0.v[i], b0.v[k - i])
+        acc += (int64_t)a1.v[i] * b1.v[k - i]; PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(a1.v[i], b1.v[k - i])
+        acc += (int64_t)a2.v[i] * b2.v[k - i]; PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(a2.v[i], b2.v[k - i])
+        acc += (int64_t)a3.v[i] * b3.v[k - i]; PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(a3.v[i], b3.v[k - i])
       }
 #pragma unroll
-      for (int i = k - N + 1; i < N; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_LZ_WIDE_MAC(m[i], P::mod(k - i)) }
+      for (int i = k - N + 1; i < N; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_KEEP_S(acc); PCD_LZ_WIDE_MAC(m[i], P::mod(k - i)) }
       r.v[k - N] = (uint32_t)acc & MASK;
       PCD_LZ_WIDE_CHECK();
       acc >>= 28;
@@ -484,22 +507,22 @@ struct Fp {
 #pragma unroll
     for (int k = 0; k < N; k++) {
 #pragma unroll
-      for (int i = 0; 2 * i < k; i++) acc += (int64_t)a2[i] * a.v[k - i];
-      if ((k & 1) == 0) acc += (int64_t)a.v[k / 2] * a.v[k / 2];
+      for (int i = 0; 2 * i < k; i++) { acc += (int64_t)a2[i] * a.v[k - i]; PCD_KEEP_S(acc); }
+      if ((k & 1) == 0) { acc += (int64_t)a.v[k / 2] * a.v[k / 2]; PCD_KEEP_S(acc); }
 #pragma unroll
-      for (int i = 0; i < k; i++) acc += (int64_t)m[i] * (int32_t)P::mod(k - i);
+      for (int i = 0; i < k; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_KEEP_S(acc); }
       m[k] = (int32_t)(((uint32_t)acc * P::INV) & MASK);
-      acc += (int64_t)m[k] * (int32_t)P::mod(0);
+      acc += (int64_t)m[k] * (int32_t)P::mod(0); PCD_KEEP_S(acc);
       acc >>= 28;
     }
     Fp r;
 #pragma unroll
     for (int k = N; k < 2 * N - 1; k++) {
 #pragma unroll
-      for (int i = k - N + 1; 2 * i < k; i++) acc += (int64_t)a2[i] * a.v[k - i];
-      if ((k & 1) == 0) acc += (int64_t)a.v[k / 2] * a.v[k / 2];
+      for (int i = k - N + 1; 2 * i < k; i++) { acc += (int64_t)a2[i] * a.v[k - i]; PCD_KEEP_S(acc); }
+      if ((k & 1) == 0) { acc += (int64_t)a.v[k / 2] * a.v[k / 2]; PCD_KEEP_S(acc); }
 #pragma unroll
-      for (int i = k - N + 1; i < N; i++) acc += (int64_t)m[i] * (int32_t)P::mod(k - i);
+      for (int i = k - N + 1; i < N; i++) { acc += (int64_t)m[i] * (int32_t)P::mod(k - i); PCD_KEEP_S(acc); }
       r.v[k - N] = (uint32_t)acc & MASK;
       acc >>= 28;
     }
@@ -530,14 +553,14 @@ struct Fp {
     for (int k = 0; k < N; k++) {
 #pragma unroll
       for (int i = 0; i <= k; i++) {
-        acc += (uint64_t)a0.v[i] * b0.v[k - i];
-        acc += (uint64_t)a1.v[i] * b1.v[k - i];
-        if (TERMS == 3) acc += (uint64_t)a2.v[i] * b2.v[k - i];
+        acc += (uint64_t)a0.v[i] * b0.v[k - i]; PCD_KEEP_U(acc);
+        acc += (uint64_t)a1.v[i] * b1.v[k - i]; PCD_KEEP_U(acc);
+        if (TERMS == 3) { acc += (uint64_t)a2.v[i] * b2.v[k - i]; PCD_KEEP_U(acc); }
       }
 #pragma unroll
-      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::mod(k - i);
+      for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_U(acc); }
       m[k] = ((uint32_t)acc * P::INV) & MASK;
-      acc += (uint64_t)m[k] * P::mod(0);
+      acc += (uint64_t)m[k] * P::mod(0); PCD_KEEP_U(acc);
       acc >>= 28;
     }
     int32_t r[N];
@@ -545,12 +568,12 @@ struct Fp {
     for (int k = N; k < 2 * N - 1; k++) {
 #pragma unroll
       for (int i = k - N + 1; i < N; i++) {
-        acc += (uint64_t)a0.v[i] * b0.v[k - i];
-        acc += (uint64_t)a1.v[i] * b1.v[k - i];
-        if (TERMS == 3) acc += (uint64_t)a2.v[i] * b2.v[k - i];
+        acc += (uint64_t)a0.v[i] * b0.v[k - i]; PCD_KEEP_U(acc);
+        acc += (uint64_t)a1.v[i] * b1.v[k - i]; PCD_KEEP_U(acc);
+        if (TERMS == 3) { acc += (uint64_t)a2.v[i] * b2.v[k - i]; PCD_KEEP_U(acc); }
       }
 #pragma unroll
-      for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * P::mod(k - i);
+      for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_U(acc); }
       r[k - N] = (int32_t)((uint32_t)acc & MASK);
       acc >>= 28;
     }
