@@ -35,9 +35,19 @@ __device__ __attribute__((weak)) uint64_t pcd_never_u = UINT64_MAX;  //  compari
 #else
 #define PCD_KEEP_U(acc) do { if constexpr (N > 11) __builtin_assume((acc) != pcd_never_u); } while (0)
 #endif
+// (single products and squarings: the chain form where the code is inlined -- the 753-bit transform passes, -4 % -- but NOT in the mailbox
+//  call bodies of the 753-bit G1 accumulation, which run one wave per SIMD: there LLVM's two interleaved sub-chains per column are the better
+//  schedule -- same-box A/B 27.45 -> 28.08 ms with the chain form; the fused two- / three-term products of the lane-split Fq2 / Fq3 take it:
+//  22.06 -> 21.04 ms, 8.34 -> 7.09 ms; profiles/r06_ab_keep_chain_753.txt)
+#if defined(PCD_KEEP_CHAIN_UNSIGNED)
+#define PCD_KEEP_UM(acc) __builtin_assume((acc) != pcd_never_u)
+#else
+#define PCD_KEEP_UM(acc) do { if constexpr (N > 11 && INLINE_ARITH) __builtin_assume((acc) != pcd_never_u); } while (0)
+#endif
 #else
 #define PCD_KEEP_S(acc) ((void)0)
 #define PCD_KEEP_U(acc) ((void)0)
+#define PCD_KEEP_UM(acc) ((void)0)
 #endif
 
 
@@ -293,20 +303,20 @@ struct Fp {
 #pragma unroll
     for (int k = 0; k < N; k++) {
 #pragma unroll
-      for (int i = 0; i <= k; i++) { acc += (uint64_t)a.v[i] * b.v[k - i]; PCD_KEEP_U(acc); }
+      for (int i = 0; i <= k; i++) { acc += (uint64_t)a.v[i] * b.v[k - i]; PCD_KEEP_UM(acc); }
 #pragma unroll
-      for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_U(acc); }
+      for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_UM(acc); }
       m[k] = ((uint32_t)acc * P::INV) & MASK;
-      acc += (uint64_t)m[k] * P::mod(0); PCD_KEEP_U(acc);
+      acc += (uint64_t)m[k] * P::mod(0); PCD_KEEP_UM(acc);
       acc >>= 28;
     }
     Fp r;
 #pragma unroll
     for (int k = N; k < 2 * N - 1; k++) {
 #pragma unroll
-      for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)a.v[i] * b.v[k - i]; PCD_KEEP_U(acc); }
+      for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)a.v[i] * b.v[k - i]; PCD_KEEP_UM(acc); }
 #pragma unroll
-      for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_U(acc); }
+      for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_UM(acc); }
       r.v[k - N] = (uint32_t)acc & MASK;
       acc >>= 28;
     }
@@ -333,22 +343,22 @@ struct Fp {
 #pragma unroll
     for (int k = 0; k < N; k++) {
 #pragma unroll
-      for (int i = 0; 2 * i < k; i++) { acc += (uint64_t)a2[i] * a.v[k - i]; PCD_KEEP_U(acc); }
-      if ((k & 1) == 0) { acc += (uint64_t)a.v[k / 2] * a.v[k / 2]; PCD_KEEP_U(acc); }
+      for (int i = 0; 2 * i < k; i++) { acc += (uint64_t)a2[i] * a.v[k - i]; PCD_KEEP_UM(acc); }
+      if ((k & 1) == 0) { acc += (uint64_t)a.v[k / 2] * a.v[k / 2]; PCD_KEEP_UM(acc); }
 #pragma unroll
-      for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_U(acc); }
+      for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_UM(acc); }
       m[k] = ((uint32_t)acc * P::INV) & MASK;
-      acc += (uint64_t)m[k] * P::mod(0); PCD_KEEP_U(acc);
+      acc += (uint64_t)m[k] * P::mod(0); PCD_KEEP_UM(acc);
       acc >>= 28;
     }
     Fp r;
 #pragma unroll
     for (int k = N; k < 2 * N - 1; k++) {
 #pragma unroll
-      for (int i = k - N + 1; 2 * i < k; i++) { acc += (uint64_t)a2[i] * a.v[k - i]; PCD_KEEP_U(acc); }
-      if ((k & 1) == 0) { acc += (uint64_t)a.v[k / 2] * a.v[k / 2]; PCD_KEEP_U(acc); }
+      for (int i = k - N + 1; 2 * i < k; i++) { acc += (uint64_t)a2[i] * a.v[k - i]; PCD_KEEP_UM(acc); }
+      if ((k & 1) == 0) { acc += (uint64_t)a.v[k / 2] * a.v[k / 2]; PCD_KEEP_UM(acc); }
 #pragma unroll
-      for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_U(acc); }
+      for (int i = k - N + 1; i < N; i++) { acc += (uint64_t)m[i] * P::mod(k - i); PCD_KEEP_UM(acc); }
       r.v[k - N] = (uint32_t)acc & MASK;
       acc >>= 28;
     }
