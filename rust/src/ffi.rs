@@ -49,6 +49,9 @@ extern "C" {
     pub fn pcdhip_g16_pk_upload(ctx: *mut pcdhip_ctx, host: *const pcdhip_g16_pk_host, out: *mut *mut pcdhip_g16_pk) -> c_int;
     pub fn pcdhip_g16_pk_set_r1cs(ctx: *mut pcdhip_ctx, pk: *mut pcdhip_g16_pk, a: *const pcdhip_csr, b: *const pcdhip_csr, c: *const pcdhip_csr) -> c_int;
     pub fn pcdhip_g16_pk_free(ctx: *mut pcdhip_ctx, pk: *mut pcdhip_g16_pk);
+    /// device bytes a resident key holds: out[0] ordinary copies, out[1] the second layout, out[2] / out[3] copies per point (what a host
+    /// that caches several keys budgets with: `prover::MAX_CACHED_KEYS`)
+    pub fn pcdhip_g16_pk_memory(pk: *const pcdhip_g16_pk, out: *mut u64) -> c_int;
     pub fn pcdhip_groth16_prove(ctx: *mut pcdhip_ctx, pk: *const pcdhip_g16_pk, a: *const pcdhip_csr, b: *const pcdhip_csr, c: *const pcdhip_csr,
                                 z: *const u64, r: *const u64, s: *const u64, proof: *mut u64, inf: *mut u8) -> c_int;
     // key memory: the second layout of a key's assignment queries (a window per proof; INTEGRATION.md "Key memory"): -1 automatic, 0 never, 6..22 bits
