@@ -165,18 +165,25 @@ def test_config4_merge_proof_2p22_sharded_equals_single_device(co, gpu_ctx, expe
     granted fewer than the G1 ones) -- and proves a witness-like assignment over the same key and matrices on those copies
     (pcdhip_groth16_last_plan), byte-equal to the oracle and to the eight shards (which fold the assembly products in and never take them)."""
     from pcd_amd import capi
+    import time
+    t_ = [time.perf_counter()]
+    def lap(what):
+        t_.append(time.perf_counter()); print(f"[2^22 merge test] {what}: {t_[-1] - t_[-2]:.1f} s", flush=True)
     curve = 2
     (r, keys, rs), want_fn = _merge_2p22_case(co)
+    lap("inputs (seeded R1CS + key, host)")
     assert keys.domain_size == 1 << 22
     oracle_proof, oracle_inf = expect("merge_proof_c2_2p22", want_fn)
     (rw, _, _), want_w_fn = _merge_2p22_witness_like_case_on(co, r, keys, rs)
     oracle_w, oracle_w_inf = expect("merge_proof_c2_2p22_witness_like", want_w_fn)
     one = capi.Context(0)
     try:
-        one.set_precompute_budget(24 << 30)        # (all 45 copies of one 2^22-point MNT4-753 query would be ~40 GB; five queries)
+        one.set_precompute_budget(12 << 30)        # (all 38 copies of one 2^22-point MNT4-753 G1 query would be ~40 GB, the G2 one twice that; five queries.
+                                                   #  12 GB per vector: 10 ordinary copies -- half the upload time of 24 GB, and the fewer-copies path all the same)
         one.groth16_set_sparse_window(13)
         pk = one.g16_pk_upload(keys.host_struct(), curve)
         one.groth16_set_sparse_window(0)
+        lap("single-device key upload (ordinary + shorter-window copies under the budget)")
         mem, plan = one.g16_pk_memory(pk), one.g16_pk_info(pk)
         print(f"2^22 MNT4-753 key on one device: {mem}, plan {plan}")
         assert 2 <= mem["copies"] < plan["a"][1] and mem["sparse_copies"] >= 2 and mem["sparse_window"] > 0   # fewer ordinary copies + the second layout
@@ -193,6 +200,7 @@ def test_config4_merge_proof_2p22_sharded_equals_single_device(co, gpu_ctx, expe
         pk.free()
     finally:
         one.close()
+    lap("single-device proofs (dense + witness-like)")
     assert np.array_equal(want, oracle_proof) and np.array_equal(winf, oracle_inf), "single-device 2^22 proof differs from the CPU oracle's"
     ndev = capi.lib().pcdhip_device_count()
     mctx = capi.Context(devices=_devices(8))
@@ -202,12 +210,14 @@ def test_config4_merge_proof_2p22_sharded_equals_single_device(co, gpu_ctx, expe
             mctx.msm_config(17, 0)                 # (a smaller window so that the bucket arrays of 8 x 7 MSMs fit beside the copies)
         mpk = mctx.g16_pk_upload(keys.host_struct(), curve)
         mctx.g16_pk_set_r1cs(mpk, r)
+        lap("eight-shard key upload")
         for _ in range(2):
             got, inf = mctx.groth16_prove(mpk, r, rs[0], rs[1], resident_r1cs=True)
             assert np.array_equal(got, want) and np.array_equal(inf, winf)
         got, inf = mctx.groth16_prove(mpk, rw, rs[0], rs[1], resident_r1cs=True)
         assert np.array_equal(got, oracle_w) and np.array_equal(inf, oracle_w_inf)
         assert mctx.groth16_last_plan() == (False, 0)
+        lap("eight-shard proofs (2 dense + 1 witness-like)")
         mpk.free()
     finally:
         mctx.close()
